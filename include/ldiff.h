@@ -1,0 +1,166 @@
+/* ldiff.h -- C ABI of libldiff_hip.so: the MI355X (gfx950) Laplace-diffusion sampling path.
+ *
+ * The reference (Lweihan/LDiffusion, /root/reference) has no FFI of its own: its sampler loops call
+ * duck-typed python objects from `diffusers`.  Each entry point below names the
+ * reference call it replaces (file:line into /root/reference); the python shims under ldiffusion_amd/ bind them with
+ * ctypes behind shim objects that keep the reference's attribute surface, and INTEGRATION.md shows
+ * the binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - every function returns 0 (LDIFF_OK) or a negative ldiff_status; the message of the last failure
+ *     on the calling thread is ldiff_last_error().  -1 = bad argument/shape (python: ValueError),
+ *     -2 = HIP runtime failure, -3 = handle not ready (weights/context missing) (python: RuntimeError).
+ *   - tensors crossing the boundary are plain device pointers in the layouts the reference uses:
+ *     float32, NCHW, contiguous (torch_dtype=torch.float32 everywhere: ldiffusion.py:67, segmentor.py:77).
+ *     Internally activations are NHWC fp16 with fp32 accumulation.
+ *   - handles own device weights and workspace; caller-owned buffers are never retained past a call.
+ *   - all work is enqueued on the caller's HIP stream (`stream` = hipStream_t, e.g. torch's current
+ *     stream); no hidden synchronisation.  A handle is thread-compatible, not thread-safe.
+ *   - there is no CPU fallback anywhere: a missing GPU or code object is an error.
+ */
+#ifndef LDIFF_H
+#define LDIFF_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LDIFF_VERSION 100 /* 0.1.0 */
+#define LDIFF_MAX_BLOCKS 8
+
+typedef enum { LDIFF_OK = 0, LDIFF_ERR_INVALID = -1, LDIFF_ERR_RUNTIME = -2, LDIFF_ERR_STATE = -3 } ldiff_status;
+typedef enum { LDIFF_F32 = 0, LDIFF_F16 = 1, LDIFF_BF16 = 2 } ldiff_dtype; /* host dtypes accepted by *_load */
+
+int ldiff_version(void);
+const char* ldiff_last_error(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * UNet2DConditionModel  --  replaces `unet(latents, t, text_embeddings)`
+ *   segmentor.py:103,444,526   pixel_latent_vector.py:78   ldiffusion.py:160,238   utils.py:201
+ * cfg mirrors diffusers' unet/config.json.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct ldiff_unet ldiff_unet;
+typedef struct {
+  int in_channels, out_channels;
+  int n_blocks;
+  int block_out_channels[LDIFF_MAX_BLOCKS];
+  int down_has_attn[LDIFF_MAX_BLOCKS]; /* CrossAttnDownBlock2D = 1, DownBlock2D = 0 */
+  int up_has_attn[LDIFF_MAX_BLOCKS];   /* CrossAttnUpBlock2D = 1, UpBlock2D = 0 */
+  int layers_per_block;
+  int heads;               /* config.json "attention_head_dim" (SD-v1.5: it is the head COUNT) */
+  int cross_attention_dim;
+  int norm_num_groups;
+  float norm_eps;
+  int flip_sin_to_cos;
+  float freq_shift;
+} ldiff_unet_cfg;
+
+int ldiff_unet_create(ldiff_unet** out, const ldiff_unet_cfg* cfg, int device);
+/* Copy one tensor of diffusion_pytorch_model.safetensors (diffusers key names, torch layouts) to the device.
+ * (from_pretrained: segmentor.py:79, ldiffusion.py:67) */
+int ldiff_unet_load(ldiff_unet*, const char* name, const void* host_ptr, int dtype, const int64_t* shape, int ndim);
+/* number of expected tensors not loaded yet; names via ldiff_unet_missing_name(i) */
+int ldiff_unet_missing(ldiff_unet*);
+const char* ldiff_unet_missing_name(ldiff_unet*, int i);
+/* encoder_hidden_states [B_ctx, L, cross_attention_dim] float32 on device; precomputes the cross-attention
+ * K/V of all transformer blocks (they do not depend on the timestep).  B_ctx is 1 (broadcast) or the batch. */
+int ldiff_unet_set_context(ldiff_unet*, const void* ctx_dev, int B_ctx, int L, void* stream);
+/* sample [B,in_channels,h,w] f32 NCHW -> out [B,out_channels,h,w] f32 NCHW */
+int ldiff_unet_forward(ldiff_unet*, const void* sample_dev, int B, int h, int w, float timestep, void* out_dev, void* stream);
+void ldiff_unet_destroy(ldiff_unet*);
+
+/* ------------------------------------------------------------------------------------------------
+ * AutoencoderKL  --  replaces vae.encode(x).latent_dist / vae.decode(z).sample / pipeline.decode_latents
+ *   segmentor.py:99,106,339,379,437,447,519,529  pixel_latent_vector.py:73,81  ldiffusion.py:228,240  utils.py:190,204
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct ldiff_vae ldiff_vae;
+typedef struct {
+  int in_channels, out_channels, latent_channels;
+  int n_blocks;
+  int block_out_channels[LDIFF_MAX_BLOCKS];
+  int layers_per_block;
+  int norm_num_groups;
+  float scaling_factor;
+} ldiff_vae_cfg;
+
+int ldiff_vae_create(ldiff_vae** out, const ldiff_vae_cfg* cfg, int device);
+int ldiff_vae_load(ldiff_vae*, const char* name, const void* host_ptr, int dtype, const int64_t* shape, int ndim);
+int ldiff_vae_missing(ldiff_vae*);
+const char* ldiff_vae_missing_name(ldiff_vae*, int i);
+/* x [B,3,H,W] f32 NCHW -> moments [B, 2*latent, H/8, W/8] f32 NCHW (mean | logvar), i.e. quant_conv(encoder(x)) */
+int ldiff_vae_encode(ldiff_vae*, const void* x_dev, int B, int H, int W, void* moments_dev, void* stream);
+/* z [B,latent,h,w] f32 NCHW, multiplied by z_scale first (decode_latents passes 1/scaling_factor, vae.decode passes 1).
+ * Any of the outputs may be NULL:
+ *   sample_nchw [B,3,8h,8w] f32            = vae.decode(z).sample
+ *   image_nhwc  [B,8h,8w,3] f32            = (sample/2+0.5).clamp(0,1)            (decode_latents)
+ *   rgb_u8      [B,8h,8w,3] u8             = (image*255).round()  half-even       (numpy_to_pil)
+ *   luma_u8     [B,n_slots,8h,8w] u8, slot = PIL convert("L") of rgb_u8           (pixel_latent_vector.py:85) */
+int ldiff_vae_decode(ldiff_vae*, const void* z_dev, int B, int h, int w, float z_scale, void* sample_nchw, void* image_nhwc,
+                     void* rgb_u8, void* luma_u8, int n_slots, int slot, void* stream);
+void ldiff_vae_destroy(ldiff_vae*);
+
+/* ------------------------------------------------------------------------------------------------
+ * Sampler arithmetic
+ * ---------------------------------------------------------------------------------------------- */
+/* PNDM/PLMS update as one linear combination out = sum_i coef[i] * ops[i] over n float32 elements
+ * (scheduler.step(...).prev_sample: segmentor.py:104,445,527  pixel_latent_vector.py:79); coefficients
+ * are computed on the host from alphas_cumprod exactly as PNDMScheduler._get_prev_sample does. */
+int ldiff_pndm_step(const float* coef, const void* const* ops, int nops, void* out, int64_t n, void* stream);
+/* alphas_cumprod table of the SD-v1.5 scheduler config (1000 float32) */
+int ldiff_pndm_alphas_cumprod(float* out_host, int n);
+/* out = z0 + Laplace(0, scale) given the uniform draw u (or u = NULL: counter-based Philox stream seed/offset)
+ * (ldiffusion.py:234-237; torch.distributions.Laplace.rsample) */
+int ldiff_laplace_add(const void* z0, float scale, const void* u_or_null, uint64_t seed, uint64_t offset, void* out, int64_t n, void* stream);
+/* logits [B,C,H,W] f32 -> mask [B,H,W] u8 = argmax over C  (segmentor.py:536-537) */
+int ldiff_argmax_u8(const void* logits, int B, int C, int H, int W, void* mask_u8, void* stream);
+/* rgb [B,3,H,W] f32 -> gray [B,1,H,W] f32 = (rgb*[0.2989,0.5870,0.1140]).sum(1)  (ldiffusion.py:241-242) */
+int ldiff_luma_float(const void* rgb_nchw, void* gray, int B, int H, int W, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Fused sampler  --  replaces the whole per-image loop body of
+ *   pixel_latent_vector.py:72-86 (mode LDIFF_SAMPLE_PLMS)  and  segmentor.py:99-107 / 519-530 (same, n_passes = 1)
+ * for a batch of B patches:  z = vae.encode(x).mean;  set_timesteps;  for t: eps = unet(z,t,ctx);
+ * z = scheduler.step(eps,t,z);  rgb = numpy_to_pil(decode_latents(z));  luma[:, pass] = convert("L").
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct ldiff_pipeline ldiff_pipeline;
+int ldiff_pipeline_create(ldiff_pipeline** out, ldiff_unet*, ldiff_vae*); /* borrows both handles */
+/* Replace the built-in alphas_cumprod table (1000 float32, host) with the caller's scheduler.alphas_cumprod
+ * (ldiffusion.py:198,234 reads that attribute); the built-in one agrees with torch's to ~2 ulp. */
+int ldiff_pipeline_set_alphas_cumprod(ldiff_pipeline*, const float* abar_host, int n);
+/* images [B,3,H,W] f32.  n_passes = number of UNet passes N (set_timesteps(N-1) for N >= 3, set_timesteps(1) for N = 1;
+ * N = 2 is rejected: the reference's set_timesteps(1) then yields a single pass, pixel_latent_vector.py:74).
+ * Outputs (any may be NULL): latents_out [B,latent,H/8,W/8] f32 (after the last pass),
+ * features_u8 [B,N,H,W] (luma of every pass), rgb_u8 [B,H,W,3] (last pass). */
+int ldiff_sample(ldiff_pipeline*, const void* images, int B, int H, int W, int n_passes, void* latents_out, void* features_u8,
+                 void* rgb_u8, void* stream);
+/* PLMS timesteps the sampler will visit for n_passes (host); returns the count written. */
+int ldiff_plms_timesteps(int n_passes, int64_t* out, int cap);
+void ldiff_pipeline_destroy(ldiff_pipeline*);
+
+/* ------------------------------------------------------------------------------------------------
+ * Single-kernel entry points (internal NHWC fp16 layout) -- used by the parity tests and the roofline
+ * bench so that every kernel is reachable through the C ABI.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+  const void* x;  const void* x2; int C1, C2;       /* NHWC f16 sources (x2 optional channel concat) */
+  int B, Hin, Win, Hout, Wout, ks, stride, pad_t, pad_l, ups;
+  const void* w;  int N, Nrows;                     /* [Nrows][ks*ks*(C1+C2)] f16, rows >= N zero */
+  const void* gn_scale; const void* gn_shift; int silu_in;   /* f32 [B, C1+C2] or NULL */
+  const void* bias;                                 /* f32 [Nrows] or NULL */
+  const void* temb; int ld_temb;                    /* f32 [B, ld_temb] or NULL */
+  const void* res; int ld_res;                      /* f16 [M, ld_res] or NULL */
+  void* y; int ldy; int out_f32;
+} ldiff_conv_args;
+int ldiff_op_conv(const ldiff_conv_args*, void* stream);
+int ldiff_op_attention(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, void* o, int ldo, int B, int heads,
+                       int Lq, int Lk, int d, int64_t q_bstride, int64_t kv_bstride, int64_t o_bstride, float scale, void* stream);
+int ldiff_op_gn_stats(const void* x, int C1, const void* x2, int C2, int B, int HW, int groups, float eps, const void* gamma,
+                      const void* beta, void* scale, void* shift, void* stream);
+int ldiff_op_layernorm(const void* x, void* y, int rows, int C, const void* gamma, const void* beta, float eps, void* stream);
+int ldiff_op_geglu(const void* x, void* y, int64_t M, int C4, void* stream);
+int ldiff_op_nchw_to_nhwc(const void* x_f32, void* y_f16, int B, int C, int H, int W, int Cpad, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LDIFF_H */

@@ -1,0 +1,333 @@
+// extern "C" boundary of libldiff_hip.so (see include/ldiff.h for the contract of every entry point).
+#include <string.h>
+
+#include <cmath>
+#include <exception>
+
+#include "model.h"
+
+const char* ldiff_error_message();
+
+#define API_BEGIN try {
+#define API_END                                                  \
+  }                                                              \
+  catch (const LdiffError& e) { return e.code; }                 \
+  catch (const std::exception& e) {                              \
+    ldiff_set_error("internal error: %s", e.what());             \
+    return LDIFF_ERR_RUNTIME;                                    \
+  }                                                              \
+  return LDIFF_OK;
+
+extern "C" {
+
+int ldiff_version(void) { return LDIFF_VERSION; }
+const char* ldiff_last_error(void) { return ldiff_error_message(); }
+
+// ---- UNet ----
+int ldiff_unet_create(ldiff_unet** out, const ldiff_unet_cfg* cfg, int device) {
+  API_BEGIN
+  LDIFF_CHECK(out && cfg, LDIFF_ERR_INVALID, "unet_create: null argument");
+  int ndev = 0;
+  HIP_CHECK(hipGetDeviceCount(&ndev));
+  LDIFF_CHECK(device >= 0 && device < ndev, LDIFF_ERR_INVALID, "unet_create: device %d not available (%d devices)", device, ndev);
+  HIP_CHECK(hipSetDevice(device));
+  ldiff_unet* u = new ldiff_unet();
+  u->cfg = *cfg;
+  u->device = device;
+  try { u->build(); } catch (...) { delete u; throw; }
+  *out = u;
+  API_END
+}
+int ldiff_unet_load(ldiff_unet* u, const char* name, const void* host_ptr, int dtype, const int64_t* shape, int ndim) {
+  API_BEGIN
+  LDIFF_CHECK(u, LDIFF_ERR_INVALID, "unet_load: null handle");
+  HIP_CHECK(hipSetDevice(u->device));
+  u->ws.load(name, host_ptr, dtype, shape, ndim);
+  API_END
+}
+int ldiff_unet_missing(ldiff_unet* u) { return u ? u->ws.missing() : -1; }
+const char* ldiff_unet_missing_name(ldiff_unet* u, int i) { return u ? u->ws.missing_name(i) : ""; }
+int ldiff_unet_set_context(ldiff_unet* u, const void* ctx_dev, int B_ctx, int L, void* stream) {
+  API_BEGIN
+  LDIFF_CHECK(u, LDIFF_ERR_INVALID, "unet_set_context: null handle");
+  u->set_context((const float*)ctx_dev, B_ctx, L, (hipStream_t)stream);
+  API_END
+}
+int ldiff_unet_forward(ldiff_unet* u, const void* sample_dev, int B, int h, int w, float timestep, void* out_dev, void* stream) {
+  API_BEGIN
+  LDIFF_CHECK(u, LDIFF_ERR_INVALID, "unet_forward: null handle");
+  u->ex.arena.reset();
+  u->forward((const float*)sample_dev, B, h, w, timestep, (float*)out_dev, (hipStream_t)stream);
+  API_END
+}
+void ldiff_unet_destroy(ldiff_unet* u) {
+  if (!u) return;
+  (void)hipSetDevice(u->device);
+  (void)hipDeviceSynchronize();
+  if (u->ctx_buf) (void)hipFree(u->ctx_buf);
+  delete u;
+}
+
+// ---- VAE ----
+int ldiff_vae_create(ldiff_vae** out, const ldiff_vae_cfg* cfg, int device) {
+  API_BEGIN
+  LDIFF_CHECK(out && cfg, LDIFF_ERR_INVALID, "vae_create: null argument");
+  int ndev = 0;
+  HIP_CHECK(hipGetDeviceCount(&ndev));
+  LDIFF_CHECK(device >= 0 && device < ndev, LDIFF_ERR_INVALID, "vae_create: device %d not available (%d devices)", device, ndev);
+  HIP_CHECK(hipSetDevice(device));
+  ldiff_vae* v = new ldiff_vae();
+  v->cfg = *cfg;
+  v->device = device;
+  try { v->build(); } catch (...) { delete v; throw; }
+  *out = v;
+  API_END
+}
+int ldiff_vae_load(ldiff_vae* v, const char* name, const void* host_ptr, int dtype, const int64_t* shape, int ndim) {
+  API_BEGIN
+  LDIFF_CHECK(v, LDIFF_ERR_INVALID, "vae_load: null handle");
+  HIP_CHECK(hipSetDevice(v->device));
+  v->ws.load(name, host_ptr, dtype, shape, ndim);
+  API_END
+}
+int ldiff_vae_missing(ldiff_vae* v) { return v ? v->ws.missing() : -1; }
+const char* ldiff_vae_missing_name(ldiff_vae* v, int i) { return v ? v->ws.missing_name(i) : ""; }
+int ldiff_vae_encode(ldiff_vae* v, const void* x_dev, int B, int H, int W, void* moments_dev, void* stream) {
+  API_BEGIN
+  LDIFF_CHECK(v, LDIFF_ERR_INVALID, "vae_encode: null handle");
+  v->ex.arena.reset();
+  v->encode((const float*)x_dev, B, H, W, (float*)moments_dev, (hipStream_t)stream);
+  API_END
+}
+int ldiff_vae_decode(ldiff_vae* v, const void* z_dev, int B, int h, int w, float z_scale, void* sample_nchw, void* image_nhwc, void* rgb_u8,
+                     void* luma_u8, int n_slots, int slot, void* stream) {
+  API_BEGIN
+  LDIFF_CHECK(v, LDIFF_ERR_INVALID, "vae_decode: null handle");
+  v->ex.arena.reset();
+  v->decode((const float*)z_dev, B, h, w, z_scale, (float*)sample_nchw, (float*)image_nhwc, (uint8_t*)rgb_u8, (uint8_t*)luma_u8, n_slots, slot,
+            (hipStream_t)stream);
+  API_END
+}
+void ldiff_vae_destroy(ldiff_vae* v) {
+  if (!v) return;
+  (void)hipSetDevice(v->device);
+  (void)hipDeviceSynchronize();
+  delete v;
+}
+
+// ---- sampler arithmetic ----
+int ldiff_pndm_step(const float* coef, const void* const* ops, int nops, void* out, int64_t n, void* stream) {
+  API_BEGIN
+  LDIFF_CHECK(coef && ops && out && n >= 0, LDIFF_ERR_INVALID, "pndm_step: bad arguments");
+  launch_lincomb(coef, ops, nops, (float*)out, n, (hipStream_t)stream);
+  API_END
+}
+int ldiff_pndm_alphas_cumprod(float* out_host, int n) {
+  API_BEGIN
+  LDIFF_CHECK(out_host && n == 1000, LDIFF_ERR_INVALID, "alphas_cumprod: n must be 1000");
+  pndm_alphas_cumprod(out_host);
+  API_END
+}
+int ldiff_laplace_add(const void* z0, float scale, const void* u, uint64_t seed, uint64_t offset, void* out, int64_t n, void* stream) {
+  API_BEGIN
+  LDIFF_CHECK(z0 && out && n >= 0, LDIFF_ERR_INVALID, "laplace_add: bad arguments");
+  LDIFF_CHECK(scale >= 0.f, LDIFF_ERR_INVALID, "laplace_add: scale must be >= 0 (got %g)", (double)scale);
+  launch_laplace_add((const float*)z0, scale, (const float*)u, seed, offset, (float*)out, n, (hipStream_t)stream);
+  API_END
+}
+int ldiff_argmax_u8(const void* logits, int B, int C, int H, int W, void* mask_u8, void* stream) {
+  API_BEGIN
+  LDIFF_CHECK(logits && mask_u8 && B >= 0 && H >= 0 && W >= 0, LDIFF_ERR_INVALID, "argmax: bad arguments");
+  launch_argmax_u8((const float*)logits, B, C, H, W, (uint8_t*)mask_u8, (hipStream_t)stream);
+  API_END
+}
+int ldiff_luma_float(const void* rgb_nchw, void* gray, int B, int H, int W, void* stream) {
+  API_BEGIN
+  LDIFF_CHECK(rgb_nchw && gray, LDIFF_ERR_INVALID, "luma_float: null argument");
+  launch_luma_float((const float*)rgb_nchw, (float*)gray, B, H, W, (hipStream_t)stream);
+  API_END
+}
+
+// ---- fused sampler ----
+int ldiff_pipeline_create(ldiff_pipeline** out, ldiff_unet* u, ldiff_vae* v) {
+  API_BEGIN
+  LDIFF_CHECK(out && u && v, LDIFF_ERR_INVALID, "pipeline_create: null argument");
+  LDIFF_CHECK(u->device == v->device, LDIFF_ERR_INVALID, "pipeline_create: unet and vae live on different devices");
+  LDIFF_CHECK(u->cfg.in_channels == v->cfg.latent_channels && u->cfg.out_channels == v->cfg.latent_channels, LDIFF_ERR_INVALID,
+              "pipeline_create: unet channels do not match the vae latent channels");
+  ldiff_pipeline* p = new ldiff_pipeline();
+  p->unet = u;
+  p->vae = v;
+  pndm_alphas_cumprod(p->abar);
+  *out = p;
+  API_END
+}
+int ldiff_pipeline_set_alphas_cumprod(ldiff_pipeline* p, const float* abar_host, int n) {
+  API_BEGIN
+  LDIFF_CHECK(p && abar_host && n == 1000, LDIFF_ERR_INVALID, "set_alphas_cumprod: need 1000 float32 values");
+  for (int i = 0; i < n; ++i) LDIFF_CHECK(abar_host[i] > 0.f && abar_host[i] <= 1.f, LDIFF_ERR_INVALID, "set_alphas_cumprod: value %d out of (0,1]", i);
+  memcpy(p->abar, abar_host, sizeof(float) * 1000);
+  API_END
+}
+int ldiff_plms_timesteps(int n_passes, int64_t* out, int cap) {
+  try { return plms_timesteps(n_passes, out, cap); } catch (const LdiffError& e) { return e.code; }
+}
+
+int ldiff_sample(ldiff_pipeline* p, const void* images, int B, int H, int W, int n_passes, void* latents_out, void* features_u8, void* rgb_u8,
+                 void* stream) {
+  API_BEGIN
+  LDIFF_CHECK(p && images, LDIFF_ERR_INVALID, "sample: null argument");
+  hipStream_t s = (hipStream_t)stream;
+  ldiff_unet* u = p->unet;
+  ldiff_vae* v = p->vae;
+  HIP_CHECK(hipSetDevice(u->device));
+  int64_t ts[1024];
+  const int nts = plms_timesteps(n_passes, ts, 1024);
+  const int f = 1 << (v->cfg.n_blocks - 1), lat = v->cfg.latent_channels;
+  LDIFF_CHECK(B >= 1 && H >= f && W >= f && H % f == 0 && W % f == 0, LDIFF_ERR_INVALID, "sample: bad batch/image size (B=%d, %dx%d)", B, H, W);
+  const int h = H / f, w = W / f;
+  const size_t nlat = (size_t)B * lat * h * w;
+  // workspace: moments (2x), latents ping-pong (2), cur_sample, eps history (4), fresh eps
+  p->arena.reserve((2 + 2 + 1 + 4 + 1) * nlat * sizeof(float) + 16 * 256);
+  p->arena.reset();
+  auto buf = [&]() { return (float*)p->arena.alloc(nlat * sizeof(float)); };
+  float* moments = (float*)p->arena.alloc(2 * nlat * sizeof(float));
+  float* z = buf();
+  float* znext = buf();
+  float* cur_sample = buf();
+  float* ets[4] = {buf(), buf(), buf(), buf()};
+  float* eps_new = buf();
+
+  // z = vae.encode(x).latent_dist.mean   (no scaling_factor: pixel_latent_vector.py:73)
+  v->ex.arena.reset();
+  v->encode((const float*)images, B, H, W, moments, s);
+  HIP_CHECK(hipMemcpy2DAsync(z, (size_t)lat * h * w * 4, moments, (size_t)2 * lat * h * w * 4, (size_t)lat * h * w * 4, B, hipMemcpyDeviceToDevice, s));
+
+  const int n_sched = n_passes == 1 ? 1 : n_passes - 1;
+  const int ratio = 1000 / n_sched;
+  int n_ets = 0, counter = 0;  // ets[0] is the oldest kept entry
+  for (int i = 0; i < nts; ++i) {
+    int t = (int)ts[i];
+    u->ex.arena.reset();
+    u->forward(z, B, h, w, (float)t, eps_new, s);
+    // ---- PNDMScheduler.step_plms ----
+    int prev_t = t - ratio;
+    const float* sample = z;
+    float wts[5] = {0, 0, 0, 0, 0};      // weights on {eps_new (when not stored), ets[-1], ets[-2], ets[-3], ets[-4]}
+    const float* opsrc[5] = {eps_new, nullptr, nullptr, nullptr, nullptr};
+    if (counter != 1) {
+      // ets = ets[-3:] + [eps_new]: rotate the ring so that ets[n_ets-1] is the newest
+      if (n_ets == 4) { float* old = ets[0]; ets[0] = ets[1]; ets[1] = ets[2]; ets[2] = ets[3]; ets[3] = old; n_ets = 3; }
+      std::swap(ets[n_ets], eps_new);     // store without copying; eps_new now names a free buffer
+      ++n_ets;
+    } else {
+      prev_t = t;
+      t = t + ratio;
+    }
+    int nops = 0;
+    float coef[6];
+    const void* ops[6];
+    if (n_ets == 1 && counter == 0) {
+      wts[1] = 1.f;
+      HIP_CHECK(hipMemcpyAsync(cur_sample, z, nlat * sizeof(float), hipMemcpyDeviceToDevice, s));
+    } else if (n_ets == 1 && counter == 1) {
+      wts[0] = 0.5f; wts[1] = 0.5f;       // (model_output + ets[-1]) / 2
+      sample = cur_sample;
+    } else if (n_ets == 2) { wts[1] = 3.f / 2.f; wts[2] = -1.f / 2.f; }
+    else if (n_ets == 3) { wts[1] = 23.f / 12.f; wts[2] = -16.f / 12.f; wts[3] = 5.f / 12.f; }
+    else { wts[1] = 55.f / 24.f; wts[2] = -59.f / 24.f; wts[3] = 37.f / 24.f; wts[4] = -9.f / 24.f; }
+    for (int k = 1; k <= 4; ++k) opsrc[k] = (n_ets - k >= 0) ? ets[n_ets - k] : nullptr;
+    // ---- _get_prev_sample: prev = sqrt(a_prev/a_t)*sample - (a_prev-a_t)*eps/(a_t*sqrt(1-a_prev)+sqrt(a_t*(1-a_t)*a_prev)) ----
+    const float a_t = p->abar[t], a_prev = prev_t >= 0 ? p->abar[prev_t] : p->abar[0];
+    const float b_t = 1.f - a_t, b_prev = 1.f - a_prev;
+    const float sample_coeff = sqrtf(a_prev / a_t);
+    const float denom = a_t * sqrtf(b_prev) + sqrtf(a_t * b_t * a_prev);
+    const float ce = -(a_prev - a_t) / denom;
+    coef[nops] = sample_coeff; ops[nops++] = sample;
+    for (int k = 0; k < 5; ++k)
+      if (wts[k] != 0.f) { coef[nops] = ce * wts[k]; ops[nops++] = opsrc[k]; }
+    launch_lincomb(coef, ops, nops, znext, (long long)nlat, s);
+    std::swap(z, znext);
+    ++counter;
+    // ---- decode_latents + numpy_to_pil + convert("L") ----
+    const bool last = i == nts - 1;
+    if (features_u8 || (last && rgb_u8)) {
+      v->ex.arena.reset();
+      v->decode(z, B, h, w, 1.0f / v->cfg.scaling_factor, nullptr, nullptr, last ? (uint8_t*)rgb_u8 : nullptr, (uint8_t*)features_u8, nts, i, s);
+    }
+  }
+  if (latents_out) HIP_CHECK(hipMemcpyAsync(latents_out, z, nlat * sizeof(float), hipMemcpyDeviceToDevice, s));
+  API_END
+}
+void ldiff_pipeline_destroy(ldiff_pipeline* p) {
+  if (!p) return;
+  (void)hipDeviceSynchronize();
+  delete p;
+}
+
+// ---- single-kernel entry points ----
+int ldiff_op_conv(const ldiff_conv_args* a, void* stream) {
+  API_BEGIN
+  LDIFF_CHECK(a && a->x && a->w && a->y, LDIFF_ERR_INVALID, "op_conv: null argument");
+  ConvParams p;
+  memset(&p, 0, sizeof(p));
+  p.x = (const f16*)a->x; p.x2 = (const f16*)a->x2; p.C1 = a->C1; p.C2 = a->C2;
+  p.B = a->B; p.Hin = a->Hin; p.Win = a->Win; p.Hout = a->Hout; p.Wout = a->Wout;
+  p.ks = a->ks; p.stride = a->stride; p.pad_t = a->pad_t; p.pad_l = a->pad_l; p.ups = a->ups;
+  LDIFF_CHECK((p.ks == 1 || p.ks == 3) && (p.stride == 1 || p.stride == 2) && (p.ups == 0 || p.ups == 1), LDIFF_ERR_INVALID,
+              "op_conv: unsupported ks=%d stride=%d ups=%d", p.ks, p.stride, p.ups);
+  p.w = (const f16*)a->w; p.N = a->N; p.Nrows = a->Nrows; p.K = a->ks * a->ks * (a->C1 + a->C2);
+  p.gn_scale = (const float*)a->gn_scale; p.gn_shift = (const float*)a->gn_shift; p.silu_in = a->silu_in;
+  p.bias = (const float*)a->bias; p.temb = (const float*)a->temb; p.ld_temb = a->ld_temb;
+  p.res = (const f16*)a->res; p.ld_res = a->ld_res;
+  p.y = a->y; p.ldy = a->ldy; p.out_f32 = a->out_f32;
+  p.M = a->B * a->Hout * a->Wout;
+  launch_igemm(p, (hipStream_t)stream);
+  API_END
+}
+int ldiff_op_attention(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, void* o, int ldo, int B, int heads, int Lq,
+                       int Lk, int d, int64_t q_bstride, int64_t kv_bstride, int64_t o_bstride, float scale, void* stream) {
+  API_BEGIN
+  LDIFF_CHECK(q && k && v && o && B >= 1 && heads >= 1, LDIFF_ERR_INVALID, "op_attention: bad arguments");
+  AttnParams p;
+  p.q = (const f16*)q; p.ldq = ldq; p.k = (const f16*)k; p.ldk = ldk; p.v = (const f16*)v; p.ldv = ldv; p.o = (f16*)o; p.ldo = ldo;
+  p.B = B; p.heads = heads; p.Lq = Lq; p.Lk = Lk; p.d = d;
+  p.q_bstride = q_bstride; p.kv_bstride = kv_bstride; p.o_bstride = o_bstride; p.scale = scale;
+  launch_attention(p, (hipStream_t)stream);
+  API_END
+}
+int ldiff_op_gn_stats(const void* x, int C1, const void* x2, int C2, int B, int HW, int groups, float eps, const void* gamma, const void* beta,
+                      void* scale, void* shift, void* stream) {
+  API_BEGIN
+  LDIFF_CHECK(x && gamma && beta && scale && shift && B >= 1 && HW >= 1 && groups >= 1, LDIFF_ERR_INVALID, "op_gn_stats: bad arguments");
+  const size_t bytes = gn_partial_bytes(B, HW, C1 + C2);
+  float* partial = nullptr;
+  HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&partial), bytes));
+  try {
+    launch_gn_stats((const f16*)x, C1, (const f16*)x2, C2, B, HW, groups, eps, (const float*)gamma, (const float*)beta, partial, bytes,
+                    (float*)scale, (float*)shift, (hipStream_t)stream);
+  } catch (...) { (void)hipFree(partial); throw; }
+  HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
+  HIP_CHECK(hipFree(partial));
+  API_END
+}
+int ldiff_op_layernorm(const void* x, void* y, int rows, int C, const void* gamma, const void* beta, float eps, void* stream) {
+  API_BEGIN
+  LDIFF_CHECK(x && y && gamma && beta, LDIFF_ERR_INVALID, "op_layernorm: null argument");
+  launch_layernorm((const f16*)x, (f16*)y, rows, C, (const float*)gamma, (const float*)beta, eps, (hipStream_t)stream);
+  API_END
+}
+int ldiff_op_geglu(const void* x, void* y, int64_t M, int C4, void* stream) {
+  API_BEGIN
+  LDIFF_CHECK(x && y, LDIFF_ERR_INVALID, "op_geglu: null argument");
+  launch_geglu((const f16*)x, (f16*)y, M, C4, (hipStream_t)stream);
+  API_END
+}
+int ldiff_op_nchw_to_nhwc(const void* x_f32, void* y_f16, int B, int C, int H, int W, int Cpad, void* stream) {
+  API_BEGIN
+  LDIFF_CHECK(x_f32 && y_f16, LDIFF_ERR_INVALID, "op_nchw_to_nhwc: null argument");
+  launch_nchw_f32_to_nhwc_f16((const float*)x_f32, (f16*)y_f16, B, C, H, W, Cpad, (hipStream_t)stream);
+  API_END
+}
+
+}  // extern "C"

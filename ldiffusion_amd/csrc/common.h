@@ -1,0 +1,124 @@
+// Shared declarations for the gfx950 (MI355X / CDNA4) kernels and the host-side executors.
+// Everything here is internal to libldiff_hip.so; the public boundary is include/ldiff.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+#include <vector>
+
+typedef _Float16 f16;
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+// ---- status / error reporting (thread-local message; status codes from include/ldiff.h) ----------
+#include "../../include/ldiff.h"
+void ldiff_set_error(const char* fmt, ...);
+
+struct LdiffError {
+  int code;
+};
+#define LDIFF_CHECK(cond, code, ...)     \
+  do {                                   \
+    if (!(cond)) {                       \
+      ldiff_set_error(__VA_ARGS__);      \
+      throw LdiffError{code};            \
+    }                                    \
+  } while (0)
+#define HIP_CHECK(expr)                                                                     \
+  do {                                                                                      \
+    hipError_t _e = (expr);                                                                 \
+    if (_e != hipSuccess) {                                                                 \
+      ldiff_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+      throw LdiffError{LDIFF_ERR_RUNTIME};                                                  \
+    }                                                                                       \
+  } while (0)
+
+// ---- implicit-GEMM convolution / linear (kernels_igemm.hip) ---------------------------------
+// y[m, n] = sum_k A[m, k] * W[n, k]  (+ bias[n] + temb[b(m), n] + res[m, n])
+//   A is the im2col view of one or two NHWC fp16 tensors (channel concat), optionally nearest-2x
+//   upsampled, optionally with GroupNorm-apply (+SiLU) folded into the load:  a = silu(x*scale[b,c]+shift[b,c]).
+//   k = (ky*ks + kx) * Cin + c,  Cin = C1 + C2.
+struct ConvParams {
+  const f16* x;      // [B, Hin, Win, C1]
+  const f16* x2;     // [B, Hin, Win, C2] or nullptr
+  int C1, C2;        // multiples of 8
+  int B, Hin, Win;   // source spatial size (before the optional 2x upsample)
+  int Hout, Wout;
+  int ks, stride, pad_t, pad_l, ups;
+  const f16* w;      // [Nrows, K] K-major, Nrows = roundup(N,16), rows >= N zero
+  int N, Nrows, K;   // N = columns stored (multiple of 4)
+  const float* gn_scale;  // [B, Cin] or nullptr
+  const float* gn_shift;  // [B, Cin]
+  int silu_in;            // apply SiLU after the affine (only with gn_scale)
+  const float* bias;      // [Nrows] or nullptr
+  const float* temb;      // [B, ld_temb] (+ column offset applied by caller) or nullptr
+  int ld_temb;
+  const f16* res;         // [M, ld_res] or nullptr
+  int ld_res;
+  void* y;                // [M, ldy] fp16 or fp32
+  int ldy;
+  int out_f32;
+  int M;                  // B*Hout*Wout
+};
+void launch_igemm(const ConvParams& p, hipStream_t s);
+
+// ---- attention (kernels_attn.hip) ------------------------------------------------------------
+// O[b, q, h*d + :] = softmax(Q K^T / sqrt(d)) V   per (b, head).   All fp16, row strides in elements.
+struct AttnParams {
+  const f16* q; int ldq;      // [B, Lq, ldq], head h at column h*d
+  const f16* k; int ldk;      // [Bk, Lk, ldk]
+  const f16* v; int ldv;
+  f16* o; int ldo;            // [B, Lq, ldo]
+  int B, heads, Lq, Lk, d;
+  long long q_bstride, kv_bstride, o_bstride;  // batch strides in elements (kv_bstride 0 => broadcast)
+  float scale;
+};
+void launch_attention(const AttnParams& p, hipStream_t s);
+
+// ---- normalisation (kernels_norm.hip) --------------------------------------------------------
+// GroupNorm statistics over one or two NHWC sources (channel concat) -> per-(b,c) scale/shift (fp32):
+//   scale = rstd*gamma, shift = beta - mean*rstd*gamma   so that  gn(x) = x*scale + shift.
+void launch_gn_stats(const f16* x, int C1, const f16* x2, int C2, int B, int HW, int groups, float eps,
+                     const float* gamma, const float* beta, float* partial /*workspace*/, size_t partial_bytes,
+                     float* scale, float* shift, hipStream_t s);
+size_t gn_partial_bytes(int B, int HW, int C);
+void launch_layernorm(const f16* x, f16* y, int rows, int C, const float* gamma, const float* beta, float eps, hipStream_t s);
+
+// ---- elementwise / layout / sampler arithmetic (kernels_elem.hip) ----------------------------
+void launch_nchw_f32_to_nhwc_f16(const float* x, f16* y, int B, int C, int H, int W, int Cpad, hipStream_t s);
+void launch_nhwc_f32_to_nchw_f32(const float* x, float* y, int B, int C, int H, int W, int ldx, hipStream_t s);
+void launch_geglu(const f16* x, f16* y, long long M, int C4, hipStream_t s);  // x [M, 2*C4] -> y [M, C4]
+void launch_timestep_embed(float t, f16* y, int B, int dim, int flip_sin_to_cos, float freq_shift, hipStream_t s);
+void launch_silu_f32_to_f16(const float* x, f16* y, long long n, hipStream_t s);
+void launch_lincomb(const float* coef, const void* const* ops, int nops, float* out, long long n, hipStream_t s);
+void launch_laplace_add(const float* z0, float scale, const float* u, unsigned long long seed, unsigned long long offset,
+                        float* out, long long n, hipStream_t s);
+void launch_scale_f32(const float* x, float* y, float a, long long n, hipStream_t s);
+void launch_decode_post(const float* x, int ldx, int B, int H, int W, float* img_f32 /*[B,H,W,3] or null*/,
+                        uint8_t* rgb_u8 /*[B,H,W,3] or null*/, uint8_t* luma /*base of [B,N,H,W] or null*/, int n_slots, int slot,
+                        hipStream_t s);
+void launch_argmax_u8(const float* logits, int B, int C, int H, int W, uint8_t* mask, hipStream_t s);
+void launch_luma_float(const float* rgb_nchw, float* gray, int B, int H, int W, hipStream_t s);
+
+// ---- device arena: bump/free-list allocator over one hipMalloc'd slab ------------------------
+// No hipMalloc/hipFree in a forward pass (graph-capturable, no implicit syncs).  Stream-ordered reuse:
+// all kernels of one handle run on one stream, so a block may be reused as soon as it is released on the host.
+class Arena {
+ public:
+  ~Arena();
+  void reserve(size_t bytes);       // (re)allocate the slab if smaller; only outside a forward
+  void* alloc(size_t bytes);
+  void free(void* p);
+  void reset();
+  size_t capacity() const { return cap_; }
+  size_t high_water() const { return high_; }
+
+ private:
+  struct Block { size_t off, size; bool used; };
+  char* base_ = nullptr;
+  size_t cap_ = 0, high_ = 0;
+  std::vector<Block> blocks_;
+};

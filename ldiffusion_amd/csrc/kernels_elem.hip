@@ -1,0 +1,242 @@
+// Elementwise / layout / sampler-arithmetic kernels for gfx950 (MI355X).  All HBM- or latency-bound.
+// Each kernel names the reference expression it replaces (file:line into /root/reference).
+#include "common.h"
+
+static inline int nblocks(long long n, int per = 256) { return (int)((n + per - 1) / per); }
+
+// ---- boundary layout: torch NCHW fp32 <-> internal NHWC fp16 ------------------------------------
+__global__ void nchw_f32_to_nhwc_f16_kernel(const float* __restrict__ x, f16* __restrict__ y, int B, int C, int HW, int Cpad) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long long)B * HW) return;
+  int b = (int)(i / HW), pix = (int)(i - (long long)b * HW);
+  const float* src = x + (long long)b * C * HW + pix;
+  f16* dst = y + i * Cpad;
+  for (int c0 = 0; c0 < Cpad; c0 += 8) {
+    f16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (c0 + j < C) ? (f16)src[(long long)(c0 + j) * HW] : (f16)0.f;
+    *reinterpret_cast<uint4*>(dst + c0) = __builtin_bit_cast(uint4, o);
+  }
+}
+void launch_nchw_f32_to_nhwc_f16(const float* x, f16* y, int B, int C, int H, int W, int Cpad, hipStream_t s) {
+  LDIFF_CHECK(Cpad % 8 == 0 && Cpad >= C, LDIFF_ERR_INVALID, "layout: Cpad=%d must be a multiple of 8 and >= C=%d", Cpad, C);
+  long long n = (long long)B * H * W;
+  if (n == 0) return;
+  hipLaunchKernelGGL(nchw_f32_to_nhwc_f16_kernel, dim3(nblocks(n)), dim3(256), 0, s, x, y, B, C, H * W, Cpad);
+  HIP_CHECK(hipGetLastError());
+}
+
+__global__ void nhwc_f32_to_nchw_f32_kernel(const float* __restrict__ x, float* __restrict__ y, int B, int C, int HW, int ldx) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long long)B * C * HW) return;
+  int pix = (int)(i % HW);
+  long long bc = i / HW;
+  int c = (int)(bc % C), b = (int)(bc / C);
+  y[i] = x[((long long)b * HW + pix) * ldx + c];
+}
+void launch_nhwc_f32_to_nchw_f32(const float* x, float* y, int B, int C, int H, int W, int ldx, hipStream_t s) {
+  long long n = (long long)B * C * H * W;
+  if (n == 0) return;
+  hipLaunchKernelGGL(nhwc_f32_to_nchw_f32_kernel, dim3(nblocks(n)), dim3(256), 0, s, x, y, B, C, H * W, ldx);
+  HIP_CHECK(hipGetLastError());
+}
+
+// ---- GEGLU: h * gelu_erf(gate)   (diffusers GEGLU inside FeedForward; BasicTransformerBlock.ff) ----
+__global__ void geglu_kernel(const f16* __restrict__ x, f16* __restrict__ y, long long M, int C4) {
+  const int cpr = C4 >> 3;
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= M * cpr) return;
+  long long m = i / cpr;
+  int cc = (int)(i - m * cpr);
+  const f16* row = x + m * 2 * C4;
+  f16x8 hv = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(row + cc * 8));
+  f16x8 gv = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(row + C4 + cc * 8));
+  f16x8 o;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    float gte = (float)gv[j];
+    float ge = 0.5f * gte * (1.0f + erff(gte * 0.70710678118654752f));
+    o[j] = (f16)((float)hv[j] * ge);
+  }
+  *reinterpret_cast<uint4*>(y + m * C4 + cc * 8) = __builtin_bit_cast(uint4, o);
+}
+void launch_geglu(const f16* x, f16* y, long long M, int C4, hipStream_t s) {
+  LDIFF_CHECK(C4 % 8 == 0, LDIFF_ERR_INVALID, "geglu: inner dim %d must be a multiple of 8", C4);
+  long long n = M * (C4 >> 3);
+  if (n == 0) return;
+  hipLaunchKernelGGL(geglu_kernel, dim3(nblocks(n)), dim3(256), 0, s, x, y, M, C4);
+  HIP_CHECK(hipGetLastError());
+}
+
+// ---- sinusoidal timestep embedding (diffusers get_timestep_embedding) ------------------
+__global__ void timestep_embed_kernel(float tval, f16* __restrict__ y, int B, int dim, int flip, float freq_shift) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int half = dim / 2;
+  if (i >= B * half) return;
+  int b = i / half, k = i - b * half;
+  float exponent = (-9.210340371976184f * (float)k) / ((float)half - freq_shift);  // -ln(10000) * k / (half - shift)
+  float arg = tval * expf(exponent);
+  float sn = sinf(arg), cs = cosf(arg);
+  f16* row = y + (long long)b * dim;
+  if (flip) { row[k] = (f16)cs; row[half + k] = (f16)sn; }
+  else { row[k] = (f16)sn; row[half + k] = (f16)cs; }
+}
+void launch_timestep_embed(float t, f16* y, int B, int dim, int flip, float freq_shift, hipStream_t s) {
+  hipLaunchKernelGGL(timestep_embed_kernel, dim3(nblocks((long long)B * dim / 2)), dim3(256), 0, s, t, y, B, dim, flip, freq_shift);
+  HIP_CHECK(hipGetLastError());
+}
+
+__global__ void silu_f32_to_f16_kernel(const float* __restrict__ x, f16* __restrict__ y, long long n) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float v = x[i];
+  y[i] = (f16)(v / (1.0f + expf(-v)));
+}
+void launch_silu_f32_to_f16(const float* x, f16* y, long long n, hipStream_t s) {
+  if (n == 0) return;
+  hipLaunchKernelGGL(silu_f32_to_f16_kernel, dim3(nblocks(n)), dim3(256), 0, s, x, y, n);
+  HIP_CHECK(hipGetLastError());
+}
+
+// ---- PNDM/PLMS update as one linear combination (scheduler.step; segmentor.py:104, pixel_latent_vector.py:79) ----
+struct LinComb { float c[6]; const float* p[6]; int n; };
+__global__ void lincomb_kernel(LinComb a, float* __restrict__ out, long long n) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float v = 0.f;
+#pragma unroll
+  for (int k = 0; k < 6; ++k)
+    if (k < a.n) v += a.c[k] * a.p[k][i];
+  out[i] = v;
+}
+void launch_lincomb(const float* coef, const void* const* ops, int nops, float* out, long long n, hipStream_t s) {
+  LDIFF_CHECK(nops >= 1 && nops <= 6, LDIFF_ERR_INVALID, "lincomb: nops=%d out of range [1,6]", nops);
+  if (n == 0) return;
+  LinComb a;
+  a.n = nops;
+  for (int k = 0; k < 6; ++k) { a.c[k] = k < nops ? coef[k] : 0.f; a.p[k] = k < nops ? (const float*)ops[k] : nullptr; }
+  hipLaunchKernelGGL(lincomb_kernel, dim3(nblocks(n)), dim3(256), 0, s, a, out, n);
+  HIP_CHECK(hipGetLastError());
+}
+
+// ---- Laplace forward noise (ldiffusion.py:234-237; torch.distributions.Laplace.rsample) ----
+// x = z0 - scale * sign(u) * log1p(-|u|),  u ~ U(eps_f32 - 1, 1).  `u` may be supplied (parity is defined
+// given u) or drawn from a counter-based Philox4x32-10 stream keyed by (seed, offset + element index / 4).
+__device__ __forceinline__ void philox4x32_10(unsigned long long ctr, unsigned long long key, unsigned out[4]) {
+  unsigned c0 = (unsigned)ctr, c1 = (unsigned)(ctr >> 32), c2 = 0, c3 = 0;
+  unsigned k0 = (unsigned)key, k1 = (unsigned)(key >> 32);
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    unsigned long long p0 = (unsigned long long)0xD2511F53u * c0, p1 = (unsigned long long)0xCD9E8D57u * c2;
+    unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0, n1 = (unsigned)p1, n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1, n3 = (unsigned)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+__global__ void laplace_add_kernel(const float* __restrict__ z0, float scale, const float* __restrict__ u, unsigned long long seed,
+                                   unsigned long long offset, float* __restrict__ out, long long n) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float uv;
+  if (u) uv = u[i];
+  else {
+    unsigned r[4];
+    philox4x32_10(offset + (unsigned long long)(i >> 2), seed, r);
+    float f = (float)(r[i & 3] >> 8) * (1.0f / 16777216.0f);           // [0,1) with 24 bits
+    const float lo = 1.1920928955078125e-07f - 1.0f;                   // finfo(float32).eps - 1
+    uv = lo + f * (1.0f - lo);
+  }
+  float sgn = (uv > 0.f) ? 1.f : ((uv < 0.f) ? -1.f : 0.f);
+  out[i] = z0[i] + (0.f - scale * sgn * log1pf(-fabsf(uv)));
+}
+void launch_laplace_add(const float* z0, float scale, const float* u, unsigned long long seed, unsigned long long offset, float* out,
+                        long long n, hipStream_t s) {
+  if (n == 0) return;
+  hipLaunchKernelGGL(laplace_add_kernel, dim3(nblocks(n)), dim3(256), 0, s, z0, scale, u, seed, offset, out, n);
+  HIP_CHECK(hipGetLastError());
+}
+
+__global__ void scale_f32_kernel(const float* __restrict__ x, float* __restrict__ y, float a, long long n) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) y[i] = a * x[i];
+}
+void launch_scale_f32(const float* x, float* y, float a, long long n, hipStream_t s) {
+  if (n == 0) return;
+  hipLaunchKernelGGL(scale_f32_kernel, dim3(nblocks(n)), dim3(256), 0, s, x, y, a, n);
+  HIP_CHECK(hipGetLastError());
+}
+
+// ---- decode post-process + uint8 + luma feature slot --------------------------------------------
+// decode_latents tail  (x/2+0.5).clamp(0,1)                       -> img_f32 [B,H,W,3]   (segmentor.py:106)
+// numpy_to_pil         (img*255).round().astype(uint8), half-even -> rgb_u8  [B,H,W,3]   (segmentor.py:107)
+// PIL convert("L")     (19595R + 38470G + 7471B + 0x8000) >> 16   -> luma[b, slot, h, w] (pixel_latent_vector.py:85)
+__global__ void decode_post_kernel(const float* __restrict__ x, int ldx, long long npix, int HW, float* __restrict__ img,
+                                   uint8_t* __restrict__ rgb, uint8_t* __restrict__ luma, int n_slots, int slot) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= npix) return;
+  const float* px = x + i * ldx;
+  unsigned q[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    float v = __fadd_rn(__fmul_rn(px[c], 0.5f), 0.5f);
+    v = fminf(fmaxf(v, 0.f), 1.f);
+    if (px[c] != px[c]) v = px[c];  // clamp propagates NaN in torch
+    if (img) img[i * 3 + c] = v;
+    q[c] = (unsigned)(int)rintf(__fmul_rn(v, 255.0f));
+  }
+  if (rgb) { rgb[i * 3 + 0] = (uint8_t)q[0]; rgb[i * 3 + 1] = (uint8_t)q[1]; rgb[i * 3 + 2] = (uint8_t)q[2]; }
+  if (luma) {
+    long long b = i / HW, pix = i - b * HW;
+    luma[(b * n_slots + slot) * HW + pix] = (uint8_t)((19595u * q[0] + 38470u * q[1] + 7471u * q[2] + 0x8000u) >> 16);
+  }
+}
+void launch_decode_post(const float* x, int ldx, int B, int H, int W, float* img_f32, uint8_t* rgb_u8, uint8_t* luma, int n_slots, int slot,
+                        hipStream_t s) {
+  LDIFF_CHECK(!luma || (slot >= 0 && slot < n_slots), LDIFF_ERR_INVALID, "decode_post: slot %d out of range [0,%d)", slot, n_slots);
+  long long n = (long long)B * H * W;
+  if (n == 0) return;
+  hipLaunchKernelGGL(decode_post_kernel, dim3(nblocks(n)), dim3(256), 0, s, x, ldx, n, H * W, img_f32, rgb_u8, luma, n_slots, slot);
+  HIP_CHECK(hipGetLastError());
+}
+
+// ---- mask tail: argmax over classes (segmentor.py:536; softmax is monotone) ----------------------
+__global__ void argmax_u8_kernel(const float* __restrict__ logits, int B, int C, int HW, uint8_t* __restrict__ mask) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long long)B * HW) return;
+  int b = (int)(i / HW), pix = (int)(i - (long long)b * HW);
+  const float* p = logits + (long long)b * C * HW + pix;
+  float best = p[0];
+  int bi = 0;
+  for (int c = 1; c < C; ++c) {
+    float v = p[(long long)c * HW];
+    // torch.argmax: first maximal element; NaN compares as the maximum
+    if ((v > best) || (v != v && best == best)) { best = v; bi = c; }
+  }
+  mask[i] = (uint8_t)bi;
+}
+void launch_argmax_u8(const float* logits, int B, int C, int H, int W, uint8_t* mask, hipStream_t s) {
+  LDIFF_CHECK(C >= 1 && C <= 256, LDIFF_ERR_INVALID, "argmax: class count %d out of range [1,256]", C);
+  long long n = (long long)B * H * W;
+  if (n == 0) return;
+  hipLaunchKernelGGL(argmax_u8_kernel, dim3(nblocks(n)), dim3(256), 0, s, logits, B, C, H * W, mask);
+  HIP_CHECK(hipGetLastError());
+}
+
+// ---- float luma of the training-time features (ldiffusion.py:241-242) ---------------------------
+__global__ void luma_float_kernel(const float* __restrict__ rgb, float* __restrict__ gray, int B, int HW) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long long)B * HW) return;
+  int b = (int)(i / HW), pix = (int)(i - (long long)b * HW);
+  const float* p = rgb + (long long)b * 3 * HW + pix;
+  float acc = __fmul_rn(p[0], 0.2989f);
+  acc = __fadd_rn(acc, __fmul_rn(p[HW], 0.5870f));
+  acc = __fadd_rn(acc, __fmul_rn(p[2LL * HW], 0.1140f));
+  gray[i] = acc;
+}
+void launch_luma_float(const float* rgb_nchw, float* gray, int B, int H, int W, hipStream_t s) {
+  long long n = (long long)B * H * W;
+  if (n == 0) return;
+  hipLaunchKernelGGL(luma_float_kernel, dim3(nblocks(n)), dim3(256), 0, s, rgb_nchw, gray, B, H * W);
+  HIP_CHECK(hipGetLastError());
+}

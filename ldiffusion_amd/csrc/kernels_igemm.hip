@@ -1,0 +1,242 @@
+// Implicit-GEMM convolution / linear for gfx950 (MI355X): fp16 operands, fp32 accumulate on MFMA 16x16x32.
+//
+// One kernel family covers every contraction of the sampling path except attention:
+//   conv3x3 (stride 1/2, symmetric or VAE-asymmetric padding, optional nearest-2x upsample gather,
+//   optional two-source channel concat), conv1x1 and nn.Linear (ks=1), with
+//   - GroupNorm-apply (+SiLU) folded into the A-tile load (statistics come from kernels_norm.hip),
+//   - bias / per-(batch,channel) time-embedding / residual folded into the epilogue.
+// Replaces the ATen conv2d / linear calls made inside diffusers' ResnetBlock2D, Transformer2DModel,
+// Downsample2D, Upsample2D (reached from /root/reference/segmentor.py:103,526 and pixel_latent_vector.py:78,81).
+//
+// Layout: activations NHWC fp16 (channels % 8 == 0), weights [N][ky][kx][Cin] fp16 (K-major rows).
+// Tiling: BM x BN x 64 per 256-thread workgroup (4 waves as 2x2), double-buffered LDS, register-staged
+// loads issued before the MFMA phase and written to LDS after it (one barrier per K-step).
+// The MFMA computes C^T (A-operand = weight rows, B-operand = activation rows) so that each lane ends up
+// holding 4 consecutive output channels of one pixel -> 8-byte epilogue loads/stores.
+// LDS rows are 128 B; 16-byte chunks are XOR-swizzled with (row>>1)&7, which makes every ds_read_b128
+// lane group of the 16x16x32 operand fetch conflict-free (bank math in DESIGN.md).
+#include "common.h"
+
+#define BK 64
+#define CPR (BK / 8)  // 16-byte chunks per tile row
+
+__device__ __forceinline__ int swz(int row, int chunk) { return chunk ^ ((row >> 1) & 7); }
+
+__device__ __forceinline__ float silu_f(float v) { return v * __frcp_rn(1.0f + __expf(-v)); }
+
+__device__ __forceinline__ uint4 gn_apply8(uint4 raw, const float* __restrict__ sc, const float* __restrict__ sh, int silu) {
+  f16x8 h = __builtin_bit_cast(f16x8, raw);
+  float4 s0 = *reinterpret_cast<const float4*>(sc), s1 = *reinterpret_cast<const float4*>(sc + 4);
+  float4 t0 = *reinterpret_cast<const float4*>(sh), t1 = *reinterpret_cast<const float4*>(sh + 4);
+  float sv[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+  float tv[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
+  f16x8 o;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    float v = (float)h[j] * sv[j] + tv[j];
+    if (silu) v = silu_f(v);
+    o[j] = (f16)v;
+  }
+  return __builtin_bit_cast(uint4, o);
+}
+
+template <int BM, int BN, bool FAST, bool GN>
+__global__ __launch_bounds__(256) void igemm_kernel(const ConvParams p) {
+  constexpr int MT = BM / 32, NT = BN / 32;       // 16x16 tiles per wave along m / n (wave tile = BM/2 x BN/2)
+  constexpr int A_IT = BM * CPR / 256, B_IT = BN * CPR / 256;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  uint4* sA = reinterpret_cast<uint4*>(smem_raw);              // [2][BM*CPR]
+  uint4* sB = sA + 2 * BM * CPR;                               // [2][BN*CPR]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wave_m = wave >> 1, wave_n = wave & 1;
+  const int Cin = p.C1 + p.C2;
+  const int ntn = (p.N + BN - 1) / BN;
+
+  // XCD-aware tile order: workgroups that share an XCD (blockIdx % 8) walk consecutive tiles, so the
+  // n-tiles of one m-tile (same activation rows, all 9 taps) hit the same 4 MiB L2.
+  int nwg = gridDim.x, id = blockIdx.x;
+  int q8 = nwg >> 3, r8 = nwg & 7, xcd = id & 7, idx = id >> 3;
+  int sw = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
+  const int m0 = (sw / ntn) * BM, n0 = (sw % ntn) * BN;
+
+  // ---- per-thread A rows (fixed over the K loop) ----
+  const int kc = tid & (CPR - 1);
+  int rb[A_IT], ry[A_IT], rx[A_IT];
+  const int HWo = p.Hout * p.Wout;
+#pragma unroll
+  for (int i = 0; i < A_IT; ++i) {
+    int m = m0 + (tid >> 3) + i * 32;
+    if (m < p.M) {
+      int b = m / HWo, rem = m - b * HWo;
+      int oy = rem / p.Wout, ox = rem - oy * p.Wout;
+      rb[i] = b; ry[i] = oy * p.stride - p.pad_t; rx[i] = ox * p.stride - p.pad_l;
+    } else { rb[i] = -1; ry[i] = 0; rx[i] = 0; }
+  }
+  const int He = p.Hin << p.ups, We = p.Win << p.ups;
+
+  uint4 ra[A_IT], rw[B_IT];
+  int gidx[A_IT];  // b*Cin + c of the chunk (GN path), -1 when the chunk is padding
+
+  auto load_tiles = [&](int kt) {
+    const int kbase = kt * BK;
+    int tap_u = 0, cb_u = 0;
+    if (FAST) { tap_u = kbase / Cin; cb_u = kbase - tap_u * Cin; }
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+      int tap, c;
+      bool kval = true;
+      if (FAST) { tap = tap_u; c = cb_u + kc * 8; }
+      else {
+        int k0 = kbase + kc * 8;
+        kval = k0 < p.K;
+        tap = k0 / Cin; c = k0 - tap * Cin;
+      }
+      int ky = tap / p.ks, kx = tap - ky * p.ks;
+      int iy = ry[i] + ky, ix = rx[i] + kx;
+      bool inb = kval && rb[i] >= 0 && iy >= 0 && iy < He && ix >= 0 && ix < We;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      gidx[i] = -1;
+      if (inb) {
+        const f16* src; int cs, Cs;
+        if (c < p.C1) { src = p.x; cs = c; Cs = p.C1; } else { src = p.x2; cs = c - p.C1; Cs = p.C2; }
+        long long pix = ((long long)rb[i] * p.Hin + (iy >> p.ups)) * p.Win + (ix >> p.ups);
+        v = *reinterpret_cast<const uint4*>(src + pix * Cs + cs);
+        gidx[i] = rb[i] * Cin + c;
+      }
+      ra[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < B_IT; ++i) {
+      int n = n0 + (tid >> 3) + i * 32;
+      int k0 = kbase + kc * 8;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (n < p.Nrows && k0 < p.K) v = *reinterpret_cast<const uint4*>(p.w + (long long)n * p.K + k0);
+      rw[i] = v;
+    }
+  };
+
+  auto store_tiles = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+      int row = (tid >> 3) + i * 32;
+      uint4 v = ra[i];
+      if (GN) { if (gidx[i] >= 0) v = gn_apply8(v, p.gn_scale + gidx[i], p.gn_shift + gidx[i], p.silu_in); }
+      sA[buf * BM * CPR + row * CPR + swz(row, kc)] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < B_IT; ++i) {
+      int row = (tid >> 3) + i * 32;
+      sB[buf * BN * CPR + row * CPR + swz(row, kc)] = rw[i];
+    }
+  };
+
+  f32x4 acc[NT][MT];
+#pragma unroll
+  for (int a = 0; a < NT; ++a)
+#pragma unroll
+    for (int b = 0; b < MT; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int nk = (p.K + BK - 1) / BK;
+  const int g = lane >> 4, l15 = lane & 15;
+
+  load_tiles(0);
+  store_tiles(0);
+  __syncthreads();
+
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) load_tiles(kt + 1);
+    const uint4* cA = sA + cur * BM * CPR;
+    const uint4* cB = sB + cur * BN * CPR;
+#pragma unroll
+    for (int kk = 0; kk < BK / 32; ++kk) {
+      f16x8 wf[NT], xf[MT];
+#pragma unroll
+      for (int a = 0; a < NT; ++a) {
+        int row = wave_n * (BN / 2) + a * 16 + l15;
+        wf[a] = __builtin_bit_cast(f16x8, cB[row * CPR + swz(row, kk * 4 + g)]);
+      }
+#pragma unroll
+      for (int b = 0; b < MT; ++b) {
+        int row = wave_m * (BM / 2) + b * 16 + l15;
+        xf[b] = __builtin_bit_cast(f16x8, cA[row * CPR + swz(row, kk * 4 + g)]);
+      }
+#pragma unroll
+      for (int a = 0; a < NT; ++a)
+#pragma unroll
+        for (int b = 0; b < MT; ++b)
+          acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[a], xf[b], acc[a][b], 0, 0, 0);
+    }
+    if (kt + 1 < nk) store_tiles(cur ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: lane holds y[m = col][n = 4g + r], r = 0..3 ----
+#pragma unroll
+  for (int b = 0; b < MT; ++b) {
+    const int m = m0 + wave_m * (BM / 2) + b * 16 + l15;
+    if (m >= p.M) continue;
+    const int bi = m / HWo;
+#pragma unroll
+    for (int a = 0; a < NT; ++a) {
+      const int n = n0 + wave_n * (BN / 2) + a * 16 + g * 4;
+      if (n >= p.N) continue;
+      f32x4 v = acc[a][b];
+      if (p.bias) { float4 bb = *reinterpret_cast<const float4*>(p.bias + n); v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w; }
+      if (p.temb) {
+        float4 tt = *reinterpret_cast<const float4*>(p.temb + (long long)bi * p.ld_temb + n);
+        v[0] += tt.x; v[1] += tt.y; v[2] += tt.z; v[3] += tt.w;
+      }
+      if (p.res) {
+        f16x4 rr = *reinterpret_cast<const f16x4*>(p.res + (long long)m * p.ld_res + n);
+        v[0] += (float)rr[0]; v[1] += (float)rr[1]; v[2] += (float)rr[2]; v[3] += (float)rr[3];
+      }
+      if (p.out_f32) {
+        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.y) + (long long)m * p.ldy + n) = v;
+      } else {
+        f16x4 o = {(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
+        *reinterpret_cast<f16x4*>(reinterpret_cast<f16*>(p.y) + (long long)m * p.ldy + n) = o;
+      }
+    }
+  }
+}
+
+template <int BM, int BN, bool FAST, bool GN>
+static void launch_cfg(const ConvParams& p, hipStream_t s) {
+  static bool attr_set = false;
+  const size_t smem = 2 * (BM + BN) * BK * sizeof(f16);
+  auto kern = igemm_kernel<BM, BN, FAST, GN>;
+  if (!attr_set) {
+    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    attr_set = true;
+  }
+  const int ntm = (p.M + BM - 1) / BM, ntn = (p.N + BN - 1) / BN;
+  hipLaunchKernelGGL(kern, dim3(ntm * ntn), dim3(256), smem, s, p);
+  HIP_CHECK(hipGetLastError());
+}
+
+template <int BM, int BN>
+static void launch_bmn(const ConvParams& p, bool fast, hipStream_t s) {
+  const bool gn = p.gn_scale != nullptr;
+  if (fast) { if (gn) launch_cfg<BM, BN, true, true>(p, s); else launch_cfg<BM, BN, true, false>(p, s); }
+  else      { if (gn) launch_cfg<BM, BN, false, true>(p, s); else launch_cfg<BM, BN, false, false>(p, s); }
+}
+
+void launch_igemm(const ConvParams& p, hipStream_t s) {
+  const int Cin = p.C1 + p.C2;
+  LDIFF_CHECK(p.C1 % 8 == 0 && p.C2 % 8 == 0 && Cin > 0, LDIFF_ERR_INVALID, "igemm: channel counts must be multiples of 8 (C1=%d C2=%d)", p.C1, p.C2);
+  LDIFF_CHECK(p.K == p.ks * p.ks * Cin, LDIFF_ERR_INVALID, "igemm: K=%d != ks*ks*Cin=%d", p.K, p.ks * p.ks * Cin);
+  LDIFF_CHECK(p.N % 4 == 0 && p.N <= p.Nrows && p.ldy % 4 == 0 && p.N <= p.ldy, LDIFF_ERR_INVALID, "igemm: bad N=%d Nrows=%d ldy=%d", p.N, p.Nrows, p.ldy);
+  LDIFF_CHECK((p.C2 == 0) == (p.x2 == nullptr), LDIFF_ERR_INVALID, "igemm: x2/C2 mismatch");
+  LDIFF_CHECK(!p.res || p.ld_res % 4 == 0, LDIFF_ERR_INVALID, "igemm: ld_res must be a multiple of 4");
+  LDIFF_CHECK(!p.temb || p.ld_temb % 4 == 0, LDIFF_ERR_INVALID, "igemm: ld_temb must be a multiple of 4");
+  if (p.M <= 0) return;
+  const bool fast = (Cin % BK == 0) && (p.C1 % BK == 0);
+  // Tile choice: largest tile that still yields >= ~2 workgroups per CU worth of tiles; narrow N gets BN=64.
+  auto tiles = [&](int bm, int bn) { return (long long)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn); };
+  const bool n_small = p.N <= 64 || (p.N % 128 != 0 && p.N % 128 <= 64 && p.N < 512);
+  if (!n_small && tiles(128, 128) >= 384) launch_bmn<128, 128>(p, fast, s);
+  else if (tiles(128, 64) >= 384) launch_bmn<128, 64>(p, fast, s);
+  else launch_bmn<64, 64>(p, fast, s);
+}

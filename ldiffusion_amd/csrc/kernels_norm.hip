@@ -1,0 +1,158 @@
+// GroupNorm statistics and LayerNorm for gfx950 (MI355X).  HBM-bound: 16-byte coalesced NHWC reads.
+//
+// GroupNorm (diffusers ResnetBlock2D.norm1/norm2, Transformer2DModel.norm, conv_norm_out, VAE norms):
+//   the apply (+SiLU) is folded into the consumer conv's A-tile load (kernels_igemm.hip); here only the
+//   statistics are computed: ONE read of the tensor -> per-(b,channel) fp32 partial sums per pixel chunk,
+//   then a finalize that combines chunks/channels per group in fp64 and emits
+//       scale[b,c] = rstd*gamma[c],  shift[b,c] = beta[c] - mean*rstd*gamma[c].
+//   Two NHWC sources (the UNet skip concat) are handled as one channel space, so a group may straddle
+//   the concat boundary (e.g. 1280+640 channels, 60 per group).
+// LayerNorm (BasicTransformerBlock.norm1/2/3): one wave per row, row held in registers, two-pass variance.
+#include "common.h"
+
+#define GN_PIX_PER_CHUNK_MIN 32
+
+static int gn_chunks(int HW) {
+  // ~1024 blocks at (B=8, HW=4096); cap the chunk count so the partial buffer stays small at 512x512.
+  int pix = GN_PIX_PER_CHUNK_MIN;
+  while (HW / pix > 1024) pix *= 2;
+  return (HW + pix - 1) / pix;
+}
+
+size_t gn_partial_bytes(int B, int HW, int C) { return (size_t)B * gn_chunks(HW) * C * 2 * sizeof(float); }
+
+// grid (nchunk, B, nsrc); block 256.  Thread (r, cc): channel chunk cc (8 channels), pixel rows r, r+R, ...
+__global__ __launch_bounds__(256) void gn_partial_kernel(const f16* __restrict__ x1, int C1, const f16* __restrict__ x2, int C2,
+                                                         int HW, int pix_per_chunk, int nchunk, float* __restrict__ partial) {
+  const int src = blockIdx.z;
+  const f16* x = src ? x2 : x1;
+  const int C = src ? C2 : C1, coff = src ? C1 : 0, Ct = C1 + C2;
+  const int b = blockIdx.y, chunk = blockIdx.x;
+  const int CC = C >> 3;              // 16-byte chunks per pixel (<= 256)
+  const int R = 256 / CC;
+  const int tid = threadIdx.x;
+  const int r = tid / CC, cc = tid - r * CC;
+  const int p0 = chunk * pix_per_chunk;
+  const int p1 = min(HW, p0 + pix_per_chunk);
+  float s[8], ss[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { s[j] = 0.f; ss[j] = 0.f; }
+  if (r < R) {
+    const f16* base = x + ((long long)b * HW) * C + cc * 8;
+    for (int pix = p0 + r; pix < p1; pix += R) {
+      f16x8 v = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(base + (long long)pix * C));
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { float f = (float)v[j]; s[j] += f; ss[j] += f * f; }
+    }
+  }
+  // reduce over r through LDS: red[r][c] for sums and squares
+  extern __shared__ float red[];  // [2][R][C]
+  if (r < R) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { red[r * C + cc * 8 + j] = s[j]; red[(R + r) * C + cc * 8 + j] = ss[j]; }
+  }
+  __syncthreads();
+  float* out = partial + (((long long)b * nchunk + chunk) * Ct + coff) * 2;
+  for (int c = tid; c < C; c += 256) {
+    float a = 0.f, q = 0.f;
+    for (int rr = 0; rr < R; ++rr) { a += red[rr * C + c]; q += red[(R + rr) * C + c]; }
+    out[c * 2] = a; out[c * 2 + 1] = q;
+  }
+}
+
+// grid (groups, B); block 64: one wave per (b, group).
+__global__ __launch_bounds__(64) void gn_finalize_kernel(const float* __restrict__ partial, int nchunk, int C, int groups, int HW, float eps,
+                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                         float* __restrict__ scale, float* __restrict__ shift) {
+  const int grp = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
+  const int Cg = C / groups, c0 = grp * Cg;
+  double a = 0.0, q = 0.0;
+  const int total = nchunk * Cg;
+  for (int i = lane; i < total; i += 64) {
+    const int ch = i / Cg, c = c0 + (i - ch * Cg);
+    const float* pp = partial + (((long long)b * nchunk + ch) * C + c) * 2;
+    a += (double)pp[0]; q += (double)pp[1];
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o); q += __shfl_xor(q, o); }
+  const double n = (double)HW * Cg;
+  const double mean = a / n;
+  double var = q / n - mean * mean;
+  if (var < 0.0) var = 0.0;
+  const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+  for (int c = c0 + lane; c < c0 + Cg; c += 64) {
+    const float gsc = gamma[c] * rstd;
+    scale[(long long)b * C + c] = gsc;
+    shift[(long long)b * C + c] = beta[c] - (float)mean * gsc;
+  }
+}
+
+void launch_gn_stats(const f16* x, int C1, const f16* x2, int C2, int B, int HW, int groups, float eps, const float* gamma,
+                     const float* beta, float* partial, size_t partial_bytes, float* scale, float* shift, hipStream_t s) {
+  const int C = C1 + C2;
+  LDIFF_CHECK(C1 % 8 == 0 && C2 % 8 == 0 && C1 > 0 && C1 <= 2048 && C2 <= 2048, LDIFF_ERR_INVALID, "gn_stats: bad channels C1=%d C2=%d", C1, C2);
+  LDIFF_CHECK(C % groups == 0, LDIFF_ERR_INVALID, "gn_stats: C=%d not divisible by groups=%d", C, groups);
+  LDIFF_CHECK(gn_partial_bytes(B, HW, C) <= partial_bytes, LDIFF_ERR_INVALID, "gn_stats: workspace too small");
+  const int nchunk = gn_chunks(HW);
+  const int pix = (HW + nchunk - 1) / nchunk;
+  const size_t smem = 2 * 2048 * sizeof(float);  // [2][R][C] with R*C <= 256*8
+  hipLaunchKernelGGL(gn_partial_kernel, dim3(nchunk, B, C2 ? 2 : 1), dim3(256), smem, s, x, C1, x2, C2, HW, pix, nchunk, partial);
+  HIP_CHECK(hipGetLastError());
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(groups, B), dim3(64), 0, s, partial, nchunk, C, groups, HW, eps, gamma, beta, scale, shift);
+  HIP_CHECK(hipGetLastError());
+}
+
+// ---- LayerNorm: one wave per row, up to 2560 channels (5 chunks of 8 per lane) ----------------
+#define LN_MAXCH 5
+__global__ __launch_bounds__(256) void layernorm_kernel(const f16* __restrict__ x, f16* __restrict__ y, int rows, int C,
+                                                        const float* __restrict__ gamma, const float* __restrict__ beta, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int CC = C >> 3;
+  const f16* xr = x + (long long)row * C;
+  f16x8 v[LN_MAXCH];
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < LN_MAXCH; ++i) {
+    const int cc = lane + i * 64;
+    if (cc < CC) {
+      v[i] = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(xr + cc * 8));
+#pragma unroll
+      for (int j = 0; j < 8; ++j) sum += (float)v[i][j];
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+  const float mean = sum / (float)C;
+  float var = 0.f;
+#pragma unroll
+  for (int i = 0; i < LN_MAXCH; ++i) {
+    const int cc = lane + i * 64;
+    if (cc < CC) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { float dlt = (float)v[i][j] - mean; var += dlt * dlt; }
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) var += __shfl_xor(var, o);
+  const float rstd = rsqrtf(var / (float)C + eps);
+  f16* yr = y + (long long)row * C;
+#pragma unroll
+  for (int i = 0; i < LN_MAXCH; ++i) {
+    const int cc = lane + i * 64;
+    if (cc < CC) {
+      f16x8 o;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = (f16)(((float)v[i][j] - mean) * rstd * gamma[cc * 8 + j] + beta[cc * 8 + j]);
+      *reinterpret_cast<uint4*>(yr + cc * 8) = __builtin_bit_cast(uint4, o);
+    }
+  }
+}
+
+void launch_layernorm(const f16* x, f16* y, int rows, int C, const float* gamma, const float* beta, float eps, hipStream_t s) {
+  LDIFF_CHECK(C % 8 == 0 && C <= 8 * 64 * LN_MAXCH, LDIFF_ERR_INVALID, "layernorm: C=%d unsupported", C);
+  if (rows <= 0) return;
+  hipLaunchKernelGGL(layernorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, x, y, rows, C, gamma, beta, eps);
+  HIP_CHECK(hipGetLastError());
+}

@@ -1,0 +1,159 @@
+// Host-side executors: weight store, op helpers over the device arena, UNet / VAE graphs.
+// Internal to libldiff_hip.so.
+#pragma once
+#include <functional>
+#include <map>
+#include <memory>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/ldiff.h"
+#include "common.h"
+
+struct Act {  // NHWC fp16 activation (tokens [M, C] are B=1,H=1,W=M or keep the image shape)
+  f16* p = nullptr;
+  int B = 0, H = 0, W = 0, C = 0;
+  long long rows() const { return (long long)B * H * W; }
+  size_t bytes() const { return (size_t)rows() * C * sizeof(f16); }
+};
+
+struct MatW {   // [Nrows][K] fp16 K-major + fp32 bias
+  f16* w = nullptr;
+  float* b = nullptr;  // nullptr => no bias
+  int N = 0, Nrows = 0, K = 0, ks = 1, Cin = 0;  // Cin = padded input channels (K = ks*ks*Cin)
+};
+struct NormW { float* g = nullptr; float* b = nullptr; int C = 0; };
+struct GNss { float* scale = nullptr; float* shift = nullptr; };
+
+// One expected checkpoint tensor and where/how it lands on the device.
+struct LoadSpec {
+  enum Kind { MATRIX, VECTOR } kind;
+  std::vector<int64_t> shape;   // expected torch shape
+  f16* mat = nullptr; int row_off = 0, K = 0, ks = 1, Cin_pad = 0;   // MATRIX
+  float* vec = nullptr; int vec_off = 0;                             // VECTOR
+  bool loaded = false;
+};
+
+class WeightStore {
+ public:
+  ~WeightStore();
+  // allocation helpers (device memory owned by the store, zero-initialised)
+  f16* alloc_mat(int Nrows, int K);
+  float* alloc_vec(int n);
+  // registration
+  MatW add_conv(const std::string& prefix, int Cin, int Cout, int ks, bool bias = true, int Cin_pad = -1, int min_rows = 0);
+  void add_rows(const std::string& wname, const std::string& bname, f16* mat, int K, int ks, int Cin, int Cin_pad, int row_off, int rows,
+                float* bias_vec, bool has_bias);
+  NormW add_norm(const std::string& prefix, int C);
+  void alias(const std::string& alias_name, const std::string& name);
+  // loading
+  void load(const char* name, const void* host, int dtype, const int64_t* shape, int ndim);
+  int missing() const;
+  const char* missing_name(int i) const;
+
+ private:
+  std::unordered_map<std::string, LoadSpec> specs_;
+  std::unordered_map<std::string, std::string> alias_;
+  std::vector<std::string> order_;
+  std::vector<void*> allocs_;
+  mutable std::vector<std::string> missing_cache_;
+};
+
+struct ConvOpts {
+  int stride = 1, pad_t = -1 /* -1 => (ks-1)/2 */, pad_l = -1, ups = 0;
+  int Hout = -1, Wout = -1;     // override output size (asymmetric-pad downsample)
+  const GNss* gn = nullptr; int silu = 0;
+  const float* temb = nullptr; int ld_temb = 0;
+  const Act* res = nullptr;
+  void* out_f32 = nullptr; int ldy_f32 = 0;   // write fp32 [M, ldy] here instead of allocating an fp16 Act
+  int N_override = 0;           // columns to store (multiple of 4), default = roundup4(w.N)
+  int ldy = 0;                  // fp16 output channel stride (default N stored rounded up to 8)
+};
+
+class Exec {
+ public:
+  Arena arena;
+  hipStream_t s = nullptr;
+  float* gn_partial = nullptr;
+  size_t gn_partial_cap = 0;
+  ~Exec();
+  void ensure_gn_partial(size_t bytes);
+  Act new_act(int B, int H, int W, int C);
+  void release(Act& a);
+  template <typename T> T* tmp(size_t n) { return reinterpret_cast<T*>(arena.alloc(n * sizeof(T))); }
+  GNss gn(const Act& x, const Act* x2, const NormW& w, int groups, float eps);
+  void release(GNss& g);
+  Act conv(const MatW& w, const Act& x, const Act* x2, const ConvOpts& o);
+  Act layernorm(const Act& x, const NormW& w);
+  Act geglu(const Act& x);
+};
+
+// ---- UNet -------------------------------------------------------------------------------------
+struct ResnetW { NormW n1, n2; MatW c1, c2, sc; bool has_sc = false; int temb_off = 0; int Cin = 0, Cout = 0; };
+struct TransformerW {
+  NormW gn, ln1, ln2, ln3;
+  MatW proj_in, qkv, out1, q2, kv2, out2, ff1, ff2, proj_out;
+  int C = 0;
+  f16* kv_ctx = nullptr;  // [Bctx*L, 2C] precomputed by set_context
+};
+
+struct ldiff_unet {
+  ldiff_unet_cfg cfg;
+  int device = 0;
+  WeightStore ws;
+  Exec ex;
+  MatW conv_in, conv_out, t_lin1, t_lin2, temb_proj_all;
+  NormW norm_out;
+  int temb_total = 0;
+  std::vector<std::vector<ResnetW>> down_res, up_res;
+  std::vector<std::vector<TransformerW>> down_attn, up_attn;
+  std::vector<MatW> down_sample, up_sample;
+  std::vector<bool> has_down, has_up;
+  ResnetW mid_res[2];
+  TransformerW mid_attn;
+  std::vector<TransformerW*> all_tf;
+  int ctx_B = 0, ctx_L = 0;
+  f16* ctx_buf = nullptr; size_t ctx_cap = 0;     // all kv_ctx live in one allocation
+  void build();
+  void set_context(const float* ctx, int Bc, int L, hipStream_t s);
+  void forward(const float* x, int B, int h, int w, float t, float* out, hipStream_t s);
+  Act resnet(const ResnetW& r, const Act& x, const Act* skip, const float* temb_all);
+  Act transformer(const TransformerW& t, const Act& x);
+};
+
+// ---- VAE --------------------------------------------------------------------------------------
+struct VaeAttnW { NormW gn; MatW qkv, out; int C = 0; };
+struct ldiff_vae {
+  ldiff_vae_cfg cfg;
+  int device = 0;
+  WeightStore ws;
+  Exec ex;
+  // encoder
+  MatW e_conv_in, e_conv_out, quant;
+  std::vector<std::vector<ResnetW>> e_res;
+  std::vector<MatW> e_down;
+  ResnetW e_mid[2]; VaeAttnW e_attn; NormW e_norm_out;
+  // decoder
+  MatW post_quant, d_conv_in, d_conv_out;
+  std::vector<std::vector<ResnetW>> d_res;
+  std::vector<MatW> d_up;
+  ResnetW d_mid[2]; VaeAttnW d_attn; NormW d_norm_out;
+  void build();
+  void encode(const float* x, int B, int H, int W, float* moments, hipStream_t s);
+  // writes the fp32 NHWC decoder output [B*8h*8w, 4] into the arena and post-processes it
+  void decode(const float* z, int B, int h, int w, float z_scale, float* sample_nchw, float* image_nhwc, uint8_t* rgb, uint8_t* luma,
+              int n_slots, int slot, hipStream_t s);
+  Act resnet(const ResnetW& r, const Act& x);
+  Act mid_attention(const VaeAttnW& a, const Act& x);
+};
+
+struct ldiff_pipeline {
+  ldiff_unet* unet;
+  ldiff_vae* vae;
+  Arena arena;   // latents / eps history
+  float abar[1000];
+};
+
+void pndm_alphas_cumprod(float* out1000);
+int plms_timesteps(int n_passes, int64_t* out, int cap);

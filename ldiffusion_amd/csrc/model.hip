@@ -1,0 +1,841 @@
+// Host-side executors for the UNet / VAE graphs of the sampling path (gfx950, MI355X).
+// Graph structure follows diffusers 0.34.0 UNet2DConditionModel / AutoencoderKL as restated in
+// SURVEY.md 8a R1-R5; every contraction runs in kernels_igemm.hip / kernels_attn.hip, every GroupNorm
+// is a statistics pass (kernels_norm.hip) whose apply+SiLU is folded into the consuming conv's load,
+// nearest-2x upsampling and the skip concat are gathers inside the conv (no copies).
+#include "model.h"
+
+#include <stdarg.h>
+#include <string.h>
+
+#include <algorithm>
+#include <cmath>
+
+// ---- error message (thread-local) --------------------------------------------------------------
+static thread_local char g_err[1024] = "";
+void ldiff_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+const char* ldiff_error_message() { return g_err; }
+
+static inline int roundup(int x, int m) { return (x + m - 1) / m * m; }
+
+// ---- Arena -------------------------------------------------------------------------------------
+Arena::~Arena() {
+  if (base_) (void)hipFree(base_);
+}
+void Arena::reserve(size_t bytes) {
+  if (bytes <= cap_) return;
+  if (base_) {
+    HIP_CHECK(hipDeviceSynchronize());
+    HIP_CHECK(hipFree(base_));
+    base_ = nullptr;
+    cap_ = 0;
+  }
+  HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&base_), bytes));
+  cap_ = bytes;
+  reset();
+}
+void Arena::reset() {
+  blocks_.clear();
+  if (cap_) blocks_.push_back({0, cap_, false});
+}
+void* Arena::alloc(size_t bytes) {
+  bytes = (bytes + 255) & ~size_t(255);
+  if (bytes == 0) bytes = 256;
+  for (size_t i = 0; i < blocks_.size(); ++i) {
+    if (!blocks_[i].used && blocks_[i].size >= bytes) {
+      if (blocks_[i].size > bytes) {
+        Block rest{blocks_[i].off + bytes, blocks_[i].size - bytes, false};
+        blocks_[i].size = bytes;
+        blocks_.insert(blocks_.begin() + i + 1, rest);
+      }
+      blocks_[i].used = true;
+      high_ = std::max(high_, blocks_[i].off + bytes);
+      return base_ + blocks_[i].off;
+    }
+  }
+  ldiff_set_error("device arena exhausted: need %zu bytes, capacity %zu", bytes, cap_);
+  throw LdiffError{LDIFF_ERR_RUNTIME};
+}
+void Arena::free(void* p) {
+  if (!p) return;
+  size_t off = (size_t)((char*)p - base_);
+  for (size_t i = 0; i < blocks_.size(); ++i) {
+    if (blocks_[i].off == off && blocks_[i].used) {
+      blocks_[i].used = false;
+      if (i + 1 < blocks_.size() && !blocks_[i + 1].used) { blocks_[i].size += blocks_[i + 1].size; blocks_.erase(blocks_.begin() + i + 1); }
+      if (i > 0 && !blocks_[i - 1].used) { blocks_[i - 1].size += blocks_[i].size; blocks_.erase(blocks_.begin() + i); }
+      return;
+    }
+  }
+  ldiff_set_error("arena: free of unknown pointer");
+  throw LdiffError{LDIFF_ERR_RUNTIME};
+}
+
+// ---- WeightStore -------------------------------------------------------------------------------
+WeightStore::~WeightStore() {
+  for (void* p : allocs_) (void)hipFree(p);
+}
+f16* WeightStore::alloc_mat(int Nrows, int K) {
+  void* p = nullptr;
+  size_t bytes = (size_t)Nrows * K * sizeof(f16);
+  HIP_CHECK(hipMalloc(&p, bytes));
+  HIP_CHECK(hipMemset(p, 0, bytes));
+  allocs_.push_back(p);
+  return (f16*)p;
+}
+float* WeightStore::alloc_vec(int n) {
+  void* p = nullptr;
+  HIP_CHECK(hipMalloc(&p, (size_t)n * sizeof(float)));
+  HIP_CHECK(hipMemset(p, 0, (size_t)n * sizeof(float)));
+  allocs_.push_back(p);
+  return (float*)p;
+}
+void WeightStore::add_rows(const std::string& wname, const std::string& bname, f16* mat, int K, int ks, int Cin, int Cin_pad, int row_off,
+                           int rows, float* bias_vec, bool has_bias) {
+  LoadSpec w;
+  w.kind = LoadSpec::MATRIX;
+  w.shape = {rows, Cin, ks, ks};
+  w.mat = mat; w.row_off = row_off; w.K = K; w.ks = ks; w.Cin_pad = Cin_pad;
+  specs_[wname] = w;
+  order_.push_back(wname);
+  if (has_bias) {
+    LoadSpec b;
+    b.kind = LoadSpec::VECTOR;
+    b.shape = {rows};
+    b.vec = bias_vec; b.vec_off = row_off;
+    specs_[bname] = b;
+    order_.push_back(bname);
+  }
+}
+MatW WeightStore::add_conv(const std::string& prefix, int Cin, int Cout, int ks, bool bias, int Cin_pad, int min_rows) {
+  if (Cin_pad < 0) Cin_pad = roundup(Cin, 8);
+  MatW m;
+  m.N = Cout; m.Nrows = roundup(std::max(Cout, min_rows), 16); m.ks = ks; m.Cin = Cin_pad; m.K = ks * ks * Cin_pad;
+  m.w = alloc_mat(m.Nrows, m.K);
+  m.b = bias ? alloc_vec(m.Nrows) : nullptr;
+  add_rows(prefix + ".weight", prefix + ".bias", m.w, m.K, ks, Cin, Cin_pad, 0, Cout, m.b, bias);
+  return m;
+}
+NormW WeightStore::add_norm(const std::string& prefix, int C) {
+  NormW n;
+  n.C = C; n.g = alloc_vec(C); n.b = alloc_vec(C);
+  LoadSpec g; g.kind = LoadSpec::VECTOR; g.shape = {C}; g.vec = n.g; g.vec_off = 0;
+  LoadSpec b = g; b.vec = n.b;
+  specs_[prefix + ".weight"] = g; order_.push_back(prefix + ".weight");
+  specs_[prefix + ".bias"] = b; order_.push_back(prefix + ".bias");
+  return n;
+}
+void WeightStore::alias(const std::string& alias_name, const std::string& name) { alias_[alias_name] = name; }
+
+static inline float host_to_float(const void* p, int dtype, size_t i) {
+  if (dtype == LDIFF_F32) return ((const float*)p)[i];
+  if (dtype == LDIFF_F16) return (float)((const f16*)p)[i];
+  uint32_t u = (uint32_t)((const uint16_t*)p)[i] << 16;  // bf16
+  float f;
+  memcpy(&f, &u, 4);
+  return f;
+}
+
+void WeightStore::load(const char* name_c, const void* host, int dtype, const int64_t* shape, int ndim) {
+  LDIFF_CHECK(name_c && host && shape, LDIFF_ERR_INVALID, "load: null argument");
+  LDIFF_CHECK(dtype == LDIFF_F32 || dtype == LDIFF_F16 || dtype == LDIFF_BF16, LDIFF_ERR_INVALID, "load(%s): unsupported dtype %d", name_c, dtype);
+  std::string name(name_c);
+  auto al = alias_.find(name);
+  if (al != alias_.end()) name = al->second;
+  auto it = specs_.find(name);
+  LDIFF_CHECK(it != specs_.end(), LDIFF_ERR_INVALID, "load: unexpected tensor name '%s'", name_c);
+  LoadSpec& sp = it->second;
+  size_t numel = 1, expect = 1;
+  for (int i = 0; i < ndim; ++i) numel *= (size_t)shape[i];
+  for (auto d : sp.shape) expect *= (size_t)d;
+  bool ok = numel == expect && ndim >= 1 && shape[0] == sp.shape[0];
+  if (sp.kind == LoadSpec::MATRIX) ok = ok && ndim >= 2 && shape[1] == sp.shape[1] && (ndim == 4 || (ndim == 2 && sp.ks == 1));
+  else ok = ok && ndim == 1;
+  if (!ok) {
+    std::string got;
+    for (int i = 0; i < ndim; ++i) got += (i ? "," : "") + std::to_string((long long)shape[i]);
+    std::string want;
+    for (size_t i = 0; i < sp.shape.size(); ++i) want += (i ? "," : "") + std::to_string((long long)sp.shape[i]);
+    ldiff_set_error("load(%s): shape [%s] does not match expected [%s]", name_c, got.c_str(), want.c_str());
+    throw LdiffError{LDIFF_ERR_INVALID};
+  }
+  if (sp.kind == LoadSpec::VECTOR) {
+    std::vector<float> tmp(numel);
+    for (size_t i = 0; i < numel; ++i) tmp[i] = host_to_float(host, dtype, i);
+    HIP_CHECK(hipMemcpy(sp.vec + sp.vec_off, tmp.data(), numel * sizeof(float), hipMemcpyHostToDevice));
+  } else {
+    const int rows = (int)sp.shape[0], Cin = (int)sp.shape[1], ks = sp.ks, taps = ks * ks;
+    std::vector<f16> tmp((size_t)rows * sp.K, (f16)0.f);
+    for (int r = 0; r < rows; ++r)
+      for (int c = 0; c < Cin; ++c)
+        for (int t = 0; t < taps; ++t)
+          tmp[(size_t)r * sp.K + (size_t)t * sp.Cin_pad + c] = (f16)host_to_float(host, dtype, ((size_t)r * Cin + c) * taps + t);
+    HIP_CHECK(hipMemcpy(sp.mat + (size_t)sp.row_off * sp.K, tmp.data(), tmp.size() * sizeof(f16), hipMemcpyHostToDevice));
+  }
+  sp.loaded = true;
+}
+int WeightStore::missing() const {
+  missing_cache_.clear();
+  for (auto& n : order_)
+    if (!specs_.at(n).loaded) missing_cache_.push_back(n);
+  return (int)missing_cache_.size();
+}
+const char* WeightStore::missing_name(int i) const {
+  if (i < 0 || i >= (int)missing_cache_.size()) return "";
+  return missing_cache_[i].c_str();
+}
+
+// ---- Exec: op helpers --------------------------------------------------------------------------
+Exec::~Exec() {
+  if (gn_partial) (void)hipFree(gn_partial);
+}
+void Exec::ensure_gn_partial(size_t bytes) {
+  if (bytes <= gn_partial_cap) return;
+  if (gn_partial) { HIP_CHECK(hipDeviceSynchronize()); HIP_CHECK(hipFree(gn_partial)); gn_partial = nullptr; }
+  HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&gn_partial), bytes));
+  gn_partial_cap = bytes;
+}
+Act Exec::new_act(int B, int H, int W, int C) {
+  Act a;
+  a.B = B; a.H = H; a.W = W; a.C = C;
+  a.p = (f16*)arena.alloc(a.bytes());
+  return a;
+}
+void Exec::release(Act& a) {
+  if (a.p) arena.free(a.p);
+  a.p = nullptr;
+}
+GNss Exec::gn(const Act& x, const Act* x2, const NormW& w, int groups, float eps) {
+  const int C = x.C + (x2 ? x2->C : 0);
+  LDIFF_CHECK(C == w.C, LDIFF_ERR_INVALID, "group norm: %d channels, weight has %d", C, w.C);
+  GNss g;
+  g.scale = tmp<float>((size_t)x.B * C);
+  g.shift = tmp<float>((size_t)x.B * C);
+  LDIFF_CHECK(gn_partial_bytes(x.B, x.H * x.W, C) <= gn_partial_cap, LDIFF_ERR_RUNTIME, "group norm workspace too small");
+  launch_gn_stats(x.p, x.C, x2 ? x2->p : nullptr, x2 ? x2->C : 0, x.B, x.H * x.W, groups, eps, w.g, w.b, gn_partial, gn_partial_cap, g.scale,
+                  g.shift, s);
+  return g;
+}
+void Exec::release(GNss& g) {
+  arena.free(g.scale);
+  arena.free(g.shift);
+  g.scale = g.shift = nullptr;
+}
+Act Exec::conv(const MatW& w, const Act& x, const Act* x2, const ConvOpts& o) {
+  ConvParams p;
+  memset(&p, 0, sizeof(p));
+  p.x = x.p; p.C1 = x.C;
+  p.x2 = x2 ? x2->p : nullptr; p.C2 = x2 ? x2->C : 0;
+  LDIFF_CHECK(p.C1 + p.C2 == w.Cin, LDIFF_ERR_INVALID, "conv: input has %d channels, weight expects %d", p.C1 + p.C2, w.Cin);
+  p.B = x.B; p.Hin = x.H; p.Win = x.W;
+  p.ks = w.ks; p.stride = o.stride; p.ups = o.ups;
+  p.pad_t = o.pad_t < 0 ? (w.ks - 1) / 2 : o.pad_t;
+  p.pad_l = o.pad_l < 0 ? (w.ks - 1) / 2 : o.pad_l;
+  const int He = x.H << o.ups, We = x.W << o.ups;
+  p.Hout = o.Hout > 0 ? o.Hout : (He + 2 * p.pad_t - w.ks) / o.stride + 1;
+  p.Wout = o.Wout > 0 ? o.Wout : (We + 2 * p.pad_l - w.ks) / o.stride + 1;
+  p.w = w.w; p.Nrows = w.Nrows; p.K = w.K;
+  p.N = o.N_override ? o.N_override : roundup(w.N, 4);
+  p.bias = w.b;
+  if (o.gn) { p.gn_scale = o.gn->scale; p.gn_shift = o.gn->shift; p.silu_in = o.silu; }
+  p.temb = o.temb; p.ld_temb = o.ld_temb;
+  p.M = x.B * p.Hout * p.Wout;
+  if (o.res) {
+    LDIFF_CHECK(o.res->rows() == p.M && o.res->C >= p.N, LDIFF_ERR_INVALID, "conv: residual shape mismatch");
+    p.res = o.res->p; p.ld_res = o.res->C;
+  }
+  Act y;
+  if (o.out_f32) {
+    p.y = o.out_f32; p.ldy = o.ldy_f32; p.out_f32 = 1;
+  } else {
+    const int C = o.ldy ? o.ldy : roundup(p.N, 8);
+    y = new_act(x.B, p.Hout, p.Wout, C);
+    if (C > p.N) HIP_CHECK(hipMemsetAsync(y.p, 0, y.bytes(), s));  // zero the pad columns
+    p.y = y.p; p.ldy = C;
+  }
+  launch_igemm(p, s);
+  return y;
+}
+Act Exec::layernorm(const Act& x, const NormW& w) {
+  Act y = new_act(x.B, x.H, x.W, x.C);
+  launch_layernorm(x.p, y.p, (int)x.rows(), x.C, w.g, w.b, 1e-5f, s);
+  return y;
+}
+Act Exec::geglu(const Act& x) {
+  Act y = new_act(x.B, x.H, x.W, x.C / 2);
+  launch_geglu(x.p, y.p, x.rows(), x.C / 2, s);
+  return y;
+}
+
+// ================================================================================================
+// UNet
+// ================================================================================================
+static ResnetW make_resnet(WeightStore& ws, const std::string& p, int Cin, int Cout, bool temb) {
+  ResnetW r;
+  r.Cin = Cin; r.Cout = Cout;
+  r.n1 = ws.add_norm(p + ".norm1", Cin);
+  r.c1 = ws.add_conv(p + ".conv1", Cin, Cout, 3);
+  r.n2 = ws.add_norm(p + ".norm2", Cout);
+  r.c2 = ws.add_conv(p + ".conv2", Cout, Cout, 3);
+  r.has_sc = Cin != Cout;
+  if (r.has_sc) r.sc = ws.add_conv(p + ".conv_shortcut", Cin, Cout, 1);
+  (void)temb;
+  return r;
+}
+
+static TransformerW make_transformer(WeightStore& ws, const std::string& p, int C, int ctx) {
+  TransformerW t;
+  t.C = C;
+  t.gn = ws.add_norm(p + ".norm", C);
+  t.proj_in = ws.add_conv(p + ".proj_in", C, C, 1);
+  const std::string b = p + ".transformer_blocks.0";
+  t.ln1 = ws.add_norm(b + ".norm1", C);
+  t.ln2 = ws.add_norm(b + ".norm2", C);
+  t.ln3 = ws.add_norm(b + ".norm3", C);
+  // fused self-attention QKV [3C][C], no bias
+  t.qkv.N = 3 * C; t.qkv.Nrows = roundup(3 * C, 16); t.qkv.ks = 1; t.qkv.Cin = C; t.qkv.K = C;
+  t.qkv.w = ws.alloc_mat(t.qkv.Nrows, C); t.qkv.b = nullptr;
+  ws.add_rows(b + ".attn1.to_q.weight", "", t.qkv.w, C, 1, C, C, 0, C, nullptr, false);
+  ws.add_rows(b + ".attn1.to_k.weight", "", t.qkv.w, C, 1, C, C, C, C, nullptr, false);
+  ws.add_rows(b + ".attn1.to_v.weight", "", t.qkv.w, C, 1, C, C, 2 * C, C, nullptr, false);
+  t.out1 = ws.add_conv(b + ".attn1.to_out.0", C, C, 1);
+  t.q2 = ws.add_conv(b + ".attn2.to_q", C, C, 1, false);
+  // fused cross-attention KV [2C][ctx], no bias
+  t.kv2.N = 2 * C; t.kv2.Nrows = roundup(2 * C, 16); t.kv2.ks = 1; t.kv2.Cin = ctx; t.kv2.K = ctx;
+  t.kv2.w = ws.alloc_mat(t.kv2.Nrows, ctx); t.kv2.b = nullptr;
+  ws.add_rows(b + ".attn2.to_k.weight", "", t.kv2.w, ctx, 1, ctx, ctx, 0, C, nullptr, false);
+  ws.add_rows(b + ".attn2.to_v.weight", "", t.kv2.w, ctx, 1, ctx, ctx, C, C, nullptr, false);
+  t.out2 = ws.add_conv(b + ".attn2.to_out.0", C, C, 1);
+  t.ff1 = ws.add_conv(b + ".ff.net.0.proj", C, 8 * C, 1);
+  t.ff2 = ws.add_conv(b + ".ff.net.2", 4 * C, C, 1);
+  t.proj_out = ws.add_conv(p + ".proj_out", C, C, 1);
+  return t;
+}
+
+void ldiff_unet::build() {
+  const int nb = cfg.n_blocks;
+  const int* boc = cfg.block_out_channels;
+  const int temb_dim = boc[0] * 4, ctx = cfg.cross_attention_dim, lpb = cfg.layers_per_block;
+  LDIFF_CHECK(nb >= 1 && nb <= LDIFF_MAX_BLOCKS, LDIFF_ERR_INVALID, "unet: n_blocks=%d out of range", nb);
+  LDIFF_CHECK(cfg.in_channels <= 8 && cfg.out_channels <= 8 && cfg.in_channels > 0, LDIFF_ERR_INVALID, "unet: in/out channels must be <= 8");
+  LDIFF_CHECK(ctx % 8 == 0 && cfg.heads > 0, LDIFF_ERR_INVALID, "unet: cross_attention_dim must be a multiple of 8");
+  for (int i = 0; i < nb; ++i) {
+    LDIFF_CHECK(boc[i] % cfg.norm_num_groups == 0 && boc[i] % 8 == 0, LDIFF_ERR_INVALID, "unet: channels %d not divisible by groups/8", boc[i]);
+    LDIFF_CHECK(boc[i] % cfg.heads == 0 && (boc[i] / cfg.heads) % 8 == 0, LDIFF_ERR_INVALID, "unet: head dim %d/%d must be a multiple of 8", boc[i], cfg.heads);
+  }
+  conv_in = ws.add_conv("conv_in", cfg.in_channels, boc[0], 3, true, 8);
+  t_lin1 = ws.add_conv("time_embedding.linear_1", boc[0], temb_dim, 1);
+  t_lin2 = ws.add_conv("time_embedding.linear_2", temb_dim, temb_dim, 1);
+
+  // first pass: count resnet output channels for the fused time-embedding projection
+  std::vector<int> temb_couts;
+  {
+    int ch = boc[0];
+    for (int i = 0; i < nb; ++i) { for (int j = 0; j < lpb; ++j) { temb_couts.push_back(boc[i]); ch = boc[i]; } }
+    temb_couts.push_back(ch); temb_couts.push_back(ch);  // mid
+    for (int i = 0; i < nb; ++i) for (int j = 0; j < lpb + 1; ++j) temb_couts.push_back(boc[nb - 1 - i]);
+  }
+  temb_total = 0;
+  for (int c : temb_couts) temb_total += c;
+  temb_proj_all.N = temb_total; temb_proj_all.Nrows = roundup(temb_total, 16); temb_proj_all.ks = 1; temb_proj_all.Cin = temb_dim;
+  temb_proj_all.K = temb_dim;
+  temb_proj_all.w = ws.alloc_mat(temb_proj_all.Nrows, temb_dim);
+  temb_proj_all.b = ws.alloc_vec(temb_proj_all.Nrows);
+  int temb_off = 0;
+  auto add_res = [&](const std::string& p, int Cin, int Cout) {
+    ResnetW r = make_resnet(ws, p, Cin, Cout, true);
+    r.temb_off = temb_off;
+    ws.add_rows(p + ".time_emb_proj.weight", p + ".time_emb_proj.bias", temb_proj_all.w, temb_dim, 1, temb_dim, temb_dim, temb_off, Cout,
+                temb_proj_all.b, true);
+    temb_off += Cout;
+    return r;
+  };
+
+  std::vector<int> skip_ch{boc[0]};
+  int ch = boc[0];
+  down_res.resize(nb); down_attn.resize(nb); down_sample.resize(nb); has_down.assign(nb, false);
+  for (int i = 0; i < nb; ++i) {
+    for (int j = 0; j < lpb; ++j) {
+      const std::string p = "down_blocks." + std::to_string(i);
+      down_res[i].push_back(add_res(p + ".resnets." + std::to_string(j), ch, boc[i]));
+      ch = boc[i];
+      if (cfg.down_has_attn[i]) down_attn[i].push_back(make_transformer(ws, p + ".attentions." + std::to_string(j), ch, ctx));
+      skip_ch.push_back(ch);
+    }
+    if (i != nb - 1) {
+      down_sample[i] = ws.add_conv("down_blocks." + std::to_string(i) + ".downsamplers.0.conv", ch, ch, 3);
+      has_down[i] = true;
+      skip_ch.push_back(ch);
+    }
+  }
+  mid_res[0] = add_res("mid_block.resnets.0", ch, ch);
+  mid_attn = make_transformer(ws, "mid_block.attentions.0", ch, ctx);
+  mid_res[1] = add_res("mid_block.resnets.1", ch, ch);
+  up_res.resize(nb); up_attn.resize(nb); up_sample.resize(nb); has_up.assign(nb, false);
+  for (int i = 0; i < nb; ++i) {
+    const int oc = boc[nb - 1 - i];
+    const std::string p = "up_blocks." + std::to_string(i);
+    for (int j = 0; j < lpb + 1; ++j) {
+      const int sc = skip_ch.back();
+      skip_ch.pop_back();
+      up_res[i].push_back(add_res(p + ".resnets." + std::to_string(j), ch + sc, oc));
+      ch = oc;
+      if (cfg.up_has_attn[i]) up_attn[i].push_back(make_transformer(ws, p + ".attentions." + std::to_string(j), ch, ctx));
+    }
+    if (i != nb - 1) { up_sample[i] = ws.add_conv(p + ".upsamplers.0.conv", ch, ch, 3); has_up[i] = true; }
+  }
+  norm_out = ws.add_norm("conv_norm_out", ch);
+  conv_out = ws.add_conv("conv_out", ch, cfg.out_channels, 3);
+  LDIFF_CHECK(temb_off == temb_total, LDIFF_ERR_RUNTIME, "unet: internal temb bookkeeping error");
+
+  for (auto& v : down_attn) for (auto& t : v) all_tf.push_back(&t);
+  all_tf.push_back(&mid_attn);
+  for (auto& v : up_attn) for (auto& t : v) all_tf.push_back(&t);
+}
+
+void ldiff_unet::set_context(const float* ctx, int Bc, int L, hipStream_t s) {
+  LDIFF_CHECK(ctx && Bc >= 1 && L >= 1, LDIFF_ERR_INVALID, "set_context: need B_ctx >= 1 and L >= 1 (got %d, %d)", Bc, L);
+  LDIFF_CHECK(ws.missing() == 0, LDIFF_ERR_STATE, "unet: %d weight tensors not loaded (first: %s)", ws.missing(), ws.missing_name(0));
+  HIP_CHECK(hipSetDevice(device));
+  const int D = cfg.cross_attention_dim, rows = Bc * L;
+  size_t need = 0;
+  for (auto* t : all_tf) need += (size_t)rows * 2 * t->C;
+  if (need * sizeof(f16) > ctx_cap) {
+    if (ctx_buf) { HIP_CHECK(hipDeviceSynchronize()); HIP_CHECK(hipFree(ctx_buf)); ctx_buf = nullptr; }
+    HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&ctx_buf), need * sizeof(f16)));
+    ctx_cap = need * sizeof(f16);
+  }
+  ex.s = s;
+  ex.arena.reserve((size_t)rows * D * 2 + (1 << 20));
+  Act c16 = ex.new_act(1, 1, rows, D);
+  launch_nchw_f32_to_nhwc_f16(ctx, c16.p, rows, D, 1, 1, D, s);
+  size_t off = 0;
+  for (auto* t : all_tf) {
+    t->kv_ctx = ctx_buf + off;
+    ConvParams p;
+    memset(&p, 0, sizeof(p));
+    p.x = c16.p; p.C1 = D; p.B = 1; p.Hin = 1; p.Win = rows; p.Hout = 1; p.Wout = rows; p.ks = 1; p.stride = 1;
+    p.w = t->kv2.w; p.N = 2 * t->C; p.Nrows = t->kv2.Nrows; p.K = D;
+    p.y = t->kv_ctx; p.ldy = 2 * t->C; p.M = rows;
+    launch_igemm(p, s);
+    off += (size_t)rows * 2 * t->C;
+  }
+  ex.release(c16);
+  ctx_B = Bc; ctx_L = L;
+}
+
+Act ldiff_unet::resnet(const ResnetW& r, const Act& x, const Act* skip, const float* temb_all) {
+  const int G = cfg.norm_num_groups;
+  GNss g1 = ex.gn(x, skip, r.n1, G, cfg.norm_eps);
+  ConvOpts o1;
+  o1.gn = &g1; o1.silu = 1; o1.temb = temb_all + r.temb_off; o1.ld_temb = temb_total;
+  Act h = ex.conv(r.c1, x, skip, o1);
+  ex.release(g1);
+  GNss g2 = ex.gn(h, nullptr, r.n2, G, cfg.norm_eps);
+  Act sc;
+  const Act* resp = &x;
+  if (r.has_sc) { sc = ex.conv(r.sc, x, skip, ConvOpts()); resp = &sc; }
+  else LDIFF_CHECK(skip == nullptr, LDIFF_ERR_RUNTIME, "resnet: concat input without shortcut conv");
+  ConvOpts o2;
+  o2.gn = &g2; o2.silu = 1; o2.res = resp;
+  Act out = ex.conv(r.c2, h, nullptr, o2);
+  ex.release(g2);
+  ex.release(h);
+  if (r.has_sc) ex.release(sc);
+  return out;
+}
+
+Act ldiff_unet::transformer(const TransformerW& t, const Act& x) {
+  const int C = t.C, heads = cfg.heads, d = C / heads, L = x.H * x.W;
+  GNss g = ex.gn(x, nullptr, t.gn, cfg.norm_num_groups, 1e-6f);
+  ConvOpts oi;
+  oi.gn = &g; oi.silu = 0;
+  Act h = ex.conv(t.proj_in, x, nullptr, oi);
+  ex.release(g);
+  // self-attention
+  Act n1 = ex.layernorm(h, t.ln1);
+  Act qkv = ex.conv(t.qkv, n1, nullptr, ConvOpts());
+  ex.release(n1);
+  Act a1 = ex.new_act(x.B, x.H, x.W, C);
+  AttnParams ap;
+  ap.q = qkv.p; ap.ldq = 3 * C; ap.k = qkv.p + C; ap.ldk = 3 * C; ap.v = qkv.p + 2 * C; ap.ldv = 3 * C;
+  ap.o = a1.p; ap.ldo = C; ap.B = x.B; ap.heads = heads; ap.Lq = L; ap.Lk = L; ap.d = d;
+  ap.q_bstride = (long long)L * 3 * C; ap.kv_bstride = (long long)L * 3 * C; ap.o_bstride = (long long)L * C;
+  ap.scale = 1.0f / sqrtf((float)d);
+  launch_attention(ap, ex.s);
+  ex.release(qkv);
+  ConvOpts o1;
+  o1.res = &h;
+  Act h2 = ex.conv(t.out1, a1, nullptr, o1);
+  ex.release(a1);
+  ex.release(h);
+  // cross-attention (K/V precomputed per prompt)
+  Act n2 = ex.layernorm(h2, t.ln2);
+  Act q2 = ex.conv(t.q2, n2, nullptr, ConvOpts());
+  ex.release(n2);
+  Act a2 = ex.new_act(x.B, x.H, x.W, C);
+  ap.q = q2.p; ap.ldq = C; ap.k = t.kv_ctx; ap.ldk = 2 * C; ap.v = t.kv_ctx + C; ap.ldv = 2 * C;
+  ap.o = a2.p; ap.Lk = ctx_L; ap.q_bstride = (long long)L * C;
+  ap.kv_bstride = ctx_B == 1 ? 0 : (long long)ctx_L * 2 * C;
+  launch_attention(ap, ex.s);
+  ex.release(q2);
+  ConvOpts o2;
+  o2.res = &h2;
+  Act h3 = ex.conv(t.out2, a2, nullptr, o2);
+  ex.release(a2);
+  ex.release(h2);
+  // GEGLU feed-forward
+  Act n3 = ex.layernorm(h3, t.ln3);
+  Act f1 = ex.conv(t.ff1, n3, nullptr, ConvOpts());
+  ex.release(n3);
+  Act gg = ex.geglu(f1);
+  ex.release(f1);
+  ConvOpts o3;
+  o3.res = &h3;
+  Act h4 = ex.conv(t.ff2, gg, nullptr, o3);
+  ex.release(gg);
+  ex.release(h3);
+  ConvOpts oo;
+  oo.res = &x;
+  Act out = ex.conv(t.proj_out, h4, nullptr, oo);
+  ex.release(h4);
+  return out;
+}
+
+void ldiff_unet::forward(const float* x, int B, int h, int w, float tval, float* out, hipStream_t s) {
+  LDIFF_CHECK(x && out && B >= 1 && h >= 1 && w >= 1, LDIFF_ERR_INVALID, "unet_forward: bad arguments (B=%d h=%d w=%d)", B, h, w);
+  const int nb = cfg.n_blocks;
+  LDIFF_CHECK(h % (1 << (nb - 1)) == 0 && w % (1 << (nb - 1)) == 0, LDIFF_ERR_INVALID, "unet_forward: latent size %dx%d must be divisible by %d", h, w, 1 << (nb - 1));
+  LDIFF_CHECK(ws.missing() == 0, LDIFF_ERR_STATE, "unet: %d weight tensors not loaded (first: %s)", ws.missing(), ws.missing_name(0));
+  LDIFF_CHECK(ctx_L > 0, LDIFF_ERR_STATE, "unet: set_context has not been called");
+  LDIFF_CHECK(ctx_B == 1 || ctx_B == B, LDIFF_ERR_INVALID, "unet: context batch %d does not match sample batch %d", ctx_B, B);
+  HIP_CHECK(hipSetDevice(device));
+  ex.s = s;
+  const int C0 = cfg.block_out_channels[0];
+  int Cmax = 0;
+  for (int i = 0; i < nb; ++i) Cmax = std::max(Cmax, cfg.block_out_channels[i]);
+  ex.arena.reserve((size_t)B * h * w * C0 * 2 * 96 + (size_t)B * temb_total * 16 + (64u << 20));
+  ex.ensure_gn_partial(gn_partial_bytes(B, h * w, 2 * Cmax));
+
+  // time embedding: sinusoid -> linear_1 -> SiLU -> linear_2, then SiLU once and all 22 per-resnet projections in one GEMM
+  const int td = C0 * 4;
+  Act e16 = ex.new_act(1, 1, B, C0);
+  launch_timestep_embed(tval, e16.p, B, C0, cfg.flip_sin_to_cos, cfg.freq_shift, s);
+  float* l1 = ex.tmp<float>((size_t)B * td);
+  { ConvOpts o; o.out_f32 = l1; o.ldy_f32 = td; ex.conv(t_lin1, e16, nullptr, o); }
+  Act l1h = ex.new_act(1, 1, B, td);
+  launch_silu_f32_to_f16(l1, l1h.p, (long long)B * td, s);
+  float* l2 = ex.tmp<float>((size_t)B * td);
+  { ConvOpts o; o.out_f32 = l2; o.ldy_f32 = td; ex.conv(t_lin2, l1h, nullptr, o); }
+  Act l2h = ex.new_act(1, 1, B, td);
+  launch_silu_f32_to_f16(l2, l2h.p, (long long)B * td, s);
+  float* temb_all = ex.tmp<float>((size_t)B * temb_total);
+  { ConvOpts o; o.out_f32 = temb_all; o.ldy_f32 = temb_total; ex.conv(temb_proj_all, l2h, nullptr, o); }
+  ex.release(e16); ex.arena.free(l1); ex.release(l1h); ex.arena.free(l2); ex.release(l2h);
+
+  Act x16 = ex.new_act(B, h, w, 8);
+  launch_nchw_f32_to_nhwc_f16(x, x16.p, B, cfg.in_channels, h, w, 8, s);
+  Act cur = ex.conv(conv_in, x16, nullptr, ConvOpts());
+  ex.release(x16);
+
+  std::vector<Act> skips{cur};
+  bool cur_is_skip = true;
+  auto advance = [&](Act nxt) {
+    if (!cur_is_skip) ex.release(cur);
+    cur = nxt;
+    cur_is_skip = false;
+  };
+  for (int i = 0; i < nb; ++i) {
+    for (size_t j = 0; j < down_res[i].size(); ++j) {
+      advance(resnet(down_res[i][j], cur, nullptr, temb_all));
+      if (cfg.down_has_attn[i]) advance(transformer(down_attn[i][j], cur));
+      skips.push_back(cur);
+      cur_is_skip = true;
+    }
+    if (has_down[i]) {
+      ConvOpts o;
+      o.stride = 2;
+      advance(ex.conv(down_sample[i], cur, nullptr, o));
+      skips.push_back(cur);
+      cur_is_skip = true;
+    }
+  }
+  advance(resnet(mid_res[0], cur, nullptr, temb_all));
+  advance(transformer(mid_attn, cur));
+  advance(resnet(mid_res[1], cur, nullptr, temb_all));
+  for (int i = 0; i < nb; ++i) {
+    for (size_t j = 0; j < up_res[i].size(); ++j) {
+      Act sk = skips.back();
+      skips.pop_back();
+      advance(resnet(up_res[i][j], cur, &sk, temb_all));
+      ex.release(sk);
+      if (cfg.up_has_attn[i]) advance(transformer(up_attn[i][j], cur));
+    }
+    if (has_up[i]) {
+      ConvOpts o;
+      o.ups = 1;
+      advance(ex.conv(up_sample[i], cur, nullptr, o));
+    }
+  }
+  GNss g = ex.gn(cur, nullptr, norm_out, cfg.norm_num_groups, cfg.norm_eps);
+  const int Nst = roundup(cfg.out_channels, 4);
+  float* o32 = ex.tmp<float>((size_t)B * h * w * Nst);
+  { ConvOpts o; o.gn = &g; o.silu = 1; o.out_f32 = o32; o.ldy_f32 = Nst; ex.conv(conv_out, cur, nullptr, o); }
+  launch_nhwc_f32_to_nchw_f32(o32, out, B, cfg.out_channels, h, w, Nst, s);
+  ex.release(g);
+  ex.arena.free(o32);
+  ex.release(cur);
+  ex.arena.free(temb_all);
+  LDIFF_CHECK(skips.empty(), LDIFF_ERR_RUNTIME, "unet: skip stack not empty at exit");
+}
+
+// ================================================================================================
+// VAE
+// ================================================================================================
+static VaeAttnW make_vae_attn(WeightStore& ws, const std::string& p, int C) {
+  VaeAttnW a;
+  a.C = C;
+  a.gn = ws.add_norm(p + ".group_norm", C);
+  a.qkv.N = 3 * C; a.qkv.Nrows = roundup(3 * C, 16); a.qkv.ks = 1; a.qkv.Cin = C; a.qkv.K = C;
+  a.qkv.w = ws.alloc_mat(a.qkv.Nrows, C);
+  a.qkv.b = ws.alloc_vec(a.qkv.Nrows);
+  const char* nn[3] = {"to_q", "to_k", "to_v"};
+  const char* old[3] = {"query", "key", "value"};
+  for (int i = 0; i < 3; ++i) {
+    ws.add_rows(p + "." + nn[i] + ".weight", p + "." + nn[i] + ".bias", a.qkv.w, C, 1, C, C, i * C, C, a.qkv.b, true);
+    ws.alias(p + "." + old[i] + ".weight", p + "." + nn[i] + ".weight");
+    ws.alias(p + "." + old[i] + ".bias", p + "." + nn[i] + ".bias");
+  }
+  a.out = ws.add_conv(p + ".to_out.0", C, C, 1);
+  ws.alias(p + ".proj_attn.weight", p + ".to_out.0.weight");
+  ws.alias(p + ".proj_attn.bias", p + ".to_out.0.bias");
+  return a;
+}
+
+void ldiff_vae::build() {
+  const int nb = cfg.n_blocks, lpb = cfg.layers_per_block, lat = cfg.latent_channels;
+  const int* boc = cfg.block_out_channels;
+  LDIFF_CHECK(nb >= 1 && nb <= LDIFF_MAX_BLOCKS, LDIFF_ERR_INVALID, "vae: n_blocks=%d out of range", nb);
+  LDIFF_CHECK(cfg.in_channels <= 8 && cfg.out_channels <= 4 && lat <= 4 && lat >= 1, LDIFF_ERR_INVALID, "vae: in<=8, out<=4, latent<=4 channels supported");
+  for (int i = 0; i < nb; ++i)
+    LDIFF_CHECK(boc[i] % cfg.norm_num_groups == 0 && boc[i] % 8 == 0, LDIFF_ERR_INVALID, "vae: channels %d not divisible by groups/8", boc[i]);
+  // encoder
+  e_conv_in = ws.add_conv("encoder.conv_in", cfg.in_channels, boc[0], 3, true, 8);
+  int ch = boc[0];
+  e_res.resize(nb); e_down.resize(nb);
+  for (int i = 0; i < nb; ++i) {
+    for (int j = 0; j < lpb; ++j) {
+      e_res[i].push_back(make_resnet(ws, "encoder.down_blocks." + std::to_string(i) + ".resnets." + std::to_string(j), ch, boc[i], false));
+      ch = boc[i];
+    }
+    if (i != nb - 1) e_down[i] = ws.add_conv("encoder.down_blocks." + std::to_string(i) + ".downsamplers.0.conv", ch, ch, 3);
+  }
+  e_mid[0] = make_resnet(ws, "encoder.mid_block.resnets.0", ch, ch, false);
+  e_attn = make_vae_attn(ws, "encoder.mid_block.attentions.0", ch);
+  e_mid[1] = make_resnet(ws, "encoder.mid_block.resnets.1", ch, ch, false);
+  e_norm_out = ws.add_norm("encoder.conv_norm_out", ch);
+  e_conv_out = ws.add_conv("encoder.conv_out", ch, 2 * lat, 3);
+  quant = ws.add_conv("quant_conv", 2 * lat, 2 * lat, 1, true, 8);
+  // decoder
+  post_quant = ws.add_conv("post_quant_conv", lat, lat, 1, true, 8);
+  ch = boc[nb - 1];
+  d_conv_in = ws.add_conv("decoder.conv_in", lat, ch, 3, true, 8);
+  d_mid[0] = make_resnet(ws, "decoder.mid_block.resnets.0", ch, ch, false);
+  d_attn = make_vae_attn(ws, "decoder.mid_block.attentions.0", ch);
+  d_mid[1] = make_resnet(ws, "decoder.mid_block.resnets.1", ch, ch, false);
+  d_res.resize(nb); d_up.resize(nb);
+  for (int i = 0; i < nb; ++i) {
+    const int oc = boc[nb - 1 - i];
+    for (int j = 0; j < lpb + 1; ++j) {
+      d_res[i].push_back(make_resnet(ws, "decoder.up_blocks." + std::to_string(i) + ".resnets." + std::to_string(j), ch, oc, false));
+      ch = oc;
+    }
+    if (i != nb - 1) d_up[i] = ws.add_conv("decoder.up_blocks." + std::to_string(i) + ".upsamplers.0.conv", ch, ch, 3);
+  }
+  d_norm_out = ws.add_norm("decoder.conv_norm_out", ch);
+  d_conv_out = ws.add_conv("decoder.conv_out", ch, cfg.out_channels, 3);
+}
+
+Act ldiff_vae::resnet(const ResnetW& r, const Act& x) {
+  const int G = cfg.norm_num_groups;
+  GNss g1 = ex.gn(x, nullptr, r.n1, G, 1e-6f);
+  ConvOpts o1;
+  o1.gn = &g1; o1.silu = 1;
+  Act h = ex.conv(r.c1, x, nullptr, o1);
+  ex.release(g1);
+  GNss g2 = ex.gn(h, nullptr, r.n2, G, 1e-6f);
+  Act sc;
+  const Act* resp = &x;
+  if (r.has_sc) { sc = ex.conv(r.sc, x, nullptr, ConvOpts()); resp = &sc; }
+  ConvOpts o2;
+  o2.gn = &g2; o2.silu = 1; o2.res = resp;
+  Act out = ex.conv(r.c2, h, nullptr, o2);
+  ex.release(g2);
+  ex.release(h);
+  if (r.has_sc) ex.release(sc);
+  return out;
+}
+
+Act ldiff_vae::mid_attention(const VaeAttnW& a, const Act& x) {
+  const int C = a.C, L = x.H * x.W;
+  GNss g = ex.gn(x, nullptr, a.gn, cfg.norm_num_groups, 1e-6f);
+  ConvOpts oq;
+  oq.gn = &g; oq.silu = 0;
+  Act qkv = ex.conv(a.qkv, x, nullptr, oq);
+  ex.release(g);
+  Act o = ex.new_act(x.B, x.H, x.W, C);
+  AttnParams ap;
+  ap.q = qkv.p; ap.ldq = 3 * C; ap.k = qkv.p + C; ap.ldk = 3 * C; ap.v = qkv.p + 2 * C; ap.ldv = 3 * C;
+  ap.o = o.p; ap.ldo = C; ap.B = x.B; ap.heads = 1; ap.Lq = L; ap.Lk = L; ap.d = C;
+  ap.q_bstride = (long long)L * 3 * C; ap.kv_bstride = ap.q_bstride; ap.o_bstride = (long long)L * C;
+  ap.scale = 1.0f / sqrtf((float)C);
+  launch_attention(ap, ex.s);
+  ex.release(qkv);
+  ConvOpts oo;
+  oo.res = &x;
+  Act out = ex.conv(a.out, o, nullptr, oo);
+  ex.release(o);
+  return out;
+}
+
+void ldiff_vae::encode(const float* x, int B, int H, int W, float* moments, hipStream_t s) {
+  const int nb = cfg.n_blocks, f = 1 << (nb - 1);
+  LDIFF_CHECK(x && moments && B >= 1, LDIFF_ERR_INVALID, "vae_encode: bad arguments");
+  LDIFF_CHECK(H >= f && W >= f && H % f == 0 && W % f == 0, LDIFF_ERR_INVALID, "vae_encode: image size %dx%d must be a positive multiple of %d", H, W, f);
+  LDIFF_CHECK(ws.missing() == 0, LDIFF_ERR_STATE, "vae: %d weight tensors not loaded (first: %s)", ws.missing(), ws.missing_name(0));
+  HIP_CHECK(hipSetDevice(device));
+  ex.s = s;
+  const int* boc = cfg.block_out_channels;
+  int Cmax = 0;
+  for (int i = 0; i < nb; ++i) Cmax = std::max(Cmax, boc[i]);
+  ex.arena.reserve((size_t)B * H * W * boc[0] * 2 * 10 + (size_t)B * (H / f) * (W / f) * Cmax * 2 * 24 + (64u << 20));
+  ex.ensure_gn_partial(std::max(gn_partial_bytes(B, H * W, boc[0]), gn_partial_bytes(B, (H / f) * (W / f), Cmax)));
+  for (int i = 0; i < nb; ++i) ex.ensure_gn_partial(gn_partial_bytes(B, (H >> i) * (W >> i), boc[i]));
+
+  Act x16 = ex.new_act(B, H, W, 8);
+  launch_nchw_f32_to_nhwc_f16(x, x16.p, B, cfg.in_channels, H, W, 8, s);
+  Act cur = ex.conv(e_conv_in, x16, nullptr, ConvOpts());
+  ex.release(x16);
+  auto advance = [&](Act nxt) { ex.release(cur); cur = nxt; };
+  for (int i = 0; i < nb; ++i) {
+    for (auto& r : e_res[i]) advance(resnet(r, cur));
+    if (i != nb - 1) {
+      ConvOpts o;  // Downsample2D(padding=0): F.pad(x,(0,1,0,1)) then stride-2 conv without padding
+      o.stride = 2; o.pad_t = 0; o.pad_l = 0; o.Hout = cur.H / 2; o.Wout = cur.W / 2;
+      advance(ex.conv(e_down[i], cur, nullptr, o));
+    }
+  }
+  advance(resnet(e_mid[0], cur));
+  advance(mid_attention(e_attn, cur));
+  advance(resnet(e_mid[1], cur));
+  GNss g = ex.gn(cur, nullptr, e_norm_out, cfg.norm_num_groups, 1e-6f);
+  ConvOpts oc;
+  oc.gn = &g; oc.silu = 1;
+  Act m = ex.conv(e_conv_out, cur, nullptr, oc);   // [B,h,w,8] (2*latent channels, zero padded)
+  ex.release(g);
+  ex.release(cur);
+  const int Nst = roundup(2 * cfg.latent_channels, 4);
+  float* q32 = ex.tmp<float>((size_t)m.rows() * Nst);
+  { ConvOpts o; o.out_f32 = q32; o.ldy_f32 = Nst; ex.conv(quant, m, nullptr, o); }
+  launch_nhwc_f32_to_nchw_f32(q32, moments, B, 2 * cfg.latent_channels, m.H, m.W, Nst, s);
+  ex.arena.free(q32);
+  ex.release(m);
+}
+
+void ldiff_vae::decode(const float* z, int B, int h, int w, float z_scale, float* sample_nchw, float* image_nhwc, uint8_t* rgb, uint8_t* luma,
+                       int n_slots, int slot, hipStream_t s) {
+  const int nb = cfg.n_blocks, f = 1 << (nb - 1);
+  LDIFF_CHECK(z && B >= 1 && h >= 1 && w >= 1, LDIFF_ERR_INVALID, "vae_decode: bad arguments");
+  LDIFF_CHECK(ws.missing() == 0, LDIFF_ERR_STATE, "vae: %d weight tensors not loaded (first: %s)", ws.missing(), ws.missing_name(0));
+  LDIFF_CHECK(!luma || (slot >= 0 && slot < n_slots), LDIFF_ERR_INVALID, "vae_decode: luma slot %d out of range [0,%d)", slot, n_slots);
+  HIP_CHECK(hipSetDevice(device));
+  ex.s = s;
+  const int* boc = cfg.block_out_channels;
+  const int H = h * f, W = w * f;
+  int Cmax = 0;
+  for (int i = 0; i < nb; ++i) Cmax = std::max(Cmax, boc[i]);
+  ex.arena.reserve((size_t)B * H * W * boc[0] * 2 * 10 + (size_t)B * h * w * Cmax * 2 * 24 + (64u << 20));
+  for (int i = 0; i < nb; ++i) ex.ensure_gn_partial(gn_partial_bytes(B, (H >> i) * (W >> i), boc[std::min(i + 1, nb - 1)]));
+  ex.ensure_gn_partial(gn_partial_bytes(B, h * w, Cmax));
+
+  const long long nz = (long long)B * cfg.latent_channels * h * w;
+  float* zs = ex.tmp<float>((size_t)nz);
+  launch_scale_f32(z, zs, z_scale, nz, s);
+  Act z16 = ex.new_act(B, h, w, 8);
+  launch_nchw_f32_to_nhwc_f16(zs, z16.p, B, cfg.latent_channels, h, w, 8, s);
+  ex.arena.free(zs);
+  ConvOpts opq;
+  opq.N_override = 8; opq.ldy = 8;   // rows >= latent_channels are zero => pad channels come out zero
+  Act pq = ex.conv(post_quant, z16, nullptr, opq);
+  ex.release(z16);
+  Act cur = ex.conv(d_conv_in, pq, nullptr, ConvOpts());
+  ex.release(pq);
+  auto advance = [&](Act nxt) { ex.release(cur); cur = nxt; };
+  advance(resnet(d_mid[0], cur));
+  advance(mid_attention(d_attn, cur));
+  advance(resnet(d_mid[1], cur));
+  for (int i = 0; i < nb; ++i) {
+    for (auto& r : d_res[i]) advance(resnet(r, cur));
+    if (i != nb - 1) {
+      ConvOpts o;
+      o.ups = 1;
+      advance(ex.conv(d_up[i], cur, nullptr, o));
+    }
+  }
+  GNss g = ex.gn(cur, nullptr, d_norm_out, cfg.norm_num_groups, 1e-6f);
+  const int Nst = 4;
+  float* o32 = ex.tmp<float>((size_t)B * H * W * Nst);
+  { ConvOpts o; o.gn = &g; o.silu = 1; o.out_f32 = o32; o.ldy_f32 = Nst; ex.conv(d_conv_out, cur, nullptr, o); }
+  ex.release(g);
+  ex.release(cur);
+  if (sample_nchw) launch_nhwc_f32_to_nchw_f32(o32, sample_nchw, B, cfg.out_channels, H, W, Nst, s);
+  if (image_nhwc || rgb || luma) {
+    LDIFF_CHECK(cfg.out_channels == 3, LDIFF_ERR_INVALID, "vae_decode: image outputs need 3 output channels");
+    launch_decode_post(o32, Nst, B, H, W, image_nhwc, rgb, luma, n_slots, slot, s);
+  }
+  ex.arena.free(o32);
+}
+
+// ================================================================================================
+// PNDM host logic (SD-v1.5 scheduler_config.json)
+// ================================================================================================
+void pndm_alphas_cumprod(float* out) {
+  // torch.linspace(sqrt(b0), sqrt(b1), 1000, dtype=float32) ** 2 -> cumprod(1 - beta), all float32.
+  // (python evaluates beta ** 0.5 in double and torch narrows it to float32.)  ATen's vectorised fill rounds
+  // start + step*i in two steps, so this table agrees with torch's to ~2 ulp, not bit for bit; callers that need
+  // torch's exact table pass it through ldiff_pipeline_set_alphas_cumprod (the python shim does).
+  const float start = (float)sqrt(0.00085), end = (float)sqrt(0.012);
+  // ATen linspace: step = (end-start)/(steps-1); first half start + i*step, second half end - (steps-1-i)*step
+  const int steps = 1000, halfway = steps / 2;
+  const float step = (end - start) / (float)(steps - 1);
+  float acc = 1.0f;
+  for (int i = 0; i < steps; ++i) {
+    float v = i < halfway ? start + step * (float)i : end - step * (float)(steps - i - 1);
+    float beta = v * v;
+    acc = acc * (1.0f - beta);
+    out[i] = acc;
+  }
+}
+int plms_timesteps(int n_passes, int64_t* out, int cap) {
+  // PNDMScheduler.set_timesteps(n), skip_prk_steps, leading spacing, steps_offset 1; n = N-1 (N>=3) or 1 (N==1)
+  LDIFF_CHECK(n_passes == 1 || n_passes >= 3, LDIFF_ERR_INVALID,
+              "n_passes=%d: the reference's set_timesteps(N-1) yields N passes only for N>=3 (N=1 via set_timesteps(1))", n_passes);
+  const int n = n_passes == 1 ? 1 : n_passes - 1;
+  LDIFF_CHECK(n <= 1000, LDIFF_ERR_INVALID, "n_passes=%d exceeds the 1000 training timesteps", n_passes);
+  const int ratio = 1000 / n;
+  std::vector<int64_t> ts(n);
+  for (int i = 0; i < n; ++i) ts[i] = (int64_t)i * ratio + 1;
+  std::vector<int64_t> pl;
+  for (int i = 0; i < n - 1; ++i) pl.push_back(ts[i]);
+  if (n >= 2) pl.push_back(ts[n - 2]);
+  pl.push_back(ts[n - 1]);
+  std::reverse(pl.begin(), pl.end());
+  LDIFF_CHECK((int)pl.size() <= cap, LDIFF_ERR_INVALID, "plms_timesteps: output capacity %d < %zu", cap, pl.size());
+  for (size_t i = 0; i < pl.size(); ++i) out[i] = pl[i];
+  return (int)pl.size();
+}

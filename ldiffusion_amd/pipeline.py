@@ -1,0 +1,149 @@
+"""`pipeline` shim (StableDiffusionImg2ImgPipeline surface) and the batched Laplace-diffusion sampler.
+
+Surface used by the reference:
+  pipeline.vae / .unet / .scheduler / .tokenizer / .text_encoder / .decode_latents(z) / .numpy_to_pil(np) / .to(device)
+  /root/reference/segmentor.py:32,57-59,77-80,106-107   ldiffusion.py:67-69,141,213-216   pixel_latent_vector.py:41-47,81-82
+`LaplaceSampler` is the batched, device-resident form of the per-image loop bodies
+  pixel_latent_vector.py:72-93 (N passes, luma feature per pass) and segmentor.py:99-107 / 519-530 (one pass),
+running entirely inside libldiff_hip.so (`ldiff_sample`).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import torch
+
+from . import _lib, weights
+from .models import AutoencoderKL, UNet2DConditionModel
+from .scheduler import PNDMScheduler
+
+PROMPT = "A pathological slide"  # segmentor.py:92, ldiffusion.py:210, pixel_latent_vector.py:65
+
+
+class StableDiffusionImg2ImgPipeline:
+    def __init__(self, vae: AutoencoderKL, unet: UNet2DConditionModel, scheduler=None, tokenizer=None, text_encoder=None):
+        self.vae, self.unet = vae, unet
+        self.scheduler = scheduler if scheduler is not None else PNDMScheduler()
+        self.tokenizer, self.text_encoder = tokenizer, text_encoder
+        self.device = vae.device
+
+    @classmethod
+    def from_pretrained(cls, path, torch_dtype=None, device=None, **_ignored):
+        """Reads the diffusers SD directory layout: {unet,vae}/(config.json + safetensors), scheduler/scheduler_config.json,
+        and tokenizer/ + text_encoder/ through `transformers` when those folders exist (CLIP is outside the kernel scope)."""
+        if torch_dtype not in (None, torch.float32):
+            raise ValueError("the reference loads the pipeline in float32 (ldiffusion.py:67); other dtypes are not supported")
+        unet = UNet2DConditionModel.from_pretrained(os.path.join(path, "unet"), device=device)
+        vae = AutoencoderKL.from_pretrained(os.path.join(path, "vae"), device=device)
+        sched_cfg = {}
+        sp = os.path.join(path, "scheduler", "scheduler_config.json")
+        if os.path.exists(sp):
+            with open(sp) as f:
+                sched_cfg = {k: v for k, v in json.load(f).items() if k in ("num_train_timesteps", "beta_start", "beta_end", "steps_offset")}
+        tok = enc = None
+        if os.path.isdir(os.path.join(path, "tokenizer")) and os.path.isdir(os.path.join(path, "text_encoder")):
+            from transformers import CLIPTextModel, CLIPTokenizer
+            tok = CLIPTokenizer.from_pretrained(os.path.join(path, "tokenizer"))
+            enc = CLIPTextModel.from_pretrained(os.path.join(path, "text_encoder")).to(vae.device)
+        return cls(vae, unet, PNDMScheduler(**sched_cfg), tok, enc)
+
+    def to(self, *a, **k):
+        return self
+
+    def decode_latents(self, latents):
+        """(1/scaling_factor * z) -> vae.decode -> (x/2+0.5).clamp(0,1) -> NHWC float32 numpy on the host."""
+        _, image, _ = self.vae._decode(latents, 1.0 / self.vae.config.scaling_factor, want_image=True)
+        return image.cpu().numpy()
+
+    @staticmethod
+    def numpy_to_pil(images):
+        from PIL import Image
+        if images.ndim == 3:
+            images = images[None, ...]
+        images = (images * 255).round().astype("uint8")
+        return [Image.fromarray(im) for im in images]
+
+
+class LaplaceSampler:
+    """Batched sampler over [B,3,H,W] patches; everything stays on the GPU until the caller reads the outputs."""
+
+    def __init__(self, pipeline: StableDiffusionImg2ImgPipeline):
+        _lib.require_gpu()
+        self.pipeline = pipeline
+        self._lib = _lib.load()
+        self._h = C.c_void_p()
+        _lib.check(self._lib.ldiff_pipeline_create(C.byref(self._h), pipeline.unet._h, pipeline.vae._h))
+        abar = pipeline.scheduler.alphas_cumprod.detach().to("cpu", torch.float32).contiguous()
+        _lib.check(self._lib.ldiff_pipeline_set_alphas_cumprod(self._h, C.cast(abar.data_ptr(), C.POINTER(C.c_float)), abar.numel()))
+
+    def timesteps(self, num_inference_steps: int):
+        buf = (C.c_int64 * 1024)()
+        n = self._lib.ldiff_plms_timesteps(int(num_inference_steps), buf, 1024)
+        _lib.check(n if n < 0 else 0)
+        return [int(buf[i]) for i in range(n)]
+
+    def sample(self, images: torch.Tensor, encoder_hidden_states: torch.Tensor, num_inference_steps: int,
+               want_features=True, want_rgb=True):
+        """Returns dict(latents [B,4,h,w] f32, features [B,N,H,W] u8, rgb [B,H,W,3] u8) as CUDA tensors."""
+        vae, unet = self.pipeline.vae, self.pipeline.unet
+        if images.dim() != 4 or images.shape[1] != 3:
+            raise ValueError(f"images must be [B,3,H,W], got {tuple(images.shape)}")
+        x = images.detach().to(vae.device, dtype=torch.float32).contiguous()
+        B, _, H, W = x.shape
+        if encoder_hidden_states.shape[0] not in (1, B):
+            raise ValueError("encoder_hidden_states batch must be 1 or the image batch")
+        unet.set_context(encoder_hidden_states)
+        N = len(self.timesteps(num_inference_steps))
+        f = vae.scale_factor
+        lat = torch.empty((B, vae.config.latent_channels, H // f, W // f), device=vae.device, dtype=torch.float32)
+        feats = torch.empty((B, N, H, W), device=vae.device, dtype=torch.uint8) if want_features else None
+        rgb = torch.empty((B, H, W, 3), device=vae.device, dtype=torch.uint8) if want_rgb else None
+        _lib.check(self._lib.ldiff_sample(self._h, _lib.ptr(x), B, H, W, int(num_inference_steps), _lib.ptr(lat), _lib.ptr(feats), _lib.ptr(rgb),
+                                          _lib.stream_ptr()))
+        return dict(latents=lat, features=feats, rgb=rgb)
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                self._lib.ldiff_pipeline_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+
+def argmax_mask(logits: torch.Tensor) -> torch.Tensor:
+    """segmentor.py:536-537 `argmax(softmax(out,1),1)` -> uint8 [B,H,W] on the GPU."""
+    _lib.require_gpu()
+    if logits.dim() != 4:
+        raise ValueError(f"logits must be [B,C,H,W], got {tuple(logits.shape)}")
+    x = logits.detach().to(dtype=torch.float32).contiguous()
+    B, Cc, H, W = x.shape
+    out = torch.empty((B, H, W), device=x.device, dtype=torch.uint8)
+    _lib.check(_lib.load().ldiff_argmax_u8(_lib.ptr(x), B, Cc, H, W, _lib.ptr(out), _lib.stream_ptr()))
+    return out
+
+
+def laplace_noise(z0: torch.Tensor, scale: float, u: torch.Tensor = None, seed: int = 0, offset: int = 0) -> torch.Tensor:
+    """ldiffusion.py:234-237: z0 + Laplace(0, scale).sample() -- given `u` (parity) or from the device Philox stream."""
+    _lib.require_gpu()
+    z = z0.detach().to(dtype=torch.float32).contiguous()
+    out = torch.empty_like(z)
+    if u is not None:
+        if u.shape != z.shape:
+            raise ValueError("u must have the shape of z0")
+        u = u.detach().to(z.device, dtype=torch.float32).contiguous()
+    _lib.check(_lib.load().ldiff_laplace_add(_lib.ptr(z), float(scale), _lib.ptr(u), int(seed), int(offset), _lib.ptr(out), z.numel(), _lib.stream_ptr()))
+    return out
+
+
+def luma_float(rgb: torch.Tensor) -> torch.Tensor:
+    """ldiffusion.py:241-242 float luma, [B,3,H,W] -> [B,1,H,W]."""
+    _lib.require_gpu()
+    x = rgb.detach().to(dtype=torch.float32).contiguous()
+    B, _, H, W = x.shape
+    out = torch.empty((B, 1, H, W), device=x.device, dtype=torch.float32)
+    _lib.check(_lib.load().ldiff_luma_float(_lib.ptr(x), _lib.ptr(out), B, H, W, _lib.stream_ptr()))
+    return out

@@ -1,0 +1,310 @@
+"""-m gpu: every HIP kernel through the C ABI against plain torch CPU ops on the same fp16-rounded inputs.
+
+Tolerance (floating-point path, stated per the task contract): operands are fp16, accumulation fp32, outputs
+rounded to fp16 (rel. 2^-11), so |got - ref| <= 2e-3*max|ref| + 2e-3*|ref| unless a test says otherwise.
+Integer outputs (uint8 images, luma, argmax) are compared bit-exactly given identical float inputs.
+"""
+import ctypes as C
+import math
+import zlib
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from ldiffusion_amd import _lib
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def sp():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def nhwc16(x):  # [B,C,H,W] f32 cpu -> [B,H,W,C] f16 cuda
+    return x.permute(0, 2, 3, 1).contiguous().to(torch.float16).to(DEV)
+
+
+def r16(x):  # fp16-rounded copy kept in fp32 (what the kernel actually sees)
+    return x.to(torch.float16).to(torch.float32)
+
+
+def assert_close(got, ref, what, rtol=2e-3, atol_rel=2e-3):
+    got, ref = got.float().cpu(), ref.float().cpu()
+    assert got.shape == ref.shape, f"{what}: shape {tuple(got.shape)} vs {tuple(ref.shape)}"
+    assert torch.isfinite(got).all(), f"{what}: non-finite output"
+    err = (got - ref).abs()
+    tol = atol_rel * ref.abs().max() + rtol * ref.abs()
+    bad = err > tol
+    assert not bad.any(), f"{what}: {int(bad.sum())}/{bad.numel()} out of tolerance, max err {err.max():.4e} (max|ref| {ref.abs().max():.3f})"
+
+
+def run_conv(lib, x, w, bias=None, x2=None, stride=1, pad=(1, 1), ups=0, gn=None, silu=0, temb=None, res=None, out_f32=False,
+             asym=False):
+    """x,x2: [B,C,H,W] f32 cpu; w: [Cout,Cin,ks,ks].  Returns ([B,Cout,Ho,Wo] got, ref)."""
+    B, C1, H, W = x.shape
+    C2 = x2.shape[1] if x2 is not None else 0
+    Cout, Cin, ks, _ = w.shape
+    assert Cin == C1 + C2
+    xin = r16(x) if x2 is None else torch.cat([r16(x), r16(x2)], 1)
+    # ---- reference ----
+    a = xin
+    if gn is not None:
+        scale, shift = gn  # [B, Cin]
+        a = a * scale[:, :, None, None] + shift[:, :, None, None]
+        if silu:
+            a = F.silu(a)
+        a = r16(a)  # the kernel rounds the normalised operand to fp16 before the MFMA
+    if ups:
+        a = F.interpolate(a, scale_factor=2.0, mode="nearest")
+    wr = r16(w)
+    if asym:
+        a = F.pad(a, (0, 1, 0, 1))
+        ref = F.conv2d(a, wr, None, stride=stride, padding=0)
+    else:
+        ref = F.conv2d(a, wr, None, stride=stride, padding=pad[0])
+    if bias is not None:
+        ref = ref + bias[None, :, None, None]
+    if temb is not None:
+        ref = ref + temb[:, :, None, None]
+    if res is not None:
+        ref = ref + r16(res)
+    Ho, Wo = ref.shape[2], ref.shape[3]
+    # ---- device ----
+    Nrows = (Cout + 15) // 16 * 16
+    Nst = (Cout + 3) // 4 * 4
+    wd = torch.zeros((Nrows, ks, ks, Cin), dtype=torch.float16)
+    wd[:Cout] = w.permute(0, 2, 3, 1).to(torch.float16)
+    wd = wd.reshape(Nrows, ks * ks * Cin).contiguous().to(DEV)
+    keep = [wd]
+    a_ = _lib.ConvArgs()
+    xd = nhwc16(x); keep.append(xd)
+    a_.x = xd.data_ptr(); a_.C1 = C1
+    if x2 is not None:
+        x2d = nhwc16(x2); keep.append(x2d)
+        a_.x2 = x2d.data_ptr(); a_.C2 = C2
+    a_.B, a_.Hin, a_.Win, a_.Hout, a_.Wout = B, H, W, Ho, Wo
+    a_.ks, a_.stride, a_.ups = ks, stride, ups
+    a_.pad_t, a_.pad_l = (0, 0) if asym else pad
+    a_.w = wd.data_ptr(); a_.N = Nst; a_.Nrows = Nrows
+    if gn is not None:
+        sd, hd = gn[0].contiguous().to(DEV), gn[1].contiguous().to(DEV); keep += [sd, hd]
+        a_.gn_scale, a_.gn_shift, a_.silu_in = sd.data_ptr(), hd.data_ptr(), silu
+    if bias is not None:
+        bd = torch.zeros(Nrows); bd[:Cout] = bias; bd = bd.to(DEV); keep.append(bd)
+        a_.bias = bd.data_ptr()
+    if temb is not None:
+        ld = (Cout + 3) // 4 * 4
+        td = torch.zeros((B, ld)); td[:, :Cout] = temb; td = td.to(DEV); keep.append(td)
+        a_.temb, a_.ld_temb = td.data_ptr(), ld
+    if res is not None:
+        rd = torch.zeros((B, Ho, Wo, Nst), dtype=torch.float16); rd[..., :Cout] = res.permute(0, 2, 3, 1).to(torch.float16)
+        rd = rd.to(DEV); keep.append(rd)
+        a_.res, a_.ld_res = rd.data_ptr(), Nst
+    y = torch.full((B, Ho, Wo, Nst), float("nan"), dtype=torch.float32 if out_f32 else torch.float16, device=DEV)
+    a_.y, a_.ldy, a_.out_f32 = y.data_ptr(), Nst, int(out_f32)
+    _lib.check(lib.ldiff_op_conv(C.byref(a_), sp()))
+    torch.cuda.synchronize()
+    got = y[..., :Cout].permute(0, 3, 1, 2).float().cpu()
+    return got, ref
+
+
+CONV_CASES = {
+    # name: (B, C1, C2, H, W, Cout, ks, stride, ups, asym, gn, extras)
+    "3x3_64_64": (2, 64, 0, 16, 16, 64, 3, 1, 0, False, False, False),
+    "3x3_320_320_tile128x64": (2, 320, 0, 128, 96, 320, 3, 1, 0, False, False, True),
+    "3x3_128_256_tile128x128": (8, 128, 0, 64, 64, 256, 3, 1, 0, False, True, True),
+    "1x1_linear_tailM": (1, 320, 0, 1, 300, 960, 1, 1, 0, False, False, False),
+    "3x3_stride2_sym": (2, 64, 0, 16, 16, 128, 3, 2, 0, False, False, False),
+    "3x3_stride2_asym_vae": (2, 64, 0, 16, 16, 64, 3, 2, 0, True, False, False),
+    "3x3_upsample2x": (2, 128, 0, 8, 8, 128, 3, 1, 1, False, False, True),
+    "3x3_concat_128_64_gn": (2, 128, 64, 16, 16, 128, 3, 1, 0, False, True, True),
+    "1x1_concat_shortcut": (2, 128, 64, 16, 16, 64, 1, 1, 0, False, False, False),
+    "3x3_cin8_general_path": (2, 8, 0, 32, 32, 320, 3, 1, 0, False, False, False),
+    "3x3_cin32_general_path_gn": (2, 32, 0, 16, 16, 32, 3, 1, 0, False, True, True),
+    "3x3_cout4_f32": (2, 320, 0, 16, 16, 4, 3, 1, 0, False, True, False),
+    "3x3_cout3_f32": (1, 128, 0, 32, 32, 3, 3, 1, 0, False, True, False),
+    "1x1_cin8_cout8": (2, 8, 0, 8, 8, 8, 1, 1, 0, False, False, False),
+    "3x3_1x1_spatial": (3, 64, 0, 1, 1, 64, 3, 1, 0, False, False, False),
+}
+
+
+@pytest.mark.parametrize("name", list(CONV_CASES))
+def test_conv(lib, name):
+    B, C1, C2, H, W, Cout, ks, stride, ups, asym, use_gn, extras = CONV_CASES[name]
+    g = torch.Generator().manual_seed(zlib.crc32(name.encode()) % 1000)
+    Cin = C1 + C2
+    x = torch.randn((B, C1, H, W), generator=g)
+    x2 = torch.randn((B, C2, H, W), generator=g) if C2 else None
+    w = torch.randn((Cout, Cin, ks, ks), generator=g) / math.sqrt(Cin * ks * ks)
+    bias = torch.randn(Cout, generator=g) * 0.1
+    gn = (1.0 + 0.2 * torch.randn((B, Cin), generator=g), 0.2 * torch.randn((B, Cin), generator=g)) if use_gn else None
+    out_f32 = Cout <= 4
+    He, We = H << ups, W << ups
+    Ho = He // 2 if asym else (He + 2 * (ks // 2) - ks) // stride + 1
+    Wo = We // 2 if asym else (We + 2 * (ks // 2) - ks) // stride + 1
+    temb = torch.randn((B, Cout), generator=g) * 0.3 if extras else None
+    res = torch.randn((B, Cout, Ho, Wo), generator=g) if extras else None
+    got, ref = run_conv(lib, x, w, bias, x2, stride, (ks // 2, ks // 2), ups, gn, 1 if use_gn else 0, temb, res, out_f32, asym)
+    assert_close(got, ref, name)
+
+
+def test_conv_zero_padding_is_applied_after_groupnorm(lib):
+    """The conv zero-pads the *normalised+activated* tensor: border taps must contribute exactly 0, not silu(shift)."""
+    B, C, H, W = 1, 64, 4, 4
+    x = torch.zeros((B, C, H, W))
+    w = torch.ones((64, C, 3, 3)) / (9 * C)
+    gn = (torch.ones((B, C)), torch.full((B, C), 2.0))  # silu(2.0) != 0 everywhere
+    got, ref = run_conv(lib, x, w, None, None, 1, (1, 1), 0, gn, 1)
+    assert_close(got, ref, "gn-pad")
+    assert got[0, 0, 0, 0] < got[0, 0, 1, 1] * 0.6  # corner sees 4 of 9 taps
+
+
+def test_conv_rejects_bad_arguments(lib):
+    a_ = _lib.ConvArgs()
+    x = torch.zeros(64, dtype=torch.float16, device=DEV)
+    a_.x = a_.w = a_.y = x.data_ptr()
+    a_.C1, a_.B, a_.Hin, a_.Win, a_.Hout, a_.Wout, a_.ks, a_.stride = 12, 1, 1, 1, 1, 1, 1, 1  # channels not % 8
+    a_.N, a_.Nrows, a_.ldy = 16, 16, 16
+    with pytest.raises(ValueError):
+        _lib.check(lib.ldiff_op_conv(C.byref(a_), sp()))
+    a_.C1, a_.ks = 16, 5
+    with pytest.raises(ValueError):
+        _lib.check(lib.ldiff_op_conv(C.byref(a_), sp()))
+
+
+ATTN_CASES = {
+    # name: (B, heads, Lq, Lk, d, kv_broadcast)
+    "self_d40_L256": (2, 8, 256, 256, 40, False),
+    "self_d40_L4096": (1, 8, 4096, 4096, 40, False),
+    "self_d80_L1024": (2, 8, 1024, 1024, 80, False),
+    "self_d160_L256": (2, 8, 256, 256, 160, False),
+    "self_d160_L64": (2, 8, 64, 64, 160, False),
+    "cross_d40_Lk6_bcast": (3, 8, 300, 6, 40, True),
+    "cross_d80_Lk77": (2, 8, 128, 77, 80, False),
+    "cross_d160_Lk1": (2, 8, 64, 1, 160, True),
+    "vae_d512_L1024": (2, 1, 1024, 1024, 512, False),
+    "vae_d128_L256": (1, 1, 256, 256, 128, False),
+    "tiny_d8": (2, 8, 256, 256, 8, False),
+    "tiny_d16_ragged": (2, 8, 100, 37, 16, False),
+    "tiny_d32": (2, 8, 64, 64, 32, False),
+}
+
+
+@pytest.mark.parametrize("name", list(ATTN_CASES))
+def test_attention(lib, name):
+    B, heads, Lq, Lk, d, bcast = ATTN_CASES[name]
+    g = torch.Generator().manual_seed(zlib.crc32(name.encode()) % 1000)
+    Cc = heads * d
+    q = torch.randn((B, Lq, Cc), generator=g)
+    Bk = 1 if bcast else B
+    k = torch.randn((Bk, Lk, Cc), generator=g)
+    v = torch.randn((Bk, Lk, Cc), generator=g)
+    qd, kd, vd = (t.to(torch.float16).to(DEV) for t in (q, k, v))
+    o = torch.full((B, Lq, Cc), float("nan"), dtype=torch.float16, device=DEV)
+    scale = 1.0 / math.sqrt(d)
+    _lib.check(lib.ldiff_op_attention(qd.data_ptr(), Cc, kd.data_ptr(), Cc, vd.data_ptr(), Cc, o.data_ptr(), Cc, B, heads, Lq, Lk, d,
+                                      Lq * Cc, 0 if bcast else Lk * Cc, Lq * Cc, scale, sp()))
+    torch.cuda.synchronize()
+    qh = r16(q).view(B, Lq, heads, d).transpose(1, 2)
+    kh = r16(k).expand(B, -1, -1).reshape(B, Lk, heads, d).transpose(1, 2)
+    vh = r16(v).expand(B, -1, -1).reshape(B, Lk, heads, d).transpose(1, 2)
+    ref = F.scaled_dot_product_attention(qh, kh, vh).transpose(1, 2).reshape(B, Lq, Cc)
+    # probabilities are rounded to fp16 before P.V: allow 3e-3 of the value range
+    assert_close(o, ref, name, rtol=3e-3, atol_rel=3e-3)
+
+
+def test_attention_fused_qkv_layout_and_online_softmax_spike(lib):
+    """q/k/v interleaved in one [B, L, 3C] buffer (the self-attention call) + a key that forces a large running-max jump
+    in a late tile (exercises the rescale branch of the online softmax)."""
+    B, heads, L, d = 1, 8, 320, 40
+    Cc = heads * d
+    g = torch.Generator().manual_seed(5)
+    qkv = torch.randn((B, L, 3 * Cc), generator=g)
+    qkv[0, 300, Cc:2 * Cc] *= 12.0  # spiky key in the last tile
+    dqkv = qkv.to(torch.float16).to(DEV)
+    o = torch.empty((B, L, Cc), dtype=torch.float16, device=DEV)
+    base = dqkv.data_ptr()
+    _lib.check(lib.ldiff_op_attention(base, 3 * Cc, base + 2 * Cc, 3 * Cc, base + 4 * Cc, 3 * Cc, o.data_ptr(), Cc, B, heads, L, L, d,
+                                      L * 3 * Cc, L * 3 * Cc, L * Cc, 1.0 / math.sqrt(d), sp()))
+    torch.cuda.synchronize()
+    x = r16(qkv)
+    sh = lambda t: t.view(B, L, heads, d).transpose(1, 2)
+    ref = F.scaled_dot_product_attention(sh(x[..., :Cc]), sh(x[..., Cc:2 * Cc]), sh(x[..., 2 * Cc:])).transpose(1, 2).reshape(B, L, Cc)
+    assert_close(o, ref, "fused-qkv-spike", rtol=3e-3, atol_rel=3e-3)
+
+
+GN_CASES = {
+    # name: (B, C1, C2, HW, groups, eps)
+    "c320_hw4096": (2, 320, 0, 4096, 32, 1e-5),
+    "c128_hw16384_eps6": (2, 128, 0, 16384, 32, 1e-6),
+    "concat_1280_640_straddle": (2, 1280, 640, 64, 32, 1e-5),
+    "concat_128_64": (3, 128, 64, 256, 32, 1e-5),
+    "c64_cg2": (2, 64, 0, 300, 32, 1e-5),
+    "c32_cg1": (2, 32, 0, 1024, 32, 1e-6),
+    "hw1": (2, 64, 0, 1, 32, 1e-5),
+    "large_mean": (2, 64, 0, 4096, 32, 1e-5),
+}
+
+
+@pytest.mark.parametrize("name", list(GN_CASES))
+def test_group_norm_stats(lib, name):
+    B, C1, C2, HW, groups, eps = GN_CASES[name]
+    g = torch.Generator().manual_seed(zlib.crc32(name.encode()) % 1000)
+    Cc = C1 + C2
+    x = torch.randn((B, HW, Cc), generator=g) * 1.7 + 0.3
+    if name == "large_mean":
+        x = x * 0.1 + 30.0  # |mean|/std = 300: the E[x^2]-mean^2 cancellation case
+    gamma, beta = 1 + 0.1 * torch.randn(Cc, generator=g), 0.1 * torch.randn(Cc, generator=g)
+    x16 = x.to(torch.float16)
+    x1 = x16[..., :C1].contiguous().to(DEV)
+    x2 = x16[..., C1:].contiguous().to(DEV) if C2 else None
+    scale = torch.empty((B, Cc), device=DEV)
+    shift = torch.empty((B, Cc), device=DEV)
+    gd, bd = gamma.to(DEV), beta.to(DEV)
+    _lib.check(lib.ldiff_op_gn_stats(x1.data_ptr(), C1, x2.data_ptr() if C2 else None, C2, B, HW, groups, eps, gd.data_ptr(), bd.data_ptr(),
+                                     scale.data_ptr(), shift.data_ptr(), sp()))
+    torch.cuda.synchronize()
+    xr = x16.float()
+    got = xr * scale.cpu()[:, None, :] + shift.cpu()[:, None, :]
+    ref = F.group_norm(xr.permute(0, 2, 1), groups, gamma, beta, eps).permute(0, 2, 1)
+    tol = 2e-2 if name == "large_mean" else 2e-4
+    assert (got - ref).abs().max() <= tol * max(1.0, ref.abs().max()), f"{name}: max err {(got - ref).abs().max():.3e}"
+
+
+@pytest.mark.parametrize("rows,C", [(4096, 320), (1024, 640), (513, 1280), (7, 64), (1, 2560)])
+def test_layernorm(lib, rows, C):
+    g = torch.Generator().manual_seed(rows + C)
+    x = torch.randn((rows, C), generator=g) * 2 + 0.5
+    gamma, beta = 1 + 0.1 * torch.randn(C, generator=g), 0.1 * torch.randn(C, generator=g)
+    xd, gd, bd = x.to(torch.float16).to(DEV), gamma.to(DEV), beta.to(DEV)
+    y = torch.empty_like(xd)
+    _lib.check(lib.ldiff_op_layernorm(xd.data_ptr(), y.data_ptr(), rows, C, gd.data_ptr(), bd.data_ptr(), 1e-5, sp()))
+    torch.cuda.synchronize()
+    ref = F.layer_norm(r16(x), (C,), gamma, beta, 1e-5)
+    assert_close(y, ref, f"layernorm {rows}x{C}", rtol=1e-3, atol_rel=1e-3)
+
+
+@pytest.mark.parametrize("M,C4", [(4096, 1280), (300, 2560), (1, 256)])
+def test_geglu(lib, M, C4):
+    g = torch.Generator().manual_seed(M)
+    x = torch.randn((M, 2 * C4), generator=g) * 1.5
+    xd = x.to(torch.float16).to(DEV)
+    y = torch.empty((M, C4), dtype=torch.float16, device=DEV)
+    _lib.check(lib.ldiff_op_geglu(xd.data_ptr(), y.data_ptr(), M, C4, sp()))
+    torch.cuda.synchronize()
+    xr = r16(x)
+    ref = xr[:, :C4] * F.gelu(xr[:, C4:])
+    assert_close(y, ref, "geglu", rtol=1e-3, atol_rel=1e-3)
+
+
+def test_layout_nchw_to_nhwc_pads_channels(lib):
+    x = torch.randn((2, 3, 5, 7))
+    xd = x.to(DEV)
+    y = torch.full((2, 5, 7, 8), float("nan"), dtype=torch.float16, device=DEV)
+    _lib.check(lib.ldiff_op_nchw_to_nhwc(xd.data_ptr(), y.data_ptr(), 2, 3, 5, 7, 8, sp()))
+    torch.cuda.synchronize()
+    assert torch.equal(y[..., :3].cpu(), x.permute(0, 2, 3, 1).to(torch.float16))
+    assert (y[..., 3:] == 0).all()

@@ -1,0 +1,216 @@
+"""bench.py -- headline benchmark of the Laplace-diffusion sampling path on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+A "step" is one pass of the hot path over one batch of synthetic input: BASELINE.json configs[1] -- 8 patches of
+512x512 per GPU through the 5-pass sampler (VAE encode -> 5 x [UNet -> PLMS step -> VAE decode -> uint8 -> luma])
+with the SD-v1.5-sized UNet/VAE (seeded synthetic weights in the diffusers key layout: no checkpoint or network
+here), followed by the mask tail (stand-in linear probe over the per-pixel latent vectors -> argmax -> uint8) and,
+for N > 1, the RCCL all-gather that reassembles the masks.  Patches shard across ranks with no data-path collective
+(weak scaling: 8 patches per GPU).  Inputs are resident in HBM when the timed region starts.
+
+Prints ONE JSON line on rank 0 (contract in the task description), including
+  roofline     -- live HIP-event measurement of the dominant kernel over the timed region
+  cpu_baseline -- the CPU oracle (plain-torch fp32 restatement, oracle/) timed on the host cores (rank 0, N=1 only)
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+PATCHES_PER_GPU = 8
+IMG = 512
+N_PASSES = 5
+N_CLASSES = 6
+MFMA_PEAK_TFLOPS = 2500.0   # dense fp16/bf16 MFMA, /opt/skills/guides/MI355X_MICROARCH.md
+HBM_PEAK_GBPS = 8000.0      # HBM3E spec, same guide
+# Algorithmic work of one UNet pass at 512x512 (SURVEY.md 8d / BASELINE.md section 2)
+UNET_WEIGHT_BYTES = 1.719e9
+UNET_ACT_BYTES_PER_SAMPLE = 1.014e9
+UNET_FLOP_PER_SAMPLE = 797.3e9
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU oracle timing (rank 0, N=1)")
+    ap.add_argument("--no-prof", action="store_true", help="skip the per-launch HIP-event profile")
+    ap.add_argument("--tiny", action="store_true", help="reduced-width graph + 64x64 patches (plumbing check only; not a valid bench line)")
+    return ap.parse_args()
+
+
+def usable_cpus() -> int:
+    """Host cores this process may actually use: the affinity mask capped by the cgroup CPU quota (the GPU box shows
+    256 logical CPUs but grants 16 -- 256 torch threads on a 16-CPU quota run 10x slower than 16 threads)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
+def cpu_baseline(ucfg, vcfg, usd, vsd, img, n_passes):
+    """Oracle timed on the host: one VAE encode, one UNet pass and one VAE decode of ONE patch, once each after an
+    untimed tiny warm-up; composed as enc + n_passes*(unet+dec) per patch."""
+    from oracle import pipeline as op
+    threads = usable_cpus()
+    torch.set_num_threads(threads)
+    pipe = op.OraclePipeline(op.OracleUNet(usd, ucfg), op.OracleVAE(vsd, vcfg))
+    g = torch.Generator().manual_seed(1234)
+    x = torch.rand((1, 3, img, img), generator=g)
+    ctx = torch.randn((1, 6, ucfg["cross_attention_dim"]), generator=g) * 0.5
+    pipe.vae.encode(torch.rand((1, 3, 64, 64)))  # thread-pool / allocator warm-up
+    t0 = time.perf_counter()
+    z = pipe.vae.encode(x).latent_dist.mean
+    t1 = time.perf_counter()
+    eps = pipe.unet(z, 501, ctx).sample
+    t2 = time.perf_counter()
+    pipe.decode_latents(eps)
+    t3 = time.perf_counter()
+    per_patch = (t1 - t0) + n_passes * ((t2 - t1) + (t3 - t2))
+    return {"value": 1.0 / per_patch, "unit": "patches/sec", "cores": threads, "kind": "port",
+            "sample": f"1 patch {img}x{img}: 1 VAE encode ({t1 - t0:.2f}s) + 1 UNet pass ({t2 - t1:.2f}s) + 1 VAE decode ({t3 - t2:.2f}s) "
+                      f"timed once each, composed as enc + {n_passes}*(unet+dec); plain-torch fp32 restatement (oracle/), "
+                      f"torch {torch.__version__}, {threads} threads -- not diffusers"}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a ROCm GPU: there is no CPU fallback for the product path")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device(f"cuda:{local_rank}")
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    from ldiffusion_amd import _lib, configs, weights
+    from ldiffusion_amd.models import AutoencoderKL, UNet2DConditionModel
+    from ldiffusion_amd.parallel import gather_masks, shard_range
+    from ldiffusion_amd.pipeline import LaplaceSampler, StableDiffusionImg2ImgPipeline, argmax_mask
+
+    ucfg, vcfg = (configs.TINY_UNET, configs.TINY_VAE) if args.tiny else (configs.SD15_UNET, configs.SD15_VAE)
+    img = 64 if args.tiny else IMG
+    usd = weights.synthetic_state_dict(weights.unet_param_shapes(ucfg), 42)
+    vsd = weights.synthetic_state_dict(weights.vae_param_shapes(vcfg), 43)
+    pipe = StableDiffusionImg2ImgPipeline(AutoencoderKL(vcfg, vsd, dev), UNet2DConditionModel(ucfg, usd, dev))
+    sampler = LaplaceSampler(pipe)
+
+    total = PATCHES_PER_GPU * world
+    lo, hi = shard_range(total, rank, world)
+    g = torch.Generator().manual_seed(1234)
+    images_all = torch.rand((total, 3, img, img), generator=g)              # ToTensor range, pixel_latent_vector.py:29-32
+    ctx = (torch.randn((1, 6, ucfg["cross_attention_dim"]), generator=torch.Generator().manual_seed(1235)) * 0.5).to(dev)
+    images = images_all[lo:hi].to(dev)
+    hg = torch.Generator().manual_seed(1236)
+    head_w = (torch.randn((N_CLASSES, N_PASSES), generator=hg) / N_PASSES ** 0.5).to(dev)  # stand-in for the out-of-scope segmentor head
+    head_b = (0.1 * torch.randn(N_CLASSES, generator=hg)).to(dev)
+
+    def step():
+        out = sampler.sample(images, ctx, N_PASSES, want_features=True, want_rgb=True)
+        logits = torch.einsum("cn,bnhw->bchw", head_w, out["features"].float() * (1.0 / 255.0)) + head_b[None, :, None, None]
+        mask = argmax_mask(logits)
+        return gather_masks(mask, total) if world > 1 else mask
+
+    def sync():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    prof = not args.no_prof
+    lib = _lib.load()
+    sync()
+    if prof:
+        lib.ldiff_prof_enable(1)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        masks = step()
+    sync()
+    elapsed = time.perf_counter() - t0
+    lib.ldiff_prof_enable(0)
+    rows = _lib.prof_collect() if prof else []
+    if dist is not None:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+    assert masks.shape[0] == total and masks.dtype == torch.uint8
+
+    # ---- UNet step alone (the metric's second half: UNet-step HBM GB/s vs peak), HIP events on the launch stream ----
+    lat = torch.randn((PATCHES_PER_GPU, 4, img // 8, img // 8), device=dev)
+    pipe.unet(lat, 501, ctx)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    reps = 5
+    e0.record()
+    for _ in range(reps):
+        pipe.unet(lat, 501, ctx)   # launched on torch's current stream, the same one the events are recorded on
+    e1.record()
+    torch.cuda.synchronize()
+    unet_ms = e0.elapsed_time(e1) / reps
+
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+    result = {
+        "metric": "patches/sec (512x512, 5 denoise steps)",
+        "value": total * args.steps / elapsed,
+        "unit": "patches/sec",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f16 (fp32 accumulate)", "data": "synthetic",
+        "config": {"workload": f"BASELINE.json configs[1]: {PATCHES_PER_GPU} patches/GPU of {img}x{img}, {N_PASSES}-pass Laplace/PLMS sampler, "
+                               f"SD-v1.5-size UNet (859.5M) + VAE, seeded synthetic weights, ctx L=6; +linear-probe argmax mask"
+                               + (", RCCL all-gather of masks" if world > 1 else ""),
+                   "patches_per_gpu": PATCHES_PER_GPU, "image": img, "n_passes": N_PASSES, "parallelism": f"dp{world} (patch sharding)"},
+    }
+    if rows:
+        dom = max(rows, key=lambda r: r["ms"])
+        tot_ms = sum(r["ms"] for r in rows)
+        ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
+        result["roofline"] = {"bound": "mfma", "kernel": dom["name"], "achieved": ach, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                              "frac": ach / MFMA_PEAK_TFLOPS, "traffic": None,
+                              "launches": dom["launches"], "avg_launch_us": 1e3 * dom["ms"] / dom["launches"],
+                              "algorithmic_GBps": dom["bytes"] / (dom["ms"] * 1e-3) / 1e9,
+                              "share_of_profiled_time": dom["ms"] / tot_ms}
+        result["kernels"] = [{"name": r["name"], "launches": r["launches"], "ms": round(r["ms"], 3),
+                              "tflops": round(r["flops"] / (r["ms"] * 1e-3) / 1e12, 1), "GBps": round(r["bytes"] / (r["ms"] * 1e-3) / 1e9, 1)}
+                             for r in sorted(rows, key=lambda r: -r["ms"])]
+    if not args.tiny:
+        ub = UNET_WEIGHT_BYTES + PATCHES_PER_GPU * UNET_ACT_BYTES_PER_SAMPLE
+        uf = PATCHES_PER_GPU * UNET_FLOP_PER_SAMPLE
+        result["unet_step"] = {"ms": unet_ms, "batch": PATCHES_PER_GPU,
+                               "hbm_GBps": ub / (unet_ms * 1e-3) / 1e9, "hbm_frac": ub / (unet_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                               "tflops": uf / (unet_ms * 1e-3) / 1e12, "mfma_frac": uf / (unet_ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS}
+    if world == 1 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(ucfg, vcfg, usd, vsd, img, N_PASSES)
+    print(json.dumps(result), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -106,6 +106,10 @@ void ldiff_vae_destroy(ldiff_vae*);
  * (scheduler.step(...).prev_sample: segmentor.py:104,445,527  pixel_latent_vector.py:79); coefficients
  * are computed on the host from alphas_cumprod exactly as PNDMScheduler._get_prev_sample does. */
 int ldiff_pndm_step(const float* coef, const void* const* ops, int nops, void* out, int64_t n, void* stream);
+/* (host) the two float32 coefficients of _get_prev_sample for alphas_cumprod values a_t, a_prev:
+ * prev_sample = sample_coeff * sample + eps_coeff * model_output.  Both the python scheduler shim and
+ * ldiff_sample use this one routine, so the two drivers agree bit for bit on every machine. */
+int ldiff_pndm_coeffs(float a_t, float a_prev, float* sample_coeff, float* eps_coeff);
 /* alphas_cumprod table of the SD-v1.5 scheduler config (1000 float32) */
 int ldiff_pndm_alphas_cumprod(float* out_host, int n);
 /* out = z0 + Laplace(0, scale) given the uniform draw u (or u = NULL: counter-based Philox stream seed/offset)
@@ -159,6 +163,15 @@ int ldiff_op_gn_stats(const void* x, int C1, const void* x2, int C2, int B, int 
 int ldiff_op_layernorm(const void* x, void* y, int rows, int C, const void* gamma, const void* beta, float eps, void* stream);
 int ldiff_op_geglu(const void* x, void* y, int64_t M, int C4, void* stream);
 int ldiff_op_nchw_to_nhwc(const void* x_f32, void* y_f16, int B, int C, int H, int W, int Cpad, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Live measurement for bench.py's roofline line: when enabled, every conv/linear, attention and
+ * GroupNorm-statistics launch is bracketed by two HIP events recorded on the launch stream.
+ * ldiff_prof_collect waits for them and returns one row per kernel (time, launches, algorithmic flops/bytes).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct { char name[64]; int64_t launches; double ms, flops, bytes; } ldiff_prof_row;
+int ldiff_prof_enable(int on);
+int ldiff_prof_collect(ldiff_prof_row* rows, int cap); /* returns the number of rows (may exceed cap) or <0 */
 
 #ifdef __cplusplus
 }

@@ -58,6 +58,7 @@ SIGNATURES = {
     "ldiff_vae_destroy": (None, [P]),
     "ldiff_pndm_step": (I, [C.POINTER(F), C.POINTER(P), I, P, I64, P]),
     "ldiff_pndm_alphas_cumprod": (I, [C.POINTER(F), I]),
+    "ldiff_pndm_coeffs": (I, [F, F, C.POINTER(F), C.POINTER(F)]),
     "ldiff_laplace_add": (I, [P, F, P, U64, U64, P, I64, P]),
     "ldiff_argmax_u8": (I, [P, I, I, I, I, P, P]),
     "ldiff_luma_float": (I, [P, P, I, I, I, P]),
@@ -72,7 +73,22 @@ SIGNATURES = {
     "ldiff_op_layernorm": (I, [P, P, I, I, P, P, F, P]),
     "ldiff_op_geglu": (I, [P, P, I64, I, P]),
     "ldiff_op_nchw_to_nhwc": (I, [P, P, I, I, I, I, I, P]),
+    "ldiff_prof_enable": (I, [I]),
+    "ldiff_prof_collect": (I, [P, I]),
 }
+
+
+class ProfRow(C.Structure):
+    _fields_ = [("name", C.c_char * 64), ("launches", C.c_int64), ("ms", C.c_double), ("flops", C.c_double), ("bytes", C.c_double)]
+
+
+def prof_collect():
+    """Rows of the live HIP-event profile: list of dict(name, launches, ms, flops, bytes)."""
+    lib = load()
+    rows = (ProfRow * 128)()
+    n = lib.ldiff_prof_collect(C.cast(rows, C.c_void_p), 128)
+    check(n if n < 0 else 0)
+    return [dict(name=r.name.decode(), launches=r.launches, ms=r.ms, flops=r.flops, bytes=r.bytes) for r in rows[:min(n, 128)]]
 
 _lib = None
 

@@ -122,6 +122,19 @@ int ldiff_pndm_step(const float* coef, const void* const* ops, int nops, void* o
   launch_lincomb(coef, ops, nops, (float*)out, n, (hipStream_t)stream);
   API_END
 }
+int ldiff_pndm_coeffs(float a_t, float a_prev, float* sample_coeff, float* eps_coeff) {
+  // PNDMScheduler._get_prev_sample in float32, one IEEE operation per python operator:
+  //   prev = sqrt(a_prev/a_t)*sample - (a_prev-a_t)*eps / (a_t*sqrt(1-a_prev) + sqrt(a_t*(1-a_t)*a_prev))
+  if (!sample_coeff || !eps_coeff || !(a_t > 0.f) || !(a_prev > 0.f)) { ldiff_set_error("pndm_coeffs: bad arguments"); return LDIFF_ERR_INVALID; }
+  const volatile float b_t = 1.f - a_t, b_prev = 1.f - a_prev;
+  const volatile float sc = sqrtf(a_prev / a_t);
+  const volatile float d1 = a_t * sqrtf(b_prev);
+  const volatile float d2 = sqrtf((a_t * b_t) * a_prev);
+  const volatile float denom = d1 + d2;
+  *sample_coeff = sc;
+  *eps_coeff = -(a_prev - a_t) / denom;
+  return LDIFF_OK;
+}
 int ldiff_pndm_alphas_cumprod(float* out_host, int n) {
   API_BEGIN
   LDIFF_CHECK(out_host && n == 1000, LDIFF_ERR_INVALID, "alphas_cumprod: n must be 1000");
@@ -137,7 +150,9 @@ int ldiff_laplace_add(const void* z0, float scale, const void* u, uint64_t seed,
 }
 int ldiff_argmax_u8(const void* logits, int B, int C, int H, int W, void* mask_u8, void* stream) {
   API_BEGIN
-  LDIFF_CHECK(logits && mask_u8 && B >= 0 && H >= 0 && W >= 0, LDIFF_ERR_INVALID, "argmax: bad arguments");
+  LDIFF_CHECK(B >= 0 && H >= 0 && W >= 0, LDIFF_ERR_INVALID, "argmax: negative extent");
+  if ((long long)B * H * W == 0) return LDIFF_OK;   // empty batch: nothing to do (pointers may be null)
+  LDIFF_CHECK(logits && mask_u8, LDIFF_ERR_INVALID, "argmax: null pointer");
   launch_argmax_u8((const float*)logits, B, C, H, W, (uint8_t*)mask_u8, (hipStream_t)stream);
   API_END
 }
@@ -213,7 +228,10 @@ int ldiff_sample(ldiff_pipeline* p, const void* images, int B, int H, int W, int
     // ---- PNDMScheduler.step_plms ----
     int prev_t = t - ratio;
     const float* sample = z;
-    float wts[5] = {0, 0, 0, 0, 0};      // weights on {eps_new (when not stored), ets[-1], ets[-2], ets[-3], ets[-4]}
+    // weights on {eps_new (when not stored), ets[-1], ets[-2], ets[-3], ets[-4]}; kept in double and folded into the
+    // float32 eps coefficient with ONE rounding, exactly like the python scheduler shim (fp16 activations amplify a
+    // 1-ulp coefficient difference into ~1e-4 latent differences, so the two drivers must agree bit for bit)
+    double wts[5] = {0, 0, 0, 0, 0};
     const float* opsrc[5] = {eps_new, nullptr, nullptr, nullptr, nullptr};
     if (counter != 1) {
       // ets = ets[-3:] + [eps_new]: rotate the ring so that ets[n_ets-1] is the newest
@@ -228,24 +246,27 @@ int ldiff_sample(ldiff_pipeline* p, const void* images, int B, int H, int W, int
     float coef[6];
     const void* ops[6];
     if (n_ets == 1 && counter == 0) {
-      wts[1] = 1.f;
+      wts[1] = 1.0;
       HIP_CHECK(hipMemcpyAsync(cur_sample, z, nlat * sizeof(float), hipMemcpyDeviceToDevice, s));
     } else if (n_ets == 1 && counter == 1) {
-      wts[0] = 0.5f; wts[1] = 0.5f;       // (model_output + ets[-1]) / 2
+      wts[0] = 0.5; wts[1] = 0.5;       // (model_output + ets[-1]) / 2
       sample = cur_sample;
-    } else if (n_ets == 2) { wts[1] = 3.f / 2.f; wts[2] = -1.f / 2.f; }
-    else if (n_ets == 3) { wts[1] = 23.f / 12.f; wts[2] = -16.f / 12.f; wts[3] = 5.f / 12.f; }
-    else { wts[1] = 55.f / 24.f; wts[2] = -59.f / 24.f; wts[3] = 37.f / 24.f; wts[4] = -9.f / 24.f; }
+    } else if (n_ets == 2) { wts[1] = 3.0 / 2; wts[2] = -1.0 / 2; }
+    else if (n_ets == 3) { wts[1] = 23.0 / 12; wts[2] = -16.0 / 12; wts[3] = 5.0 / 12; }
+    else { wts[1] = 55.0 / 24; wts[2] = -59.0 / 24; wts[3] = 37.0 / 24; wts[4] = -9.0 / 24; }
     for (int k = 1; k <= 4; ++k) opsrc[k] = (n_ets - k >= 0) ? ets[n_ets - k] : nullptr;
     // ---- _get_prev_sample: prev = sqrt(a_prev/a_t)*sample - (a_prev-a_t)*eps/(a_t*sqrt(1-a_prev)+sqrt(a_t*(1-a_t)*a_prev)) ----
     const float a_t = p->abar[t], a_prev = prev_t >= 0 ? p->abar[prev_t] : p->abar[0];
-    const float b_t = 1.f - a_t, b_prev = 1.f - a_prev;
-    const float sample_coeff = sqrtf(a_prev / a_t);
-    const float denom = a_t * sqrtf(b_prev) + sqrtf(a_t * b_t * a_prev);
-    const float ce = -(a_prev - a_t) / denom;
+    float sample_coeff, ce;
+    ldiff_pndm_coeffs(a_t, a_prev, &sample_coeff, &ce);
     coef[nops] = sample_coeff; ops[nops++] = sample;
     for (int k = 0; k < 5; ++k)
-      if (wts[k] != 0.f) { coef[nops] = ce * wts[k]; ops[nops++] = opsrc[k]; }
+      if (wts[k] != 0.0) { coef[nops] = (float)((double)ce * wts[k]); ops[nops++] = opsrc[k]; }
+    if (getenv("LDIFF_DEBUG")) {
+      fprintf(stderr, "[ldiff_sample] pass %d t=%d prev_t=%d n_ets=%d nops=%d coef:", i, t, prev_t, n_ets, nops);
+      for (int k = 0; k < nops; ++k) fprintf(stderr, " %.9g", (double)coef[k]);
+      fprintf(stderr, "\n");
+    }
     launch_lincomb(coef, ops, nops, znext, (long long)nlat, s);
     std::swap(z, znext);
     ++counter;

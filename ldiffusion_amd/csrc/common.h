@@ -63,7 +63,9 @@ struct ConvParams {
   int out_f32;
   int M;                  // B*Hout*Wout
 };
-void launch_igemm(const ConvParams& p, hipStream_t s);
+void launch_igemm(const ConvParams& p, hipStream_t s);   // dispatches to the halo-tile 3x3 kernel when eligible
+bool conv3x3_eligible(const ConvParams& p);
+void launch_conv3x3(const ConvParams& p, hipStream_t s);       // kernels_conv3x3.hip
 
 // ---- attention (kernels_attn.hip) ------------------------------------------------------------
 // O[b, q, h*d + :] = softmax(Q K^T / sqrt(d)) V   per (b, head).   All fp16, row strides in elements.
@@ -121,4 +123,16 @@ class Arena {
   char* base_ = nullptr;
   size_t cap_ = 0, high_ = 0;
   std::vector<Block> blocks_;
+};
+
+// ---- optional per-launch profiling with HIP events (prof.hip) ---------------------------------
+// When enabled (ldiff_prof_enable), every wrapped launch is bracketed by two events recorded on the
+// launch stream; ldiff_prof_collect sums elapsed time / algorithmic flops / algorithmic bytes per kernel name.
+bool prof_on();
+void prof_begin(const char* name, double flops, double bytes, hipStream_t s);
+void prof_end(hipStream_t s);
+struct ProfScope {
+  hipStream_t s; bool on;
+  ProfScope(const char* name, double flops, double bytes, hipStream_t st) : s(st), on(prof_on()) { if (on) prof_begin(name, flops, bytes, s); }
+  ~ProfScope() { if (on) prof_end(s); }
 };

@@ -191,6 +191,10 @@ static void launch_attn_cfg(const AttnParams& p, hipStream_t s) {
     attr_set = true;
   }
   dim3 grid((p.Lq + 64 * QT - 1) / (64 * QT), p.heads, p.B);
+  static const std::string pname = std::string("attn<") + std::to_string(DQK) + "," + std::to_string(DV) + ">";
+  const double bh = (double)p.B * p.heads;
+  ProfScope prof(pname.c_str(), 4.0 * bh * p.Lq * p.Lk * p.d,
+                 2.0 * bh * p.d * (2.0 * p.Lq + 2.0 * p.Lk * (p.kv_bstride ? 1.0 : 1.0 / p.B)), s);
   hipLaunchKernelGGL(kern, grid, dim3(256), smem, s, p);
   HIP_CHECK(hipGetLastError());
 }

@@ -1,0 +1,258 @@
+// 3x3 stride-1 convolution for gfx950 (MI355X): halo-tile implicit GEMM, fp16 operands, fp32 MFMA accumulate.
+//
+// This is the dominant kernel of the sampling path (97 % of the VAE MACs, 50 % of the UNet MACs).
+// It replaces the conv2d inside diffusers' ResnetBlock2D / Upsample2D / conv_in / conv_out
+// (reached from /root/reference/segmentor.py:103,106,519 and pixel_latent_vector.py:73,78,81).
+//
+// Per workgroup (256 threads = 4 waves as 2x2): an output tile of TH x TW pixels of ONE image and BN output channels.
+// For every 64-channel slab of the input:
+//   * the (TH+2) x (TW+2) halo tile of that slab is loaded ONCE global -> registers -> LDS, with GroupNorm-apply
+//     (+SiLU), the nearest-2x upsample gather and the skip-concat source select applied on the way (so the
+//     normalisation runs once per element per workgroup instead of once per tap), double-buffered across slabs;
+//   * the 9 taps are 9 MFMA steps that read the SAME halo image at a shifted pixel offset, while the [BN][64]
+//     weight slice of each tap streams global -> LDS by LDS-DMA (global_load_lds_dwordx4, no VGPR/ds_write
+//     traffic), double-buffered one tap ahead.
+// LDS rows are 128 B; 16-byte chunk c of row r lives at position c ^ ((r>>1)&7) (conflict-free ds_read_b128 for
+// the 16x16x32 operand fetch).  The DMA writes LDS linearly, so the swizzle is applied on the weight SOURCE address.
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ int swz8(int row, int chunk) { return chunk ^ ((row >> 1) & 7); }
+__device__ __forceinline__ float silu_f(float v) { return v * __frcp_rn(1.0f + __expf(-v)); }
+
+typedef __attribute__((address_space(1))) const void gptr_t;
+typedef __attribute__((address_space(3))) void lptr_t;
+
+template <int TH, int TW, int BN, bool GN>
+__global__ __launch_bounds__(256, 2) void conv3x3_kernel(const ConvParams p) {   // 2 waves/SIMD = 2 workgroups per CU
+  constexpr int BM = TH * TW, HWD = TW + 2, HP = (TH + 2) * (TW + 2);
+  constexpr int MT = BM / 32, NT = BN / 32;
+  constexpr int A_IT = (HP * 8 + 255) / 256, W_IT = BN * 8 / 256;
+  static_assert(BN % 32 == 0 && (BN * 8) % 256 == 0, "BN must be a multiple of 32");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  uint4* sA = reinterpret_cast<uint4*>(smem_raw);   // [2][HP*8]
+  uint4* sW = sA + 2 * HP * 8;                      // [2][BN*8]
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform (LDS-DMA base, M0)
+  const int wave_m = wave >> 1, wave_n = wave & 1;
+  const int g = lane >> 4, l15 = lane & 15;
+  const int Cin = p.C1 + p.C2;
+  const int tiles_x = (p.Wout + TW - 1) / TW, tiles_y = (p.Hout + TH - 1) / TH;
+  const int ntn = (p.N + BN - 1) / BN;
+
+  // XCD-aware order: blocks sharing an XCD (blockIdx % 8) walk consecutive tiles -> the n-tiles of one pixel tile
+  // (same halo) and neighbouring pixel tiles (overlapping halos) share a 4 MiB L2.
+  int nwg = gridDim.x, id = blockIdx.x;
+  int q8 = nwg >> 3, r8 = nwg & 7, xcd = id & 7, idx = id >> 3;
+  int sw = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
+  const int tile_n = sw % ntn;
+  int tm = sw / ntn;
+  const int tx = tm % tiles_x; tm /= tiles_x;
+  const int ty = tm % tiles_y;
+  const int b = tm / tiles_y;
+  const int n0 = tile_n * BN, oy0 = ty * TH, ox0 = tx * TW;
+  const int He = p.Hin << p.ups, We = p.Win << p.ups;
+
+  // ---- halo staging: thread owns chunk column kc of halo pixels hp = tid/8 + 32*i ----
+  const int kc = tid & 7;
+  long long a_off[A_IT];   // source pixel offset (in pixels) or -1 when the halo pixel is padding / outside
+#pragma unroll
+  for (int i = 0; i < A_IT; ++i) {
+    const int hp = (tid >> 3) + i * 32;
+    a_off[i] = -1;
+    if (hp < HP) {
+      const int hy = hp / HWD, hx = hp - hy * HWD;
+      const int iy = oy0 + hy - 1, ix = ox0 + hx - 1;
+      if (iy >= 0 && iy < He && ix >= 0 && ix < We) a_off[i] = ((long long)b * p.Hin + (iy >> p.ups)) * p.Win + (ix >> p.ups);
+    }
+  }
+  uint4 ra[A_IT];
+  float4 gs0, gs1, gt0, gt1;
+  auto load_halo = [&](int c) {
+    const int cb = c * 64;
+    const f16* src; int cs, Cs;
+    if (cb < p.C1) { src = p.x; cs = cb; Cs = p.C1; } else { src = p.x2; cs = cb - p.C1; Cs = p.C2; }
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (a_off[i] >= 0) v = *reinterpret_cast<const uint4*>(src + a_off[i] * Cs + cs + kc * 8);
+      ra[i] = v;
+    }
+    if (GN) {
+      const float* sc = p.gn_scale + (long long)b * Cin + cb + kc * 8;
+      const float* sh = p.gn_shift + (long long)b * Cin + cb + kc * 8;
+      gs0 = *reinterpret_cast<const float4*>(sc); gs1 = *reinterpret_cast<const float4*>(sc + 4);
+      gt0 = *reinterpret_cast<const float4*>(sh); gt1 = *reinterpret_cast<const float4*>(sh + 4);
+    }
+  };
+  auto store_halo = [&](int buf) {
+    float sv[8] = {gs0.x, gs0.y, gs0.z, gs0.w, gs1.x, gs1.y, gs1.z, gs1.w};
+    float tv[8] = {gt0.x, gt0.y, gt0.z, gt0.w, gt1.x, gt1.y, gt1.z, gt1.w};
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+      const int hp = (tid >> 3) + i * 32;
+      if (hp >= HP) continue;
+      uint4 v = ra[i];
+      if (GN && a_off[i] >= 0) {   // zero padding applies to the normalised tensor: padding chunks stay exactly 0
+        f16x8 h = __builtin_bit_cast(f16x8, v), o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          float f = (float)h[j] * sv[j] + tv[j];
+          if (p.silu_in) f = silu_f(f);
+          o[j] = (f16)f;
+        }
+        v = __builtin_bit_cast(uint4, o);
+      }
+      sA[buf * HP * 8 + hp * 8 + swz8(hp, kc)] = v;
+    }
+  };
+  // ---- weight slice of step s = (slab c, tap) by LDS-DMA: LDS position q (linear) <- global chunk (row q/8, (q%8)^swz) ----
+  auto issue_w = [&](int c, int tap, int buf) {
+    const long long kbase = (long long)tap * Cin + c * 64;
+#pragma unroll
+    for (int i = 0; i < W_IT; ++i) {
+      const int q = tid + i * 256;
+      const int r = q >> 3, pos = q & 7;
+      int n = n0 + r;
+      n = n < p.Nrows ? n : p.Nrows - 1;   // rows beyond the matrix are never stored; keep the address valid
+      const f16* gsrc = p.w + (long long)n * p.K + kbase + (swz8(r, pos)) * 8;
+      uint4* ldst = sW + buf * BN * 8 + i * 256 + wave * 64;   // wave-uniform base; hardware adds lane*16 B
+      __builtin_amdgcn_global_load_lds((gptr_t*)gsrc, (lptr_t*)ldst, 16, 0, 0);
+    }
+  };
+
+  f32x4 acc[NT][MT];
+#pragma unroll
+  for (int a = 0; a < NT; ++a)
+#pragma unroll
+    for (int m = 0; m < MT; ++m) acc[a][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // per-lane halo pixel of output row (m-tile, l15) at tap (0,0)
+  int hp0[MT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+    const int ml = wave_m * (BM / 2) + m * 16 + l15;
+    hp0[m] = (ml / TW) * HWD + (ml % TW);
+  }
+
+  const int nslab = Cin / 64;
+  load_halo(0);
+  store_halo(0);
+  issue_w(0, 0, 0);
+  __syncthreads();
+
+  int step = 0;
+  for (int c = 0; c < nslab; ++c) {
+    const uint4* cA = sA + (c & 1) * HP * 8;
+#pragma unroll 1
+    for (int tap = 0; tap < 9; ++tap, ++step) {
+      const bool more = !(c == nslab - 1 && tap == 8);
+      if (more) { if (tap == 8) issue_w(c + 1, 0, (step + 1) & 1); else issue_w(c, tap + 1, (step + 1) & 1); }
+      const bool stage = tap == 0 && c + 1 < nslab;
+      if (stage) load_halo(c + 1);
+      const uint4* cW = sW + (step & 1) * BN * 8;
+      const int ky = tap / 3, kx = tap - ky * 3;
+      const int hoff = ky * HWD + kx;
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        f16x8 wf[NT], xf[MT];
+#pragma unroll
+        for (int a = 0; a < NT; ++a) {
+          const int row = wave_n * (BN / 2) + a * 16 + l15;
+          wf[a] = __builtin_bit_cast(f16x8, cW[row * 8 + swz8(row, kk * 4 + g)]);
+        }
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+          const int hp = hp0[m] + hoff;
+          xf[m] = __builtin_bit_cast(f16x8, cA[hp * 8 + swz8(hp, kk * 4 + g)]);
+        }
+#pragma unroll
+        for (int a = 0; a < NT; ++a)
+#pragma unroll
+          for (int m = 0; m < MT; ++m)
+            acc[a][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[a], xf[m], acc[a][m], 0, 0, 0);
+      }
+      if (stage) store_halo((c + 1) & 1);
+      __syncthreads();   // also drains the weight DMA issued at the top of this step (vmcnt(0) before s_barrier)
+    }
+  }
+
+  // ---- epilogue: lane holds y[pixel = column][n = 4g + r] ----
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+    const int ml = wave_m * (BM / 2) + m * 16 + l15;
+    const int oy = oy0 + ml / TW, ox = ox0 + ml % TW;
+    if (oy >= p.Hout || ox >= p.Wout) continue;
+    const long long mrow = ((long long)b * p.Hout + oy) * p.Wout + ox;
+#pragma unroll
+    for (int a = 0; a < NT; ++a) {
+      const int n = n0 + wave_n * (BN / 2) + a * 16 + g * 4;
+      if (n >= p.N) continue;
+      f32x4 v = acc[a][m];
+      if (p.bias) { float4 bb = *reinterpret_cast<const float4*>(p.bias + n); v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w; }
+      if (p.temb) {
+        float4 tt = *reinterpret_cast<const float4*>(p.temb + (long long)b * p.ld_temb + n);
+        v[0] += tt.x; v[1] += tt.y; v[2] += tt.z; v[3] += tt.w;
+      }
+      if (p.res) {
+        f16x4 rr = *reinterpret_cast<const f16x4*>(p.res + mrow * p.ld_res + n);
+        v[0] += (float)rr[0]; v[1] += (float)rr[1]; v[2] += (float)rr[2]; v[3] += (float)rr[3];
+      }
+      if (p.out_f32) {
+        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.y) + mrow * p.ldy + n) = v;
+      } else {
+        f16x4 o = {(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
+        *reinterpret_cast<f16x4*>(reinterpret_cast<f16*>(p.y) + mrow * p.ldy + n) = o;
+      }
+    }
+  }
+}
+
+template <int TH, int TW, int BN, bool GN>
+void launch_c3(const ConvParams& p, hipStream_t s) {
+  static bool attr_set = false;
+  constexpr int HP = (TH + 2) * (TW + 2);
+  const size_t smem = (size_t)(2 * HP * 8 + 2 * BN * 8) * 16;
+  auto kern = conv3x3_kernel<TH, TW, BN, GN>;
+  if (!attr_set) {
+    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    attr_set = true;
+  }
+  const int tiles = p.B * ((p.Hout + TH - 1) / TH) * ((p.Wout + TW - 1) / TW);
+  const int ntn = (p.N + BN - 1) / BN;
+  static const std::string pname = std::string("conv3x3<") + std::to_string(TH) + "x" + std::to_string(TW) + "," + std::to_string(BN) + (GN ? ",gn>" : ">");
+  const double bytes = (double)p.B * p.Hin * p.Win * (p.C1 + p.C2) * 2.0 + (double)p.N * p.K * 2.0 + (double)p.M * p.N * (p.out_f32 ? 4.0 : 2.0) +
+                       (p.res ? (double)p.M * p.N * 2.0 : 0.0);
+  ProfScope prof(pname.c_str(), 2.0 * p.M * (double)p.N * p.K, bytes, s);
+  hipLaunchKernelGGL(kern, dim3(tiles * ntn), dim3(256), smem, s, p);
+  HIP_CHECK(hipGetLastError());
+}
+
+template <int TH, int TW, int BN>
+void launch_c3_gn(const ConvParams& p, hipStream_t s) {
+  if (p.gn_scale) launch_c3<TH, TW, BN, true>(p, s); else launch_c3<TH, TW, BN, false>(p, s);
+}
+
+}  // namespace
+
+bool conv3x3_eligible(const ConvParams& p) {
+  const int Cin = p.C1 + p.C2;
+  return p.ks == 3 && p.stride == 1 && p.pad_t == 1 && p.pad_l == 1 && Cin % 64 == 0 && p.C1 % 64 == 0 &&
+         p.Hout == (p.Hin << p.ups) && p.Wout == (p.Win << p.ups);
+}
+
+void launch_conv3x3(const ConvParams& p, hipStream_t s) {
+  const bool wide = p.Wout >= 16;
+  const int bn = (p.N % 128 != 0 && p.N % 160 == 0) ? 160 : (p.N <= 64 ? 64 : 128);
+  if (wide) {
+    if (bn == 160) launch_c3_gn<8, 16, 160>(p, s);
+    else if (bn == 64) launch_c3_gn<8, 16, 64>(p, s);
+    else launch_c3_gn<8, 16, 128>(p, s);
+  } else {
+    if (bn == 160) launch_c3_gn<8, 8, 160>(p, s);
+    else if (bn == 64) launch_c3_gn<8, 8, 64>(p, s);
+    else launch_c3_gn<8, 8, 128>(p, s);
+  }
+}

@@ -208,12 +208,14 @@ __global__ void argmax_u8_kernel(const float* __restrict__ logits, int B, int C,
   const float* p = logits + (long long)b * C * HW + pix;
   float best = p[0];
   int bi = 0;
+  bool any_nan = best != best || best == INFINITY;
   for (int c = 1; c < C; ++c) {
     float v = p[(long long)c * HW];
-    // torch.argmax: first maximal element; NaN compares as the maximum
-    if ((v > best) || (v != v && best == best)) { best = v; bi = c; }
+    any_nan |= v != v || v == INFINITY;
+    if (v > best) { best = v; bi = c; }  // first maximal element, like torch.argmax
   }
-  mask[i] = (uint8_t)bi;
+  // softmax turns a pixel with any NaN or +inf logit into all-NaN; torch.argmax of an all-NaN row is index 0
+  mask[i] = any_nan ? (uint8_t)0 : (uint8_t)bi;
 }
 void launch_argmax_u8(const float* logits, int B, int C, int H, int W, uint8_t* mask, hipStream_t s) {
   LDIFF_CHECK(C >= 1 && C <= 256, LDIFF_ERR_INVALID, "argmax: class count %d out of range [1,256]", C);

@@ -212,6 +212,13 @@ static void launch_cfg(const ConvParams& p, hipStream_t s) {
     attr_set = true;
   }
   const int ntm = (p.M + BM - 1) / BM, ntn = (p.N + BN - 1) / BN;
+  static const std::string pname = std::string("igemm<") + std::to_string(BM) + "," + std::to_string(BN) + (FAST ? ",fast" : ",gen") +
+                                   (GN ? ",gn>" : ">");
+  // algorithmic work: 2*M*N*K flops; each source tensor, the weights and the residual read once, the output written once
+  const double esz = 2.0;
+  const double in_bytes = (double)p.B * p.Hin * p.Win * (p.C1 + p.C2) * esz;
+  const double bytes = in_bytes + (double)p.N * p.K * esz + (double)p.M * p.N * (p.out_f32 ? 4.0 : esz) + (p.res ? (double)p.M * p.N * esz : 0.0);
+  ProfScope prof(pname.c_str(), 2.0 * p.M * (double)p.N * p.K, bytes, s);
   hipLaunchKernelGGL(kern, dim3(ntm * ntn), dim3(256), smem, s, p);
   HIP_CHECK(hipGetLastError());
 }
@@ -232,6 +239,7 @@ void launch_igemm(const ConvParams& p, hipStream_t s) {
   LDIFF_CHECK(!p.res || p.ld_res % 4 == 0, LDIFF_ERR_INVALID, "igemm: ld_res must be a multiple of 4");
   LDIFF_CHECK(!p.temb || p.ld_temb % 4 == 0, LDIFF_ERR_INVALID, "igemm: ld_temb must be a multiple of 4");
   if (p.M <= 0) return;
+  if (conv3x3_eligible(p)) { launch_conv3x3(p, s); return; }
   const bool fast = (Cin % BK == 0) && (p.C1 % BK == 0);
   // Tile choice: largest tile that still yields >= ~2 workgroups per CU worth of tiles; narrow N gets BN=64.
   auto tiles = [&](int bm, int bn) { return (long long)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn); };

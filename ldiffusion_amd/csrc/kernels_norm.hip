@@ -96,6 +96,7 @@ void launch_gn_stats(const f16* x, int C1, const f16* x2, int C2, int B, int HW,
   const int nchunk = gn_chunks(HW);
   const int pix = (HW + nchunk - 1) / nchunk;
   const size_t smem = 2 * 2048 * sizeof(float);  // [2][R][C] with R*C <= 256*8
+  ProfScope prof("gn_stats", 3.0 * B * HW * (double)C, 2.0 * B * HW * (double)C, s);
   hipLaunchKernelGGL(gn_partial_kernel, dim3(nchunk, B, C2 ? 2 : 1), dim3(256), smem, s, x, C1, x2, C2, HW, pix, nchunk, partial);
   HIP_CHECK(hipGetLastError());
   hipLaunchKernelGGL(gn_finalize_kernel, dim3(groups, B), dim3(64), 0, s, partial, nchunk, C, groups, HW, eps, gamma, beta, scale, shift);

@@ -10,6 +10,7 @@ spacing, steps_offset=1, set_alpha_to_one=False), see SURVEY.md 8a R6.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from types import SimpleNamespace
 
 import numpy as np
@@ -60,10 +61,9 @@ class PNDMScheduler:
     def _coeffs(self, timestep, prev_timestep):
         a_t = self.alphas_cumprod[timestep]
         a_prev = self.alphas_cumprod[prev_timestep] if prev_timestep >= 0 else self.final_alpha_cumprod
-        b_t, b_prev = 1 - a_t, 1 - a_prev
-        sample_coeff = (a_prev / a_t) ** 0.5
-        denom = a_t * b_prev ** 0.5 + (a_t * b_t * a_prev) ** 0.5
-        return float(sample_coeff), float(-(a_prev - a_t) / denom)
+        sc, ce = C.c_float(), C.c_float()
+        _lib.check(_lib.load().ldiff_pndm_coeffs(float(a_t), float(a_prev), C.byref(sc), C.byref(ce)))
+        return sc.value, ce.value
 
     def step(self, model_output, timestep, sample, return_dict=True):
         if self.num_inference_steps is None:
@@ -101,6 +101,8 @@ class PNDMScheduler:
             raise ValueError("scheduler.step operands must be CUDA tensors of one shape")
         out = torch.empty_like(sample)
         cf = (C.c_float * len(coef))(*coef)
+        if os.environ.get("LDIFF_DEBUG"):
+            print(f"[scheduler.step] t={timestep} prev_t={prev_timestep} n_ets={len(self.ets)} coef:", " ".join(f"{v:.9g}" for v in cf))
         op = (C.c_void_p * len(ops))(*[o.data_ptr() for o in ops])
         _lib.check(lib.ldiff_pndm_step(cf, op, len(ops), _lib.ptr(out), sample.numel(), _lib.stream_ptr()))
         self.counter += 1

@@ -196,7 +196,7 @@ def test_laplace_given_u_matches_oracle_and_torch_distribution():
     assert abs(a.mean().item()) < 5e-3 and abs(a.abs().mean().item() - 0.5) < 5e-3 and abs(a.var().item() - 0.5) < 2e-2
 
 
-def test_argmax_and_float_luma_bit_exact():
+def test_argmax_bit_exact_and_float_luma():
     g = torch.Generator().manual_seed(11)
     logits = torch.randn((2, 6, 33, 47), generator=g)
     logits[0, :, 0, 0] = 1.0           # all tie -> lowest index
@@ -204,7 +204,8 @@ def test_argmax_and_float_luma_bit_exact():
     m = argmax_mask(logits.to(DEV)).cpu().numpy()
     assert np.array_equal(m, noise_post.argmax_mask(logits))
     rgb = torch.rand((2, 3, 17, 19), generator=g) * 2 - 0.5
-    assert torch.equal(luma_float(rgb.to(DEV)).cpu(), noise_post.luma_float(rgb))
+    # float luma: same three products; torch's CPU reduction order over the 3 channels is ISA dependent -> 1-2 ulp
+    assert (luma_float(rgb.to(DEV)).cpu() - noise_post.luma_float(rgb)).abs().max() <= 2.5e-7
     assert argmax_mask(torch.zeros((0, 6, 4, 4), device=DEV)).shape == (0, 4, 4)
 
 

@@ -1,0 +1,123 @@
+"""CPU (-m "not gpu"): the C-ABI library loads and exports every declared symbol; host-only entry points; patch
+sharding + the N>1 gather path on gloo with world_size 2.  No compute kernel is launched here (there is no GPU)."""
+import ctypes as C
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from ldiffusion_amd import _lib, parallel
+from oracle import schedule
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_symbol_declared_in_header(lib):
+    hdr = open(os.path.join(ROOT, "include", "ldiff.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(ldiff_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 30
+    assert declared == set(_lib.SIGNATURES), f"header vs ctypes table differ: {declared ^ set(_lib.SIGNATURES)}"
+    for name in declared:
+        assert hasattr(lib, name), f"{name} not exported by libldiff_hip.so"
+    assert lib.ldiff_version() == 100
+
+
+def test_host_only_entry_points_match_oracle(lib):
+    buf = (C.c_float * 1000)()
+    assert lib.ldiff_pndm_alphas_cumprod(buf, 1000) == 0
+    a, b = np.array(buf[:], np.float32), schedule.alphas_cumprod().numpy()
+    assert np.abs(a - b).max() <= 4e-7            # ~2 ulp (ATen's vectorised linspace rounds twice); python passes torch's table
+    ts = (C.c_int64 * 64)()
+    for n_passes in (1, 3, 5, 20):
+        k = lib.ldiff_plms_timesteps(n_passes, ts, 64)
+        assert list(ts[:k]) == schedule.plms_timesteps(1 if n_passes == 1 else n_passes - 1).tolist() and k == n_passes
+    for bad in (0, 2, -3, 1002):
+        assert lib.ldiff_plms_timesteps(bad, ts, 64) == -1 and b"n_passes" in lib.ldiff_last_error()
+    assert lib.ldiff_plms_timesteps(5, ts, 2) == -1   # capacity too small
+    # _get_prev_sample coefficients vs the oracle's float32 torch arithmetic
+    sch = schedule.PNDMOracle()
+    sc, ce = C.c_float(), C.c_float()
+    for t, p in [(751, 501), (501, 251), (251, 1), (1, -249)]:
+        a_prev = sch.alphas_cumprod[p] if p >= 0 else sch.final_alpha_cumprod
+        assert lib.ldiff_pndm_coeffs(float(sch.alphas_cumprod[t]), float(a_prev), C.byref(sc), C.byref(ce)) == 0
+        osc, oce, _, _ = sch.prev_sample_coeffs(t, p)
+        assert abs(sc.value - float(osc)) <= 3e-7 * abs(float(osc)) and abs(ce.value + float(oce)) <= 3e-7 * abs(float(oce))
+    assert lib.ldiff_pndm_coeffs(0.0, 0.5, C.byref(sc), C.byref(ce)) == -1
+
+
+def test_error_mapping_and_no_cpu_fallback(lib):
+    with pytest.raises(ValueError):
+        _lib.check(lib.ldiff_plms_timesteps(2, (C.c_int64 * 4)(), 4))
+    if not torch.cuda.is_available():
+        with pytest.raises(RuntimeError, match="no CPU fallback"):
+            _lib.require_gpu()
+        from ldiffusion_amd import configs, weights
+        from ldiffusion_amd.models import UNet2DConditionModel
+        with pytest.raises(RuntimeError):
+            UNet2DConditionModel(configs.TINY_UNET, {}, "cuda:0")   # product path refuses to run without the GPU
+
+
+def test_product_never_imports_the_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "ldiffusion_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f"{f} imports the oracle"
+
+
+def test_shard_range_partitions_exactly():
+    for total in (0, 1, 7, 8, 64, 65):
+        for world in (1, 2, 3, 8):
+            spans = [parallel.shard_range(total, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == total
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+            sizes = [hi - lo for lo, hi in spans]
+            assert max(sizes) - min(sizes) <= 1
+    assert parallel.shard_range(64, 3, 8) == (24, 32)
+    with pytest.raises(ValueError):
+        parallel.shard_range(8, 2, 2)
+    m = torch.arange(6, dtype=torch.uint8).view(6, 1, 1)
+    assert parallel.gather_masks(m, 6) is m          # no process group: identity on the full batch
+    with pytest.raises(ValueError):
+        parallel.gather_masks(m, 7)
+
+
+_WORKER = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, {root!r})
+from ldiffusion_amd import parallel
+dist.init_process_group("gloo")
+rank, world, _ = parallel.world_info()
+assert (rank, world) == (dist.get_rank(), dist.get_world_size()) and world == 2
+for total in (8, 5):                                   # even and ragged shards
+    lo, hi = parallel.shard_range(total, rank, world)
+    full = (torch.arange(total * 4 * 4, dtype=torch.int64) % 251).to(torch.uint8).view(total, 4, 4)   # "masks" every rank can rebuild
+    got = parallel.gather_masks(full[lo:hi].clone(), total)
+    assert got.dtype == torch.uint8 and torch.equal(got, full), (rank, total)
+feats = torch.full((4, 5, 2, 2), rank, dtype=torch.uint8)          # features [n_r, N, H, W]
+allf = parallel.gather_masks(feats, 8)
+assert allf.shape == (8, 5, 2, 2) and allf[:4].eq(0).all() and allf[4:].eq(1).all()
+try:
+    parallel.gather_masks(torch.zeros((3, 4, 4), dtype=torch.uint8), 8)
+    raise SystemExit("expected ValueError")
+except ValueError:
+    pass
+dist.barrier()
+dist.destroy_process_group()
+print("rank", rank, "ok")
+"""
+
+
+def test_gather_masks_world_size_2_gloo(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(_WORKER.format(root=ROOT))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", "29541", str(script)]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=240, env=dict(os.environ, OMP_NUM_THREADS="1"))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "rank 0 ok" in r.stdout and "rank 1 ok" in r.stdout

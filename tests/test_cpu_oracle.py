@@ -1,0 +1,211 @@
+"""CPU (-m "not gpu"): the oracle against the committed golden fixtures.
+
+third_party fixtures (tests/golden/{laplace_torch,luma_pil,round_numpy}.npz, reference_*.{json,npz}) PIN the oracle:
+they were produced by installed torch / Pillow / numpy and by the reference's own python (scripts/gen_golden*.py).
+restatement fixtures (pndm.npz, tiny_graph.npz) freeze the restated diffusers semantics (diffusers itself is absent:
+parity for those functions is unpinned, see oracle/__init__.py).
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from ldiffusion_amd import configs, weights
+from oracle import metrics, noise_post, pipeline as op, schedule, unet as ounet
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def gold(name):
+    return np.load(os.path.join(GOLD, name), allow_pickle=False)
+
+
+# ---------------------------------------------------------------- pinned against third-party code
+def test_laplace_matches_torch_distributions_bit_exact():
+    z = gold("laplace_torch.npz")
+    assert str(z["provenance"]).startswith("third_party")
+    for scale, u, sample in zip(z["scale"], z["u"], z["sample"]):
+        got = noise_post.laplace_from_uniform(torch.from_numpy(u), 0.0, torch.tensor(float(scale)))
+        assert np.array_equal(got.numpy(), sample)
+    # and live against the installed torch (same global-generator draw)
+    torch.manual_seed(11)
+    ref = torch.distributions.Laplace(0, torch.tensor(0.5)).sample((64,))
+    torch.manual_seed(11)
+    u = torch.empty(64).uniform_(torch.finfo(torch.float32).eps - 1, 1)
+    assert torch.equal(noise_post.laplace_from_uniform(u, 0.0, torch.tensor(0.5)), ref)
+
+
+def test_laplace_forward_noise_scale_and_edges():
+    abar = schedule.alphas_cumprod()
+    for t, s in [(1, 0.0413), (251, 0.573), (501, 0.851), (751, 0.972)]:   # SURVEY R7 spot values
+        assert abs(float(torch.sqrt(1 - abar[t])) - s) < 5e-4
+    z0 = torch.zeros(4)
+    u = torch.tensor([0.0, 0.5, -0.5, torch.finfo(torch.float32).eps - 1])
+    x = noise_post.laplace_forward_noise(z0, abar[501], u)
+    assert x[0] == 0 and x[1] > 0 and x[2] == -x[1] and torch.isfinite(x).all() and x[3] < -10
+
+
+def test_luma_matches_pillow_bit_exact():
+    z = gold("luma_pil.npz")
+    assert np.array_equal(noise_post.luma_u8(z["rgb"]), z["luma"])
+    from PIL import Image
+    rgb = np.random.default_rng(5).integers(0, 256, size=(33, 17, 3), dtype=np.uint8)
+    assert np.array_equal(noise_post.luma_u8(rgb), np.array(Image.fromarray(rgb).convert("L")))
+
+
+def test_uint8_rounding_matches_numpy_half_even():
+    z = gold("round_numpy.npz")
+    assert np.array_equal(noise_post.to_uint8(z["x"]), z["u8"])
+    assert noise_post.to_uint8(np.array([0.5 / 255, 1.5 / 255, 2.5 / 255], np.float32)).tolist() == [0, 2, 2]
+
+
+def test_metrics_and_luts_match_reference_python():
+    with open(os.path.join(GOLD, "reference_metrics.json")) as f:
+        fx = json.load(f)
+    for c in fx["metrics"]:
+        B, Cc, H, W = c["shape"]
+        g = torch.Generator().manual_seed(c["seed"])
+        logits = torch.randn((B, Cc, H, W), generator=g)
+        target = torch.randint(0, Cc, (B, H, W), generator=g)
+        if c["force_class0"]:
+            target[:] = 0
+            logits[:, 0] += 100
+        per, avg = metrics.micro_dice(logits, target, Cc)
+        assert per.tolist() == pytest.approx(c["dice_per_class"], abs=1e-7) and float(avg) == pytest.approx(c["dice"], abs=1e-7)
+        miou, iou = metrics.mean_iou_and_per_class(logits, target, Cc)
+        assert miou == pytest.approx(c["miou"], abs=1e-12) and {str(k): v for k, v in iou.items()} == c["iou_per_class"]
+        assert metrics.pixel_accuracy(logits, target, Cc)[0] == pytest.approx(c["pixel_accuracy"], abs=1e-12)
+        assert metrics.frequency_weighted_iou(logits, target, Cc) == pytest.approx(c["fw_iou"], abs=1e-7)
+    assert {str(k): v for k, v in metrics.PIXEL_TO_LABEL.items()} == fx["luts"]["pixel_to_label"]
+    assert {str(k): v for k, v in metrics.PIXEL_TO_LABEL_CELL.items()} == fx["luts"]["pixel_to_label_cell"]
+    assert metrics.map_mask(np.array(fx["luts"]["map_mask_in"], np.uint8)).tolist() == fx["luts"]["map_mask_out"]
+
+
+def test_one_pass_sampler_restatement_equals_reference_loop():
+    """Segmentor.ldiffusion_augment (reference code, segmentor.py:86-112) was run on the oracle's objects to make the fixture;
+    the oracle's own restatement of that loop must reproduce it: same UNet timesteps, same decoded images."""
+    from PIL import Image
+    z = gold("reference_augment_v3.npz")
+    ucfg, vcfg = configs.TINY_UNET, configs.TINY_VAE
+    usd = weights.synthetic_state_dict(weights.unet_param_shapes(ucfg), 42)
+    vsd = weights.synthetic_state_dict(weights.vae_param_shapes(vcfg), 43)
+    pipe = op.OraclePipeline(op.OracleUNet(usd, ucfg), op.OracleVAE(vsd, vcfg))
+    g = torch.Generator().manual_seed(int(z["inputs_seed"]))
+    inputs = torch.rand((2, 3, 64, 64), generator=g)
+    table = torch.randn((49408, int(z["hidden"])), generator=torch.Generator().manual_seed(99)) * 0.5
+    emb = table[torch.tensor([z["ids"].tolist()])]                                  # text_encoder(ids)["last_hidden_state"]
+    ctx = torch.nn.functional.linear(emb, torch.from_numpy(z["proj_weight"]), torch.from_numpy(z["proj_bias"]))  # segmentor.py:60
+    outs = []
+    for i in range(2):                                                              # the reference loops one image at a time
+        r = op.sample_one_pass(pipe, inputs[i:i + 1], ctx)
+        im = Image.fromarray(r["rgb_u8"][0]).resize((1024, 1024), Image.BILINEAR)   # Resize((1024,1024)) + ToTensor (segmentor.py:87-90,108)
+        outs.append(torch.from_numpy(np.asarray(im, np.float32) / 255.0).permute(2, 0, 1))
+    out = torch.stack(outs)
+    assert pipe.unet.calls == z["unet_calls"].tolist() == [1, 1]                    # set_timesteps(1) -> one pass at t = 1 per image
+    assert list(out.shape) == z["out_shape"].tolist()
+    assert np.array_equal(torch.nn.functional.avg_pool2d(out, 64).numpy(), z["pooled"])
+
+
+# ---------------------------------------------------------------- restated diffusers semantics (regression fixtures)
+def test_pndm_schedule_and_trajectory():
+    z = gold("pndm.npz")
+    sch = schedule.PNDMOracle()
+    assert np.array_equal(sch.alphas_cumprod.numpy(), z["alphas_cumprod"])
+    a = sch.alphas_cumprod
+    for t, v in [(0, 0.999150), (1, 0.998296), (251, 0.672151), (501, 0.274999), (751, 0.055719)]:   # SURVEY R6 spot values
+        assert abs(float(a[t]) - v) < 2e-6
+    for n in (1, 2, 4, 5, 10, 19, 20):
+        assert np.array_equal(schedule.plms_timesteps(n), z[f"timesteps_{n}"])
+    assert schedule.plms_timesteps(1).tolist() == [1]
+    assert schedule.plms_timesteps(4).tolist() == [751, 501, 501, 251, 1]
+    assert schedule.plms_timesteps(5).tolist() == [801, 601, 601, 401, 201, 1]
+    assert len(schedule.plms_timesteps(20)) == 21
+    sch.set_timesteps(4)
+    x = torch.from_numpy(z["traj_x"][0])
+    for i, t in enumerate(sch.timesteps):
+        x = sch.step(torch.from_numpy(z["traj_eps"][i]), t, x).prev_sample
+        assert np.allclose(x.numpy(), z["traj_x"][i + 1], rtol=0, atol=1e-6)
+    with pytest.raises(ZeroDivisionError):
+        schedule.plms_timesteps(0)
+
+
+def test_plms_second_call_reuses_first_sample():
+    """counter==1 branch: timestep is rewound and the update restarts from the sample of the first call."""
+    sch = schedule.PNDMOracle()
+    sch.set_timesteps(4)
+    x0 = torch.ones(3)
+    e0, e1 = torch.full((3,), 0.5), torch.full((3,), -0.25)
+    x1 = sch.step(e0, 751, x0).prev_sample
+    x2 = sch.step(e1, 501, x1).prev_sample
+    sc, ce, _, _ = sch.prev_sample_coeffs(751, 501)
+    assert torch.allclose(x2, sc * x0 - ce * (e0 + e1) / 2, atol=1e-6)
+
+
+def test_timestep_embedding_layout():
+    e = ounet.timestep_embedding(torch.tensor([0, 7]), 320, True, 0)
+    assert e.shape == (2, 320)
+    assert torch.all(e[0, :160] == 1) and torch.all(e[0, 160:] == 0)         # flip_sin_to_cos: [cos | sin]
+    assert abs(float(e[1, 0]) - float(torch.cos(torch.tensor(7.0)))) < 1e-6  # freq_0 = 1
+
+
+def test_param_counts_match_sd15():
+    u = weights.param_count(weights.unet_param_shapes(configs.SD15_UNET))
+    v = weights.vae_param_shapes(configs.SD15_VAE)
+    enc = weights.param_count({k: s for k, s in v.items() if k.startswith(("encoder", "quant"))})
+    dec = weights.param_count({k: s for k, s in v.items() if k.startswith(("decoder", "post"))})
+    assert (u, enc, dec) == (859_520_964, 34_163_664, 49_490_199)           # published SD-v1.5 sizes
+
+
+def test_tiny_graph_regression():
+    z = gold("tiny_graph.npz")
+    ucfg, vcfg = configs.TINY_UNET, configs.TINY_VAE
+    usd = weights.synthetic_state_dict(weights.unet_param_shapes(ucfg), 42)
+    vsd = weights.synthetic_state_dict(weights.vae_param_shapes(vcfg), 43)
+    pipe = op.OraclePipeline(op.OracleUNet(usd, ucfg), op.OracleVAE(vsd, vcfg))
+    x, ctx, lat = (torch.from_numpy(z[k]) for k in ("images", "ctx", "lat_in"))
+    close = lambda a, b: np.abs(a - b).max() <= 2e-5 * max(1.0, np.abs(b).max())   # thread-count dependent fp32 summation order
+    assert close(pipe.unet(lat, 501, ctx).sample.numpy(), z["unet_eps_t501"])
+    d = pipe.vae.encode(x).latent_dist
+    assert close(torch.cat([d.mean, d.logvar], 1).numpy(), z["vae_moments"])
+    assert close(pipe.vae.decode(lat).sample.numpy(), z["vae_decode"])
+    s5 = op.sample_v6(pipe, x, ctx, 5)
+    assert pipe.unet.calls[-5:] == z["v6_unet_calls"].tolist() == [751, 501, 501, 251, 1]
+    assert close(s5["latents"][-1].numpy(), z["v6_latents"][-1])
+    assert (np.abs(s5["features"].astype(int) - z["v6_features"].astype(int)) > 1).mean() < 1e-3
+
+
+def test_sampler_edge_cases():
+    ucfg, vcfg = configs.TINY_UNET, configs.TINY_VAE
+    usd = weights.synthetic_state_dict(weights.unet_param_shapes(ucfg), 42)
+    vsd = weights.synthetic_state_dict(weights.vae_param_shapes(vcfg), 43)
+    pipe = op.OraclePipeline(op.OracleUNet(usd, ucfg), op.OracleVAE(vsd, vcfg))
+    x = torch.rand((1, 3, 64, 64))                    # smallest patch the 4-level UNet accepts (8x8 latents)
+    ctx = torch.randn((1, 1, 64))                     # shortest possible context
+    r = op.sample_v6(pipe, x, ctx, 3)
+    assert r["features"].shape == (1, 3, 64, 64) and r["features"].dtype == np.uint8
+    with pytest.raises(ZeroDivisionError):            # N=1 -> set_timesteps(0), as the reference would (pixel_latent_vector.py:74)
+        op.sample_v6(pipe, x, ctx, 1)
+    lat = pipe.vae.encode(x).latent_dist
+    assert torch.equal(lat.sample(noise=torch.zeros_like(lat.mean)), lat.mean)
+    g = torch.Generator().manual_seed(3)
+    u = [noise_post.laplace_uniform_draw((1, 4, 8, 8), g) for _ in range(2)]
+    f = op.laplace_features_v5(pipe, x, ctx, 1, u, out_hw=16)   # ldiffusion.py:198: N=5 -> set_timesteps(1) -> one pass
+    assert f["gray"].shape == (1, 1, 16, 16)
+
+
+def test_weights_layout_roundtrip(tmp_path):
+    cfg = configs.TINY_VAE
+    sd = weights.synthetic_state_dict(weights.vae_param_shapes(cfg), 1)
+    weights.save_model_dir(str(tmp_path / "vae"), cfg, sd)
+    cfg2, sd2 = weights.load_model_dir(str(tmp_path / "vae"))
+    assert cfg2["block_out_channels"] == cfg["block_out_channels"] and all(torch.equal(sd[k], sd2[k]) for k in sd)
+    old = {k.replace(".to_q.", ".query.").replace(".to_k.", ".key.").replace(".to_v.", ".value.").replace(".to_out.0.", ".proj_attn."): v
+           for k, v in sd.items()}
+    assert set(weights.normalize_vae_keys(old)) == set(sd)
+    with pytest.raises(FileNotFoundError):
+        os.remove(tmp_path / "vae" / weights.WEIGHTS_NAME)
+        weights.load_model_dir(str(tmp_path / "vae"))
+    with pytest.raises(ValueError):
+        configs.validate_unet_config(dict(configs.SD15_UNET, block_out_channels=[100, 200, 400, 400]))

@@ -1,0 +1,51 @@
+"""Host-side mirror of the reference's orchestrator `LDiffusionModel` (/root/reference/ldiffusion.py:31-324) for the
+sampling path: same constructor and `inference(...)` signature, same error for an invalid level.  Training
+(`train`, `train_ldiffusion`: DeepSpeed ZeRO-3 fine-tuning, ldiffusion.py:121-315) is a "next" row of SURVEY.md 8f and raises.
+"""
+from __future__ import annotations
+
+import os
+
+import torch
+
+from .parallel import world_info
+from .segmentor import Segmentor
+
+
+class LDiffusionModel:
+    def __init__(self, diffusion_path, level, local_rank=-1):
+        rank, world, env_local = world_info()                     # ldiffusion.py:34-35,42
+        self.world_size, self.rank = world, rank
+        self.is_distributed = world > 1
+        self.local_rank = int(local_rank if local_rank is not None and local_rank >= 0 else env_local)
+        if not torch.cuda.is_available():
+            raise RuntimeError("ldiffusion_amd.LDiffusionModel needs a ROCm GPU (the MI355X path has no CPU fallback)")
+        torch.cuda.set_device(self.local_rank)
+        self.device = torch.device(f"cuda:{self.local_rank}")
+        self.diffusion_path = diffusion_path
+        self.level = level
+        self.linear_layer = None
+
+    def _is_main_process(self):
+        return self.rank == 0
+
+    def load_model(self, model_path):
+        """ldiffusion.py:66-70 -> (pipeline, vae)"""
+        from .pipeline import StableDiffusionImg2ImgPipeline
+        pipeline = StableDiffusionImg2ImgPipeline.from_pretrained(model_path, torch_dtype=torch.float32, device=self.device)
+        return pipeline, pipeline.vae
+
+    def train(self, args, component="all", ldiffusion_weight=None, **_ignored):
+        raise NotImplementedError("LDiffusionModel.train (ZeRO-3 fine-tuning, ldiffusion.py:121-315) is outside the sampling hot path "
+                                  "this build accelerates (SURVEY.md 8f rank 2)")
+
+    def inference(self, image_path, ldiffusion_weight, segmentor_weight, num_classes, head=None, **_readme_kwargs):
+        """ldiffusion.py:317-324.  `head` = the segmentation head callable (out of scope, see segmentor.py); extra README-era
+        keyword arguments (dtm_path, output_path) are accepted and ignored like the code ignores them."""
+        segmentor = Segmentor(train_loader=None, val_loader=None, level=self.level, num_classes=num_classes)
+        if self.level == "tissue":
+            raise RuntimeError("tissue inference runs the vendored nnU-Net predictor (segmentor.py:388-488), which is outside the hot-path scope")
+        elif self.level == "cell":
+            return segmentor.inference_cell_model(image_path, self.diffusion_path, ldiffusion_weight, segmentor_weight, head=head)
+        else:
+            raise ValueError("Invalid level specified. Choose 'tissue' or 'cell'.")

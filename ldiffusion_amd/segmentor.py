@@ -1,0 +1,141 @@
+"""Host-side mirror of the reference's `Segmentor` for the sampling path (same names, argument meaning and errors).
+
+Mirrors /root/reference/segmentor.py: `_resolve_ldiffusion_dir` (:26-29), `_ensure_ldiffusion_proj` (:31-52),
+`_get_text_embeddings` (:54-60), `load_ldiffusion` (:76-84), `ldiffusion_augment` (:86-112), `_UNetTextAlignWrapper`
+(:183-205), and the sampler part + mask tail of `inference_cell_model` (:490-545).  The segmentation heads themselves
+(`model/conductor.py`, nnU-Net) are outside the hot-path scope: `inference_cell_model` takes the head as
+a callable and raises if none is given instead of silently substituting one.
+"""
+from __future__ import annotations
+
+import os
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .models import UNet2DConditionModel
+from .pipeline import PROMPT, LaplaceSampler, StableDiffusionImg2ImgPipeline, argmax_mask
+
+IMAGENET_MEAN = (0.485, 0.456, 0.406)  # segmentor.py:508
+IMAGENET_STD = (0.229, 0.224, 0.225)
+
+
+class TextAlignedUNet:
+    """`_UNetTextAlignWrapper` (segmentor.py:183-205): when `encoder_hidden_states` is None or its last dim differs from
+    `cross_attention_dim`, the cached default embeddings are used instead, expanded to the batch."""
+
+    def __init__(self, base_unet, default_text_embeddings):
+        self.base_unet = base_unet
+        self.default_text_embeddings = default_text_embeddings
+        self.cross_attention_dim = base_unet.config.cross_attention_dim
+        self.config = base_unet.config
+
+    def __call__(self, sample, timestep, encoder_hidden_states, *args, **kwargs):
+        use_fallback = encoder_hidden_states is None or encoder_hidden_states.shape[-1] != self.cross_attention_dim
+        if use_fallback:
+            emb = self.default_text_embeddings
+            if emb.shape[0] != sample.shape[0]:
+                emb = emb[:1].expand(sample.shape[0], -1, -1)
+            encoder_hidden_states = emb
+        return self.base_unet(sample, timestep, encoder_hidden_states.to(sample.device, dtype=torch.float32), *args, **kwargs)
+
+    forward = __call__
+
+    def eval(self):
+        return self
+
+    def to(self, *a, **k):
+        return self
+
+
+class Segmentor:
+    def __init__(self, train_loader, val_loader, level, num_classes):
+        if not torch.cuda.is_available():
+            raise RuntimeError("ldiffusion_amd.Segmentor needs a ROCm GPU (no CPU fallback)")
+        self.device = torch.device(f"cuda:{torch.cuda.current_device()}")
+        self.level = level
+        self.num_classes = num_classes
+        self.model = None
+        self.train_loader, self.val_loader = train_loader, val_loader
+        self.ldiffusion_proj = None
+        self._sampler = None
+
+    def _resolve_ldiffusion_dir(self, ldiffusion_weight):
+        return ldiffusion_weight if os.path.isdir(ldiffusion_weight) else os.path.dirname(ldiffusion_weight)
+
+    def _ensure_ldiffusion_proj(self, pipeline, unet, ldiffusion_weight=None):
+        hidden = pipeline.text_encoder.config.hidden_size
+        cad = unet.config.cross_attention_dim
+        if self.ldiffusion_proj is None or self.ldiffusion_proj.in_features != hidden or self.ldiffusion_proj.out_features != cad:
+            self.ldiffusion_proj = nn.Linear(hidden, cad).to(self.device, dtype=torch.float32)
+        if ldiffusion_weight is not None:
+            p = os.path.join(self._resolve_ldiffusion_dir(ldiffusion_weight), "proj_weights.pt")
+            if os.path.exists(p):
+                self.ldiffusion_proj.load_state_dict(torch.load(p, map_location=self.device), strict=True)
+        self.ldiffusion_proj = self.ldiffusion_proj.to(self.device, dtype=torch.float32).eval()
+        return self.ldiffusion_proj
+
+    @torch.no_grad()
+    def _get_text_embeddings(self, prompt, batch_size, pipeline, unet):
+        proj = self._ensure_ldiffusion_proj(pipeline, unet)
+        ids = torch.tensor(pipeline.tokenizer([prompt] * batch_size)["input_ids"], dtype=torch.long, device=self.device)
+        emb = pipeline.text_encoder(ids)["last_hidden_state"].to(dtype=torch.float32)
+        return proj(emb).to(dtype=torch.float32)
+
+    def initialize_model(self, level, num_classes):
+        if level not in ("tissue", "cell"):
+            raise ValueError("Invalid level specified. Choose 'tissue' or 'cell'.")
+        raise RuntimeError("the segmentation heads (model/conductor.py, nnU-Net) are outside the MI355X hot-path scope; pass `head=`")
+
+    def load_ldiffusion(self, ldiffusion_weight, diffusion_path):
+        pipeline = StableDiffusionImg2ImgPipeline.from_pretrained(diffusion_path, torch_dtype=torch.float32, device=self.device)
+        unet = UNet2DConditionModel.from_pretrained(ldiffusion_weight, device=self.device).eval()
+        vae = pipeline.vae
+        pipeline.unet = unet
+        if pipeline.text_encoder is not None:
+            self._ensure_ldiffusion_proj(pipeline, unet, ldiffusion_weight=ldiffusion_weight)
+        return pipeline, unet, vae
+
+    def _one_pass(self, images, text_embeddings, pipeline, unet):
+        if self._sampler is None or self._sampler.pipeline is not pipeline or pipeline.unet is not unet:
+            pipeline.unet = unet
+            self._sampler = LaplaceSampler(pipeline)
+        return self._sampler.sample(images, text_embeddings, 1, want_features=False, want_rgb=True)
+
+    @torch.no_grad()
+    def ldiffusion_augment(self, inputs, pipeline, unet, vae, text_embeddings=None):
+        """segmentor.py:86-112, batched: encode mean -> set_timesteps(1) -> one UNet pass -> step -> decode -> uint8 ->
+        Resize((1024,1024)) + ToTensor.  Returns float [B,3,1024,1024] in [0,1] on the device."""
+        if text_embeddings is None:
+            text_embeddings = self._get_text_embeddings(PROMPT, 1, pipeline, unet)
+        out = self._one_pass(inputs.to(self.device, dtype=torch.float32), text_embeddings, pipeline, unet)
+        rgb = out["rgb"]  # [B,H,W,3] u8
+        if rgb.shape[1:3] == (1024, 1024):
+            return rgb.permute(0, 3, 1, 2).float() / 255.0
+        from PIL import Image  # other sizes: the reference's PIL bilinear Resize, on the host
+        ims = [np.asarray(Image.fromarray(a).resize((1024, 1024), Image.BILINEAR), np.float32) / 255.0 for a in rgb.cpu().numpy()]
+        return torch.from_numpy(np.stack(ims)).permute(0, 3, 1, 2).contiguous().to(self.device)
+
+    @torch.no_grad()
+    def inference_cell_model(self, image_path, diffusion_path, ldiffusion_weight, segmentor_weight, head=None, text_embeddings=None):
+        """segmentor.py:490-545 with the head injected: `head(decoded_rgb_float[1,3,1024,1024] normalised) -> logits [1,C,H,W]`."""
+        from PIL import Image
+        if head is None:
+            raise RuntimeError("inference_cell_model: CellSegClassifier (Cellpose + ResNet152) is outside the hot-path scope; pass `head=`")
+        pipeline, unet, _ = self.load_ldiffusion(ldiffusion_weight, diffusion_path)
+        image = Image.open(image_path).convert("RGB")
+        width, height = image.size
+        mean = torch.tensor(IMAGENET_MEAN, device=self.device).view(1, 3, 1, 1)
+        std = torch.tensor(IMAGENET_STD, device=self.device).view(1, 3, 1, 1)
+        x = torch.from_numpy(np.asarray(image.resize((1024, 1024), Image.BILINEAR), np.float32) / 255.0).permute(2, 0, 1)[None].to(self.device)
+        x = (x - mean) / std
+        if text_embeddings is None:
+            text_embeddings = self._get_text_embeddings(PROMPT, 1, pipeline, unet)
+        out = self._one_pass(x, text_embeddings, pipeline, unet)
+        decoded = Image.fromarray(out["rgb"][0].cpu().numpy())
+        model_input = (out["rgb"].permute(0, 3, 1, 2).float() / 255.0 - mean) / std
+        logits = head(model_input)
+        mask = argmax_mask(logits)[0].cpu().numpy()
+        mask = np.array(Image.fromarray(mask.astype(np.uint8)).resize((width, height), resample=Image.NEAREST))
+        return decoded.resize((width, height), Image.BILINEAR), mask

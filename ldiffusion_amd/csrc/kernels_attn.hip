@@ -109,29 +109,36 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
     }
 
     // ---- online softmax (lane: query l15, keys 16t + 4g + r) ----
+    // VALU-bound for small head dims, so the per-score work is kept to max, one FMA, one bare v_exp_f32, one add and
+    // the fp16 convert: the running max is tracked on the RAW scores (scale > 0 keeps the order), the softmax scale
+    // and log2(e) are folded into the exponent FMA, and the key mask is applied only on the (uniform) tail tile.
     f16x8 pf[QT][NT / 2];
+    const bool tail = kv0 + BKV > p.Lk;
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) {
       float mx = -1e30f;
+      if (tail) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (kv0 + t * 16 + g * 4 + r >= p.Lk) sacc[qt][t][r] = -1e30f;
+      }
 #pragma unroll
       for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float sv = sacc[qt][t][r] * sl2;
-          if (kv0 + t * 16 + g * 4 + r >= p.Lk) sv = -1e30f;
-          sacc[qt][t][r] = sv;
-          mx = fmaxf(mx, sv);
-        }
+        for (int r = 0; r < 4; ++r) mx = fmaxf(mx, sacc[qt][t][r]);
       mx = fmaxf(mx, __shfl_xor(mx, 16));
       mx = fmaxf(mx, __shfl_xor(mx, 32));
       const float mnew = fmaxf(mrun[qt], mx);
-      const float alpha = exp2f(mrun[qt] - mnew);
+      const float alpha = __builtin_amdgcn_exp2f((mrun[qt] - mnew) * sl2);
+      const float moff = -mnew * sl2;
       float rs = 0.f;
 #pragma unroll
       for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          float pv = exp2f(sacc[qt][t][r] - mnew);
+          float pv = __builtin_amdgcn_exp2f(fmaf(sacc[qt][t][r], sl2, moff));
           rs += pv;
           pf[qt][t >> 1][(t & 1) * 4 + r] = (f16)pv;
         }

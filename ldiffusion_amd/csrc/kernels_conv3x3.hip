@@ -180,31 +180,51 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const ConvParams p) {  
   }
 
   // ---- epilogue: lane holds y[pixel = column][n = 4g + r] ----
+  // All global loads of the epilogue (bias, time embedding, residual) are issued back to back BEFORE any use; a
+  // load -> wait -> store chain per 16x16 tile costs a full memory round trip per tile (16-48 us per workgroup).
+  const int ncol = n0 + wave_n * (BN / 2) + g * 4;
+  f32x4 bt[NT];
+#pragma unroll
+  for (int a = 0; a < NT; ++a) {
+    const int n = ncol + a * 16;
+    float4 bb = make_float4(0.f, 0.f, 0.f, 0.f), tt = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (n < p.N) {
+      if (p.bias) bb = *reinterpret_cast<const float4*>(p.bias + n);
+      if (p.temb) tt = *reinterpret_cast<const float4*>(p.temb + (long long)b * p.ld_temb + n);
+    }
+    bt[a] = (f32x4){bb.x + tt.x, bb.y + tt.y, bb.z + tt.z, bb.w + tt.w};
+  }
+  long long mrow[MT];
 #pragma unroll
   for (int m = 0; m < MT; ++m) {
     const int ml = wave_m * (BM / 2) + m * 16 + l15;
     const int oy = oy0 + ml / TW, ox = ox0 + ml % TW;
-    if (oy >= p.Hout || ox >= p.Wout) continue;
-    const long long mrow = ((long long)b * p.Hout + oy) * p.Wout + ox;
+    mrow[m] = (oy < p.Hout && ox < p.Wout) ? ((long long)b * p.Hout + oy) * p.Wout + ox : -1;
+  }
+  f16x4 rr[MT][NT];
+  if (p.res) {
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int a = 0; a < NT; ++a) {
+        rr[m][a] = (f16x4){(f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f};
+        if (mrow[m] >= 0 && ncol + a * 16 < p.N) rr[m][a] = *reinterpret_cast<const f16x4*>(p.res + mrow[m] * p.ld_res + ncol + a * 16);
+      }
+  }
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+    if (mrow[m] < 0) continue;
 #pragma unroll
     for (int a = 0; a < NT; ++a) {
-      const int n = n0 + wave_n * (BN / 2) + a * 16 + g * 4;
+      const int n = ncol + a * 16;
       if (n >= p.N) continue;
-      f32x4 v = acc[a][m];
-      if (p.bias) { float4 bb = *reinterpret_cast<const float4*>(p.bias + n); v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w; }
-      if (p.temb) {
-        float4 tt = *reinterpret_cast<const float4*>(p.temb + (long long)b * p.ld_temb + n);
-        v[0] += tt.x; v[1] += tt.y; v[2] += tt.z; v[3] += tt.w;
-      }
-      if (p.res) {
-        f16x4 rr = *reinterpret_cast<const f16x4*>(p.res + mrow * p.ld_res + n);
-        v[0] += (float)rr[0]; v[1] += (float)rr[1]; v[2] += (float)rr[2]; v[3] += (float)rr[3];
-      }
+      f32x4 v = acc[a][m] + bt[a];
+      if (p.res) { v[0] += (float)rr[m][a][0]; v[1] += (float)rr[m][a][1]; v[2] += (float)rr[m][a][2]; v[3] += (float)rr[m][a][3]; }
       if (p.out_f32) {
-        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.y) + mrow * p.ldy + n) = v;
+        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.y) + mrow[m] * p.ldy + n) = v;
       } else {
         f16x4 o = {(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
-        *reinterpret_cast<f16x4*>(reinterpret_cast<f16*>(p.y) + mrow * p.ldy + n) = o;
+        *reinterpret_cast<f16x4*>(reinterpret_cast<f16*>(p.y) + mrow[m] * p.ldy + n) = o;
       }
     }
   }

@@ -173,30 +173,58 @@ __global__ __launch_bounds__(256) void igemm_kernel(const ConvParams p) {
   }
 
   // ---- epilogue: lane holds y[m = col][n = 4g + r], r = 0..3 ----
+  // Loads (bias, time embedding, residual) are issued back to back before any use: a load -> wait -> store chain per
+  // 16x16 tile costs one memory round trip per tile.
+  const int ncol = n0 + wave_n * (BN / 2) + g * 4;
+  f32x4 bb[NT];
+#pragma unroll
+  for (int a = 0; a < NT; ++a) {
+    float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p.bias && ncol + a * 16 < p.N) t = *reinterpret_cast<const float4*>(p.bias + ncol + a * 16);
+    bb[a] = (f32x4){t.x, t.y, t.z, t.w};
+  }
+  int mrow[MT];
 #pragma unroll
   for (int b = 0; b < MT; ++b) {
     const int m = m0 + wave_m * (BM / 2) + b * 16 + l15;
-    if (m >= p.M) continue;
-    const int bi = m / HWo;
+    mrow[b] = m < p.M ? m : -1;
+  }
+  f16x4 rr[MT][NT];
+  if (p.res) {
+#pragma unroll
+    for (int b = 0; b < MT; ++b)
+#pragma unroll
+      for (int a = 0; a < NT; ++a) {
+        rr[b][a] = (f16x4){(f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f};
+        if (mrow[b] >= 0 && ncol + a * 16 < p.N) rr[b][a] = *reinterpret_cast<const f16x4*>(p.res + (long long)mrow[b] * p.ld_res + ncol + a * 16);
+      }
+  }
+#pragma unroll
+  for (int b = 0; b < MT; ++b) {
+    if (mrow[b] < 0) continue;
+    const long long m = mrow[b];
+    f32x4 tt[NT];
+    if (p.temb) {
+      const int bi = mrow[b] / HWo;
+#pragma unroll
+      for (int a = 0; a < NT; ++a) {
+        float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ncol + a * 16 < p.N) t = *reinterpret_cast<const float4*>(p.temb + (long long)bi * p.ld_temb + ncol + a * 16);
+        tt[a] = (f32x4){t.x, t.y, t.z, t.w};
+      }
+    }
 #pragma unroll
     for (int a = 0; a < NT; ++a) {
-      const int n = n0 + wave_n * (BN / 2) + a * 16 + g * 4;
+      const int n = ncol + a * 16;
       if (n >= p.N) continue;
-      f32x4 v = acc[a][b];
-      if (p.bias) { float4 bb = *reinterpret_cast<const float4*>(p.bias + n); v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w; }
-      if (p.temb) {
-        float4 tt = *reinterpret_cast<const float4*>(p.temb + (long long)bi * p.ld_temb + n);
-        v[0] += tt.x; v[1] += tt.y; v[2] += tt.z; v[3] += tt.w;
-      }
-      if (p.res) {
-        f16x4 rr = *reinterpret_cast<const f16x4*>(p.res + (long long)m * p.ld_res + n);
-        v[0] += (float)rr[0]; v[1] += (float)rr[1]; v[2] += (float)rr[2]; v[3] += (float)rr[3];
-      }
+      f32x4 v = acc[a][b] + bb[a];
+      if (p.temb) v += tt[a];
+      if (p.res) { v[0] += (float)rr[b][a][0]; v[1] += (float)rr[b][a][1]; v[2] += (float)rr[b][a][2]; v[3] += (float)rr[b][a][3]; }
       if (p.out_f32) {
-        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.y) + (long long)m * p.ldy + n) = v;
+        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.y) + m * p.ldy + n) = v;
       } else {
         f16x4 o = {(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
-        *reinterpret_cast<f16x4*>(reinterpret_cast<f16*>(p.y) + (long long)m * p.ldy + n) = o;
+        *reinterpret_cast<f16x4*>(reinterpret_cast<f16*>(p.y) + m * p.ldy + n) = o;
       }
     }
   }

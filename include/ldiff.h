@@ -154,8 +154,14 @@ typedef struct {
   const void* temb; int ld_temb;                    /* f32 [B, ld_temb] or NULL */
   const void* res; int ld_res;                      /* f16 [M, ld_res] or NULL */
   void* y; int ldy; int out_f32;
+  void* stats;                                      /* optional f32 [B][N][R][2]: fused GroupNorm partial sums of y (R from ldiff_op_conv_stats_blocks) */
 } ldiff_conv_args;
 int ldiff_op_conv(const ldiff_conv_args*, void* stream);
+/* row blocks per image the launch would emit statistics for (0 = unsupported for this shape) */
+int ldiff_op_conv_stats_blocks(const ldiff_conv_args*);
+/* finalize producer-fused partial sums into per-(b,channel) scale/shift; part2 (second concat source) may be NULL */
+int ldiff_op_gn_finalize(const void* part1, int R1, int C1, const void* part2, int R2, int C2, int B, int HW, int groups, float eps,
+                         const void* gamma, const void* beta, void* scale, void* shift, void* stream);
 int ldiff_op_attention(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, void* o, int ldo, int B, int heads,
                        int Lq, int Lk, int d, int64_t q_bstride, int64_t kv_bstride, int64_t o_bstride, float scale, void* stream);
 int ldiff_op_gn_stats(const void* x, int C1, const void* x2, int C2, int B, int HW, int groups, float eps, const void* gamma,

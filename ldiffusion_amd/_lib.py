@@ -34,7 +34,7 @@ class ConvArgs(C.Structure):
                 ("w", C.c_void_p), ("N", C.c_int), ("Nrows", C.c_int),
                 ("gn_scale", C.c_void_p), ("gn_shift", C.c_void_p), ("silu_in", C.c_int),
                 ("bias", C.c_void_p), ("temb", C.c_void_p), ("ld_temb", C.c_int),
-                ("res", C.c_void_p), ("ld_res", C.c_int), ("y", C.c_void_p), ("ldy", C.c_int), ("out_f32", C.c_int)]
+                ("res", C.c_void_p), ("ld_res", C.c_int), ("y", C.c_void_p), ("ldy", C.c_int), ("out_f32", C.c_int), ("stats", C.c_void_p)]
 
 
 # name -> (restype, argtypes); every symbol include/ldiff.h declares
@@ -68,6 +68,8 @@ SIGNATURES = {
     "ldiff_plms_timesteps": (I, [I, C.POINTER(I64), I]),
     "ldiff_pipeline_destroy": (None, [P]),
     "ldiff_op_conv": (I, [C.POINTER(ConvArgs), P]),
+    "ldiff_op_conv_stats_blocks": (I, [C.POINTER(ConvArgs)]),
+    "ldiff_op_gn_finalize": (I, [P, I, I, P, I, I, I, I, I, F, P, P, P, P, P]),
     "ldiff_op_attention": (I, [P, I, P, I, P, I, P, I, I, I, I, I, I, I64, I64, I64, F, P]),
     "ldiff_op_gn_stats": (I, [P, I, P, I, I, I, I, F, P, P, P, P, P]),
     "ldiff_op_layernorm": (I, [P, P, I, I, P, P, F, P]),

@@ -287,10 +287,8 @@ void ldiff_pipeline_destroy(ldiff_pipeline* p) {
 }
 
 // ---- single-kernel entry points ----
-int ldiff_op_conv(const ldiff_conv_args* a, void* stream) {
-  API_BEGIN
+static void conv_args_to_params(const ldiff_conv_args* a, ConvParams& p) {
   LDIFF_CHECK(a && a->x && a->w && a->y, LDIFF_ERR_INVALID, "op_conv: null argument");
-  ConvParams p;
   memset(&p, 0, sizeof(p));
   p.x = (const f16*)a->x; p.x2 = (const f16*)a->x2; p.C1 = a->C1; p.C2 = a->C2;
   p.B = a->B; p.Hin = a->Hin; p.Win = a->Win; p.Hout = a->Hout; p.Wout = a->Wout;
@@ -303,7 +301,30 @@ int ldiff_op_conv(const ldiff_conv_args* a, void* stream) {
   p.res = (const f16*)a->res; p.ld_res = a->ld_res;
   p.y = a->y; p.ldy = a->ldy; p.out_f32 = a->out_f32;
   p.M = a->B * a->Hout * a->Wout;
+  p.stats = (float*)a->stats;
+}
+int ldiff_op_conv(const ldiff_conv_args* a, void* stream) {
+  API_BEGIN
+  ConvParams p;
+  conv_args_to_params(a, p);
+  p.stats_R = p.stats ? conv_stats_blocks_per_image(p) : 0;
+  LDIFF_CHECK(!p.stats || p.stats_R > 0, LDIFF_ERR_INVALID, "op_conv: fused statistics are not supported for this shape");
   launch_igemm(p, (hipStream_t)stream);
+  API_END
+}
+int ldiff_op_conv_stats_blocks(const ldiff_conv_args* a) {
+  try {
+    ConvParams p;
+    conv_args_to_params(a, p);
+    return conv_stats_blocks_per_image(p);
+  } catch (const LdiffError& e) { return e.code; }
+}
+int ldiff_op_gn_finalize(const void* part1, int R1, int C1, const void* part2, int R2, int C2, int B, int HW, int groups, float eps,
+                         const void* gamma, const void* beta, void* scale, void* shift, void* stream) {
+  API_BEGIN
+  LDIFF_CHECK(part1 && gamma && beta && scale && shift && B >= 1 && HW >= 1 && groups >= 1, LDIFF_ERR_INVALID, "op_gn_finalize: bad arguments");
+  launch_gn_finalize((const float*)part1, R1, C1, (const float*)part2, R2, C2, B, HW, groups, eps, (const float*)gamma, (const float*)beta,
+                     (float*)scale, (float*)shift, (hipStream_t)stream);
   API_END
 }
 int ldiff_op_attention(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, void* o, int ldo, int B, int heads, int Lq,

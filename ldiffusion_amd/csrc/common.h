@@ -62,10 +62,14 @@ struct ConvParams {
   int ldy;
   int out_f32;
   int M;                  // B*Hout*Wout
+  float* stats;           // optional fused GroupNorm partial statistics of the output (see below)
+  int stats_R;            // row blocks per image of `stats`
 };
 void launch_igemm(const ConvParams& p, hipStream_t s);   // dispatches to the halo-tile 3x3 kernel when eligible
 bool conv3x3_eligible(const ConvParams& p);
 void launch_conv3x3(const ConvParams& p, hipStream_t s);       // kernels_conv3x3.hip
+bool gemm_dma_eligible(const ConvParams& p);
+void launch_gemm_dma(const ConvParams& p, hipStream_t s);      // kernels_gemm.hip
 
 // ---- attention (kernels_attn.hip) ------------------------------------------------------------
 // O[b, q, h*d + :] = softmax(Q K^T / sqrt(d)) V   per (b, head).   All fp16, row strides in elements.
@@ -136,3 +140,51 @@ struct ProfScope {
   ProfScope(const char* name, double flops, double bytes, hipStream_t st) : s(st), on(prof_on()) { if (on) prof_begin(name, flops, bytes, s); }
   ~ProfScope() { if (on) prof_end(s); }
 };
+
+// ---- GroupNorm statistics fused into the producing kernel's epilogue ------------------------------------------
+// ConvParams::stats (optional): per row-block partial sums of the fp16-rounded outputs, CHANNEL-major so that the
+// finalize kernel reads each (image, group) as one contiguous run:
+//     stats[((b * N + n) * R + r) * 2 + {0,1}] = {sum, sum of squares} of channel n over row block r of image b
+// Row blocks never straddle two images (R = ConvParams::stats_R blocks per image):
+//   conv3x3   : r = (ty*tiles_x + tx)*2 + wave_m      (half a pixel tile)
+//   gemm/igemm: r = (m % HW) / 32                      (32 consecutive rows; needs HW % 32 == 0)
+// conv_stats_blocks_per_image() returns R for a launch (0 = not supported -> the caller falls back to the separate
+// statistics pass of kernels_norm.hip).
+int conv_stats_blocks_per_image(const ConvParams& p);
+void launch_gn_finalize(const float* part1, int R1, int C1, const float* part2, int R2, int C2, int B, int HW, int groups, float eps,
+                        const float* gamma, const float* beta, float* scale, float* shift, hipStream_t s);
+
+#ifdef __HIPCC__
+// sum over the 16 lanes that share lane>>4 (one MFMA accumulator row group), by DPP (no LDS crossbar traffic)
+__device__ __forceinline__ float row16_sum(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));   // row_half_mirror
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));   // row_mirror
+  return v;
+}
+// Per-wave reduction used by the epilogues: `o[a][m][r]` = final (fp16-rounded) value of pixel (m, l15), channel
+// ncol + 16a + r; `ok[m]` = pixel valid.  Tiles m in [M0, M1) form one row block.  Lanes with l15 == 0 write 4 channels.
+// dst = &stats[(b*N*R + rblk) * 2]; channel n lives at dst + n*R*2.
+template <int MT, int NT>
+__device__ __forceinline__ void wave_stats_store(const f32x4 (&o)[NT][MT], const bool (&ok)[MT], int M0, int M1, float* dst, long long R, int N,
+                                                 int ncol, int l15) {
+#pragma unroll
+  for (int a = 0; a < NT; ++a) {
+    float s[4] = {0.f, 0.f, 0.f, 0.f}, q[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      if (m < M0 || m >= M1 || !ok[m]) continue;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { const float v = o[a][m][r]; s[r] += v; q[r] += v * v; }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { s[r] = row16_sum(s[r]); q[r] = row16_sum(q[r]); }
+    const int n = ncol + a * 16;
+    if (l15 == 0 && n < N) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) *reinterpret_cast<float2*>(dst + (long long)(n + r) * R * 2) = make_float2(s[r], q[r]);
+    }
+  }
+}
+#endif

@@ -225,8 +225,16 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const ConvParams p) {  
       } else {
         f16x4 o = {(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
         *reinterpret_cast<f16x4*>(reinterpret_cast<f16*>(p.y) + mrow[m] * p.ldy + n) = o;
+        if (p.stats) acc[a][m] = (f32x4){(float)o[0], (float)o[1], (float)o[2], (float)o[3]};   // what the consumer will read
       }
     }
+  }
+  if (p.stats) {   // fused GroupNorm statistics of this half tile (common.h)
+    bool ok[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) ok[m] = mrow[m] >= 0;
+    const long long R = p.stats_R, rblk = (ty * tiles_x + tx) * 2 + wave_m;
+    wave_stats_store<MT, NT>(acc, ok, 0, MT, p.stats + ((long long)b * p.N * R + rblk) * 2, R, p.N, ncol, l15);
   }
 }
 
@@ -257,6 +265,11 @@ void launch_c3_gn(const ConvParams& p, hipStream_t s) {
 
 }  // namespace
 
+int conv3x3_stats_blocks(const ConvParams& p) {
+  const int TW = p.Wout >= 16 ? 16 : 8;
+  return ((p.Hout + 7) / 8) * ((p.Wout + TW - 1) / TW) * 2;
+}
+
 bool conv3x3_eligible(const ConvParams& p) {
   const int Cin = p.C1 + p.C2;
   return p.ks == 3 && p.stride == 1 && p.pad_t == 1 && p.pad_l == 1 && Cin % 64 == 0 && p.C1 % 64 == 0 &&
@@ -265,14 +278,16 @@ bool conv3x3_eligible(const ConvParams& p) {
 
 void launch_conv3x3(const ConvParams& p, hipStream_t s) {
   const bool wide = p.Wout >= 16;
-  const int bn = (p.N % 128 != 0 && p.N % 160 == 0) ? 160 : (p.N <= 64 ? 64 : 128);
+  const int bn = (p.N % 128 != 0 && p.N % 160 == 0) ? 160 : (p.N <= 32 ? 32 : (p.N <= 64 ? 64 : 128));
   if (wide) {
     if (bn == 160) launch_c3_gn<8, 16, 160>(p, s);
     else if (bn == 64) launch_c3_gn<8, 16, 64>(p, s);
+    else if (bn == 32) launch_c3_gn<8, 16, 32>(p, s);
     else launch_c3_gn<8, 16, 128>(p, s);
   } else {
     if (bn == 160) launch_c3_gn<8, 8, 160>(p, s);
     else if (bn == 64) launch_c3_gn<8, 8, 64>(p, s);
+    else if (bn == 32) launch_c3_gn<8, 8, 32>(p, s);
     else launch_c3_gn<8, 8, 128>(p, s);
   }
 }

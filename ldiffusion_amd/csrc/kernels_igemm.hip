@@ -225,7 +225,18 @@ __global__ __launch_bounds__(256) void igemm_kernel(const ConvParams p) {
       } else {
         f16x4 o = {(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
         *reinterpret_cast<f16x4*>(reinterpret_cast<f16*>(p.y) + m * p.ldy + n) = o;
+        if (p.stats) acc[a][b] = (f32x4){(float)o[0], (float)o[1], (float)o[2], (float)o[3]};
       }
+    }
+  }
+  if (p.stats) {   // fused GroupNorm statistics per 32-row block (common.h)
+    bool ok[MT];
+#pragma unroll
+    for (int b = 0; b < MT; ++b) ok[b] = mrow[b] >= 0;
+#pragma unroll
+    for (int sb = 0; sb < MT / 2; ++sb) {
+      const long long blk = (m0 + wave_m * (BM / 2)) / 32 + sb, R = p.stats_R;   // global 32-row block -> (image, block in image)
+      if (blk * 32 < p.M) wave_stats_store<MT, NT>(acc, ok, 2 * sb, 2 * sb + 2, p.stats + ((blk / R) * p.N * R + blk % R) * 2, R, p.N, ncol, l15);
     }
   }
 }
@@ -258,6 +269,15 @@ static void launch_bmn(const ConvParams& p, bool fast, hipStream_t s) {
   else      { if (gn) launch_cfg<BM, BN, false, true>(p, s); else launch_cfg<BM, BN, false, false>(p, s); }
 }
 
+int conv3x3_stats_blocks(const ConvParams& p);
+
+int conv_stats_blocks_per_image(const ConvParams& p) {
+  if (p.out_f32) return 0;
+  if (conv3x3_eligible(p)) return conv3x3_stats_blocks(p);
+  const int hw = p.Hout * p.Wout;
+  return hw % 32 == 0 ? hw / 32 : 0;
+}
+
 void launch_igemm(const ConvParams& p, hipStream_t s) {
   const int Cin = p.C1 + p.C2;
   LDIFF_CHECK(p.C1 % 8 == 0 && p.C2 % 8 == 0 && Cin > 0, LDIFF_ERR_INVALID, "igemm: channel counts must be multiples of 8 (C1=%d C2=%d)", p.C1, p.C2);
@@ -268,6 +288,7 @@ void launch_igemm(const ConvParams& p, hipStream_t s) {
   LDIFF_CHECK(!p.temb || p.ld_temb % 4 == 0, LDIFF_ERR_INVALID, "igemm: ld_temb must be a multiple of 4");
   if (p.M <= 0) return;
   if (conv3x3_eligible(p)) { launch_conv3x3(p, s); return; }
+  if (gemm_dma_eligible(p)) { launch_gemm_dma(p, s); return; }
   const bool fast = (Cin % BK == 0) && (p.C1 % BK == 0);
   // Tile choice: largest tile that still yields >= ~2 workgroups per CU worth of tiles; narrow N gets BN=64.
   auto tiles = [&](int bm, int bn) { return (long long)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn); };

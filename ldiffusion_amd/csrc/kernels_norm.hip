@@ -101,6 +101,49 @@ __global__ __launch_bounds__(64) void gn_finalize_kernel(const float* __restrict
   }
 }
 
+// Finalize from producer-fused partials (common.h "GroupNorm statistics fused into the producing kernel's epilogue"):
+// channels [0,C1) come from part1 ([B][C1][R1][2]), channels [C1,C1+C2) from part2 ([B][C2][R2][2]); each channel's R
+// partial sums are contiguous, so a (image, group) block streams Cg contiguous runs.
+__global__ __launch_bounds__(256) void gn_finalize2_kernel(const float* __restrict__ p1, int R1, int C1, const float* __restrict__ p2, int R2, int C2,
+                                                           int groups, int HW, float eps, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, float* __restrict__ scale, float* __restrict__ shift) {
+  const int grp = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  const int C = C1 + C2, Cg = C / groups, c0 = grp * Cg;
+  double a = 0.0, q = 0.0;
+  for (int cc = 0; cc < Cg; ++cc) {
+    const int c = c0 + cc;
+    const bool second = c >= C1;
+    const int R = second ? R2 : R1;
+    const float2* base = reinterpret_cast<const float2*>(second ? p2 + ((long long)b * C2 + (c - C1)) * R2 * 2 : p1 + ((long long)b * C1 + c) * R1 * 2);
+    for (int r = tid; r < R; r += 256) { const float2 v = base[r]; a += (double)v.x; q += (double)v.y; }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o); q += __shfl_xor(q, o); }
+  __shared__ double red[2][4];
+  if ((tid & 63) == 0) { red[0][tid >> 6] = a; red[1][tid >> 6] = q; }
+  __syncthreads();
+  a = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+  q = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+  const double n = (double)HW * Cg;
+  const double mean = a / n;
+  double var = q / n - mean * mean;
+  if (var < 0.0) var = 0.0;
+  const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+  for (int c = c0 + tid; c < c0 + Cg; c += 256) {
+    const float gsc = gamma[c] * rstd;
+    scale[(long long)b * C + c] = gsc;
+    shift[(long long)b * C + c] = beta[c] - (float)mean * gsc;
+  }
+}
+
+void launch_gn_finalize(const float* part1, int R1, int C1, const float* part2, int R2, int C2, int B, int HW, int groups, float eps,
+                        const float* gamma, const float* beta, float* scale, float* shift, hipStream_t s) {
+  LDIFF_CHECK((C1 + C2) % groups == 0 && part1 && R1 > 0 && (C2 == 0 || (part2 && R2 > 0)), LDIFF_ERR_INVALID, "gn_finalize: bad arguments");
+  ProfScope prof("gn_finalize", 0.0, 8.0 * B * ((double)R1 * C1 + (double)R2 * C2), s);
+  hipLaunchKernelGGL(gn_finalize2_kernel, dim3(groups, B), dim3(256), 0, s, part1, R1, C1, part2, R2, C2, groups, HW, eps, gamma, beta, scale, shift);
+  HIP_CHECK(hipGetLastError());
+}
+
 void launch_gn_stats(const f16* x, int C1, const f16* x2, int C2, int B, int HW, int groups, float eps, const float* gamma,
                      const float* beta, float* partial, size_t partial_bytes, float* scale, float* shift, hipStream_t s) {
   const int C = C1 + C2;

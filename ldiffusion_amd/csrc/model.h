@@ -14,6 +14,8 @@
 struct Act {  // NHWC fp16 activation (tokens [M, C] are B=1,H=1,W=M or keep the image shape)
   f16* p = nullptr;
   int B = 0, H = 0, W = 0, C = 0;
+  float* st = nullptr;   // producer-fused GroupNorm partial statistics [B][st_R][C][2] (nullptr: none)
+  int st_R = 0;
   long long rows() const { return (long long)B * H * W; }
   size_t bytes() const { return (size_t)rows() * C * sizeof(f16); }
 };
@@ -69,6 +71,7 @@ struct ConvOpts {
   void* out_f32 = nullptr; int ldy_f32 = 0;   // write fp32 [M, ldy] here instead of allocating an fp16 Act
   int N_override = 0;           // columns to store (multiple of 4), default = roundup4(w.N)
   int ldy = 0;                  // fp16 output channel stride (default N stored rounded up to 8)
+  bool want_stats = false;      // also emit GroupNorm partial statistics of the output (consumed by Exec::gn)
 };
 
 class Exec {

@@ -208,7 +208,9 @@ Act Exec::new_act(int B, int H, int W, int C) {
 }
 void Exec::release(Act& a) {
   if (a.p) arena.free(a.p);
+  if (a.st) arena.free(a.st);
   a.p = nullptr;
+  a.st = nullptr;
 }
 GNss Exec::gn(const Act& x, const Act* x2, const NormW& w, int groups, float eps) {
   const int C = x.C + (x2 ? x2->C : 0);
@@ -216,6 +218,11 @@ GNss Exec::gn(const Act& x, const Act* x2, const NormW& w, int groups, float eps
   GNss g;
   g.scale = tmp<float>((size_t)x.B * C);
   g.shift = tmp<float>((size_t)x.B * C);
+  if (x.st && (!x2 || x2->st)) {   // statistics were accumulated by the producing kernels: finalize only, no extra read
+    launch_gn_finalize(x.st, x.st_R, x.C, x2 ? x2->st : nullptr, x2 ? x2->st_R : 0, x2 ? x2->C : 0, x.B, x.H * x.W, groups, eps, w.g, w.b,
+                       g.scale, g.shift, s);
+    return g;
+  }
   LDIFF_CHECK(gn_partial_bytes(x.B, x.H * x.W, C) <= gn_partial_cap, LDIFF_ERR_RUNTIME, "group norm workspace too small");
   launch_gn_stats(x.p, x.C, x2 ? x2->p : nullptr, x2 ? x2->C : 0, x.B, x.H * x.W, groups, eps, w.g, w.b, gn_partial, gn_partial_cap, g.scale,
                   g.shift, s);
@@ -257,6 +264,15 @@ Act Exec::conv(const MatW& w, const Act& x, const Act* x2, const ConvOpts& o) {
     y = new_act(x.B, p.Hout, p.Wout, C);
     if (C > p.N) HIP_CHECK(hipMemsetAsync(y.p, 0, y.bytes(), s));  // zero the pad columns
     p.y = y.p; p.ldy = C;
+    if (o.want_stats && C == p.N && p.N == w.N) {
+      const int R = conv_stats_blocks_per_image(p);
+      if (R > 0) {
+        y.st = tmp<float>((size_t)x.B * R * p.N * 2);
+        y.st_R = R;
+        p.stats = y.st;
+        p.stats_R = R;
+      }
+    }
   }
   launch_igemm(p, s);
   return y;
@@ -433,7 +449,7 @@ Act ldiff_unet::resnet(const ResnetW& r, const Act& x, const Act* skip, const fl
   const int G = cfg.norm_num_groups;
   GNss g1 = ex.gn(x, skip, r.n1, G, cfg.norm_eps);
   ConvOpts o1;
-  o1.gn = &g1; o1.silu = 1; o1.temb = temb_all + r.temb_off; o1.ld_temb = temb_total;
+  o1.gn = &g1; o1.silu = 1; o1.temb = temb_all + r.temb_off; o1.ld_temb = temb_total; o1.want_stats = true;
   Act h = ex.conv(r.c1, x, skip, o1);
   ex.release(g1);
   GNss g2 = ex.gn(h, nullptr, r.n2, G, cfg.norm_eps);
@@ -442,7 +458,7 @@ Act ldiff_unet::resnet(const ResnetW& r, const Act& x, const Act* skip, const fl
   if (r.has_sc) { sc = ex.conv(r.sc, x, skip, ConvOpts()); resp = &sc; }
   else LDIFF_CHECK(skip == nullptr, LDIFF_ERR_RUNTIME, "resnet: concat input without shortcut conv");
   ConvOpts o2;
-  o2.gn = &g2; o2.silu = 1; o2.res = resp;
+  o2.gn = &g2; o2.silu = 1; o2.res = resp; o2.want_stats = true;
   Act out = ex.conv(r.c2, h, nullptr, o2);
   ex.release(g2);
   ex.release(h);
@@ -501,7 +517,7 @@ Act ldiff_unet::transformer(const TransformerW& t, const Act& x) {
   ex.release(gg);
   ex.release(h3);
   ConvOpts oo;
-  oo.res = &x;
+  oo.res = &x; oo.want_stats = true;
   Act out = ex.conv(t.proj_out, h4, nullptr, oo);
   ex.release(h4);
   return out;
@@ -540,7 +556,9 @@ void ldiff_unet::forward(const float* x, int B, int h, int w, float tval, float*
 
   Act x16 = ex.new_act(B, h, w, 8);
   launch_nchw_f32_to_nhwc_f16(x, x16.p, B, cfg.in_channels, h, w, 8, s);
-  Act cur = ex.conv(conv_in, x16, nullptr, ConvOpts());
+  ConvOpts oci;
+  oci.want_stats = true;
+  Act cur = ex.conv(conv_in, x16, nullptr, oci);
   ex.release(x16);
 
   std::vector<Act> skips{cur};
@@ -559,7 +577,7 @@ void ldiff_unet::forward(const float* x, int B, int h, int w, float tval, float*
     }
     if (has_down[i]) {
       ConvOpts o;
-      o.stride = 2;
+      o.stride = 2; o.want_stats = true;
       advance(ex.conv(down_sample[i], cur, nullptr, o));
       skips.push_back(cur);
       cur_is_skip = true;
@@ -578,7 +596,7 @@ void ldiff_unet::forward(const float* x, int B, int h, int w, float tval, float*
     }
     if (has_up[i]) {
       ConvOpts o;
-      o.ups = 1;
+      o.ups = 1; o.want_stats = true;
       advance(ex.conv(up_sample[i], cur, nullptr, o));
     }
   }
@@ -665,7 +683,7 @@ Act ldiff_vae::resnet(const ResnetW& r, const Act& x) {
   const int G = cfg.norm_num_groups;
   GNss g1 = ex.gn(x, nullptr, r.n1, G, 1e-6f);
   ConvOpts o1;
-  o1.gn = &g1; o1.silu = 1;
+  o1.gn = &g1; o1.silu = 1; o1.want_stats = true;
   Act h = ex.conv(r.c1, x, nullptr, o1);
   ex.release(g1);
   GNss g2 = ex.gn(h, nullptr, r.n2, G, 1e-6f);
@@ -673,7 +691,7 @@ Act ldiff_vae::resnet(const ResnetW& r, const Act& x) {
   const Act* resp = &x;
   if (r.has_sc) { sc = ex.conv(r.sc, x, nullptr, ConvOpts()); resp = &sc; }
   ConvOpts o2;
-  o2.gn = &g2; o2.silu = 1; o2.res = resp;
+  o2.gn = &g2; o2.silu = 1; o2.res = resp; o2.want_stats = true;
   Act out = ex.conv(r.c2, h, nullptr, o2);
   ex.release(g2);
   ex.release(h);
@@ -697,7 +715,7 @@ Act ldiff_vae::mid_attention(const VaeAttnW& a, const Act& x) {
   launch_attention(ap, ex.s);
   ex.release(qkv);
   ConvOpts oo;
-  oo.res = &x;
+  oo.res = &x; oo.want_stats = true;
   Act out = ex.conv(a.out, o, nullptr, oo);
   ex.release(o);
   return out;
@@ -719,14 +737,16 @@ void ldiff_vae::encode(const float* x, int B, int H, int W, float* moments, hipS
 
   Act x16 = ex.new_act(B, H, W, 8);
   launch_nchw_f32_to_nhwc_f16(x, x16.p, B, cfg.in_channels, H, W, 8, s);
-  Act cur = ex.conv(e_conv_in, x16, nullptr, ConvOpts());
+  ConvOpts oci;
+  oci.want_stats = true;
+  Act cur = ex.conv(e_conv_in, x16, nullptr, oci);
   ex.release(x16);
   auto advance = [&](Act nxt) { ex.release(cur); cur = nxt; };
   for (int i = 0; i < nb; ++i) {
     for (auto& r : e_res[i]) advance(resnet(r, cur));
     if (i != nb - 1) {
       ConvOpts o;  // Downsample2D(padding=0): F.pad(x,(0,1,0,1)) then stride-2 conv without padding
-      o.stride = 2; o.pad_t = 0; o.pad_l = 0; o.Hout = cur.H / 2; o.Wout = cur.W / 2;
+      o.stride = 2; o.pad_t = 0; o.pad_l = 0; o.Hout = cur.H / 2; o.Wout = cur.W / 2; o.want_stats = true;
       advance(ex.conv(e_down[i], cur, nullptr, o));
     }
   }
@@ -773,7 +793,9 @@ void ldiff_vae::decode(const float* z, int B, int h, int w, float z_scale, float
   opq.N_override = 8; opq.ldy = 8;   // rows >= latent_channels are zero => pad channels come out zero
   Act pq = ex.conv(post_quant, z16, nullptr, opq);
   ex.release(z16);
-  Act cur = ex.conv(d_conv_in, pq, nullptr, ConvOpts());
+  ConvOpts odi;
+  odi.want_stats = true;
+  Act cur = ex.conv(d_conv_in, pq, nullptr, odi);
   ex.release(pq);
   auto advance = [&](Act nxt) { ex.release(cur); cur = nxt; };
   advance(resnet(d_mid[0], cur));
@@ -783,7 +805,7 @@ void ldiff_vae::decode(const float* z, int B, int h, int w, float z_scale, float
     for (auto& r : d_res[i]) advance(resnet(r, cur));
     if (i != nb - 1) {
       ConvOpts o;
-      o.ups = 1;
+      o.ups = 1; o.want_stats = true;
       advance(ex.conv(d_up[i], cur, nullptr, o));
     }
   }

@@ -308,3 +308,47 @@ def test_layout_nchw_to_nhwc_pads_channels(lib):
     torch.cuda.synchronize()
     assert torch.equal(y[..., :3].cpu(), x.permute(0, 2, 3, 1).to(torch.float16))
     assert (y[..., 3:] == 0).all()
+
+
+FUSED_STATS_CASES = {
+    # name: (B, C1, H, W, Cout, ks, stride)   -- producer conv emits GroupNorm partial sums in its epilogue
+    "conv3x3_halo_128": (2, 64, 32, 32, 128, 3, 1),
+    "conv3x3_halo_partial_tile_320": (2, 64, 20, 24, 320, 3, 1),
+    "conv3x3_small_image_8x8": (3, 128, 8, 8, 128, 3, 1),
+    "gemm_dma_1x1": (2, 128, 16, 16, 256, 1, 1),
+    "igemm_stride2": (2, 64, 32, 32, 64, 3, 2),
+}
+
+
+@pytest.mark.parametrize("name", list(FUSED_STATS_CASES))
+def test_fused_groupnorm_statistics(lib, name):
+    """Statistics accumulated in the producer's epilogue + finalize == F.group_norm of the (fp16) output it wrote."""
+    B, C1, H, W, Cout, ks, stride = FUSED_STATS_CASES[name]
+    g = torch.Generator().manual_seed(zlib.crc32(name.encode()) % 1000)
+    x = torch.randn((B, C1, H, W), generator=g)
+    w = torch.randn((Cout, C1, ks, ks), generator=g) / math.sqrt(C1 * ks * ks)
+    bias = torch.randn(Cout, generator=g) * 0.5
+    Ho, Wo = (H + 2 * (ks // 2) - ks) // stride + 1, (W + 2 * (ks // 2) - ks) // stride + 1
+    wd = w.permute(0, 2, 3, 1).reshape(Cout, -1).to(torch.float16).contiguous().to(DEV)
+    xd, bd = nhwc16(x), bias.to(DEV)
+    y = torch.empty((B, Ho, Wo, Cout), dtype=torch.float16, device=DEV)
+    a_ = _lib.ConvArgs()
+    a_.x, a_.C1, a_.B, a_.Hin, a_.Win, a_.Hout, a_.Wout = xd.data_ptr(), C1, B, H, W, Ho, Wo
+    a_.ks, a_.stride, a_.pad_t, a_.pad_l = ks, stride, ks // 2, ks // 2
+    a_.w, a_.N, a_.Nrows, a_.bias, a_.y, a_.ldy = wd.data_ptr(), Cout, Cout, bd.data_ptr(), y.data_ptr(), Cout
+    R = lib.ldiff_op_conv_stats_blocks(C.byref(a_))
+    assert R > 0
+    st = torch.full((B, Cout, R, 2), float("nan"), device=DEV)
+    a_.stats = st.data_ptr()
+    _lib.check(lib.ldiff_op_conv(C.byref(a_), sp()))
+    gamma, beta = 1 + 0.1 * torch.randn(Cout, generator=g), 0.1 * torch.randn(Cout, generator=g)
+    scale, shift = torch.empty((B, Cout), device=DEV), torch.empty((B, Cout), device=DEV)
+    gd, btd = gamma.to(DEV), beta.to(DEV)
+    _lib.check(lib.ldiff_op_gn_finalize(st.data_ptr(), R, Cout, None, 0, 0, B, Ho * Wo, 32, 1e-5, gd.data_ptr(), btd.data_ptr(),
+                                        scale.data_ptr(), shift.data_ptr(), sp()))
+    torch.cuda.synchronize()
+    assert torch.isfinite(st).all()
+    yr = y.float().cpu().permute(0, 3, 1, 2)
+    got = yr * scale.cpu()[:, :, None, None] + shift.cpu()[:, :, None, None]
+    ref = F.group_norm(yr, 32, gamma, beta, 1e-5)
+    assert (got - ref).abs().max() <= 2e-4 * max(1.0, ref.abs().max())

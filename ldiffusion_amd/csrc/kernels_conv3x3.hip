@@ -19,7 +19,9 @@
 namespace {
 
 __device__ __forceinline__ int swz8(int row, int chunk) { return chunk ^ ((row >> 1) & 7); }
-__device__ __forceinline__ float silu_f(float v) { return v * __frcp_rn(1.0f + __expf(-v)); }
+// x * sigmoid(x) with the two hardware transcendentals only (v_exp_f32, v_rcp_f32: 1 ulp); __frcp_rn would expand to a
+// 11-instruction IEEE division per element
+__device__ __forceinline__ float silu_f(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v * -1.4426950408889634f)); }
 
 typedef __attribute__((address_space(1))) const void gptr_t;
 typedef __attribute__((address_space(3))) void lptr_t;
@@ -87,6 +89,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const ConvParams p) {  
       gt0 = *reinterpret_cast<const float4*>(sh); gt1 = *reinterpret_cast<const float4*>(sh + 4);
     }
   };
+  const bool silu = p.silu_in != 0;
   auto store_halo = [&](int buf) {
     float sv[8] = {gs0.x, gs0.y, gs0.z, gs0.w, gs1.x, gs1.y, gs1.z, gs1.w};
     float tv[8] = {gt0.x, gt0.y, gt0.z, gt0.w, gt1.x, gt1.y, gt1.z, gt1.w};
@@ -100,7 +103,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const ConvParams p) {  
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           float f = (float)h[j] * sv[j] + tv[j];
-          if (p.silu_in) f = silu_f(f);
+          const float fs = silu_f(f);
+          f = silu ? fs : f;   // select, not a branch per element
           o[j] = (f16)f;
         }
         v = __builtin_bit_cast(uint4, o);

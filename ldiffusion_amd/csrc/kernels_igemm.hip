@@ -22,7 +22,9 @@
 
 __device__ __forceinline__ int swz(int row, int chunk) { return chunk ^ ((row >> 1) & 7); }
 
-__device__ __forceinline__ float silu_f(float v) { return v * __frcp_rn(1.0f + __expf(-v)); }
+// x * sigmoid(x) with the two hardware transcendentals only (v_exp_f32, v_rcp_f32: 1 ulp); __frcp_rn would expand to a
+// 11-instruction IEEE division per element
+__device__ __forceinline__ float silu_f(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v * -1.4426950408889634f)); }
 
 __device__ __forceinline__ uint4 gn_apply8(uint4 raw, const float* __restrict__ sc, const float* __restrict__ sh, int silu) {
   f16x8 h = __builtin_bit_cast(f16x8, raw);
@@ -34,7 +36,8 @@ __device__ __forceinline__ uint4 gn_apply8(uint4 raw, const float* __restrict__ 
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     float v = (float)h[j] * sv[j] + tv[j];
-    if (silu) v = silu_f(v);
+    const float vs = silu_f(v);
+    v = silu ? vs : v;   // select, not a branch per element
     o[j] = (f16)v;
   }
   return __builtin_bit_cast(uint4, o);

@@ -16,6 +16,8 @@ DEV = "cuda:0"
 # name: (B, C1, C2, Hin, Win, Cout, ks, stride, ups, gn)
 SHAPES = {
     "vae512_128_128_gn": (8, 128, 0, 512, 512, 128, 3, 1, 0, 1),
+    "vae512_128_128_nogn": (8, 128, 0, 512, 512, 128, 3, 1, 0, 0),
+    "vae256_256_256_nogn": (8, 256, 0, 256, 256, 256, 3, 1, 0, 0),
     "vae512_256_128_gn": (8, 256, 0, 512, 512, 128, 3, 1, 0, 1),
     "vae512_up_256_256": (8, 256, 0, 256, 256, 256, 3, 1, 1, 0),
     "vae256_256_256_gn": (8, 256, 0, 256, 256, 256, 3, 1, 0, 1),
@@ -88,7 +90,11 @@ def main():
         if gn:
             a.gn_scale, a.gn_shift, a.silu_in = sc.data_ptr(), sh.data_ptr(), 1
         a.y, a.ldy = y.data_ptr(), Nst
-        a.ld_temb = int(os.environ.get('LDIFF_EXP_LDTEMB', '0'))
+        if os.environ.get('LDIFF_BENCH_STATS'):
+            R = lib.ldiff_op_conv_stats_blocks(C.byref(a))
+            if R > 0:
+                st = torch.empty((B, Nst, R, 2), device=DEV)
+                a.stats = st.data_ptr()
         ms = time_it(lambda: _lib.check(lib.ldiff_op_conv(C.byref(a), sp)), iters)
         fl = 2.0 * B * Ho * Wo * Cout * ks * ks * Cin
         print(f"{name:28s} {ms*1e3:9.1f} us  {fl/ms/1e9:8.1f} TFLOP/s  ({fl/1e9:.1f} GFLOP)", flush=True)

@@ -309,6 +309,19 @@ int ldiff_op_conv(const ldiff_conv_args* a, void* stream) {
   conv_args_to_params(a, p);
   p.stats_R = p.stats ? conv_stats_blocks_per_image(p) : 0;
   LDIFF_CHECK(!p.stats || p.stats_R > 0, LDIFF_ERR_INVALID, "op_conv: fused statistics are not supported for this shape");
+  // same split-K plan the executors use; this test/bench entry point owns a persistent scratch workspace for it
+  static float* ws = nullptr;
+  static size_t ws_cap = 0;
+  if (!p.stats && !p.out_f32 && conv3x3_eligible(p)) p.splitk = conv3x3_splitk_plan(p);
+  if (p.splitk > 1) {
+    const size_t need = (size_t)p.splitk * p.M * p.N * sizeof(float);
+    if (need > ws_cap) {
+      if (ws) { HIP_CHECK(hipDeviceSynchronize()); HIP_CHECK(hipFree(ws)); ws = nullptr; ws_cap = 0; }
+      HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&ws), need));
+      ws_cap = need;
+    }
+    p.splitk_ws = ws;
+  }
   launch_igemm(p, (hipStream_t)stream);
   API_END
 }

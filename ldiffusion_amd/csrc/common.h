@@ -64,9 +64,12 @@ struct ConvParams {
   int M;                  // B*Hout*Wout
   float* stats;           // optional fused GroupNorm partial statistics of the output (see below)
   int stats_R;            // row blocks per image of `stats`
+  int splitk;             // conv3x3 only: >1 => K (input-channel slabs) split over blockIdx.y, fp32 partials to splitk_ws
+  float* splitk_ws;       // [splitk][M][N] fp32 workspace (then reduced + epilogue by splitk_reduce)
 };
 void launch_igemm(const ConvParams& p, hipStream_t s);   // dispatches to the halo-tile 3x3 kernel when eligible
 bool conv3x3_eligible(const ConvParams& p);
+int conv3x3_splitk_plan(const ConvParams& p);                  // 1 = no split; >1 needs splitk_ws of splitk*M*N floats
 void launch_conv3x3(const ConvParams& p, hipStream_t s);       // kernels_conv3x3.hip
 bool gemm_dma_eligible(const ConvParams& p);
 void launch_gemm_dma(const ConvParams& p, hipStream_t s);      // kernels_gemm.hip

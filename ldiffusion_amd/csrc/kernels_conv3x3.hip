@@ -141,15 +141,17 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const ConvParams p) {  
     hp0[m] = (ml / TW) * HWD + (ml % TW);
   }
 
-  const int nslab = Cin / 64;
-  load_halo(0);
+  // split-K (small grids, huge K: the 8x8 / 16x16 UNet levels): blockIdx.y owns a contiguous range of input slabs
+  const int nslab_all = Cin / 64, S = p.splitk > 1 ? p.splitk : 1, ksplit = blockIdx.y;
+  const int c_begin = ksplit * nslab_all / S, nslab = (ksplit + 1) * nslab_all / S;
+  load_halo(c_begin);
   store_halo(0);
-  issue_w(0, 0, 0);
+  issue_w(c_begin, 0, 0);
   __syncthreads();
 
   int step = 0;
-  for (int c = 0; c < nslab; ++c) {
-    const uint4* cA = sA + (c & 1) * HP * 8;
+  for (int c = c_begin; c < nslab; ++c) {
+    const uint4* cA = sA + ((c - c_begin) & 1) * HP * 8;
 #pragma unroll 1
     for (int tap = 0; tap < 9; ++tap, ++step) {
       const bool more = !(c == nslab - 1 && tap == 8);
@@ -178,11 +180,27 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const ConvParams p) {  
           for (int m = 0; m < MT; ++m)
             acc[a][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[a], xf[m], acc[a][m], 0, 0, 0);
       }
-      if (stage) store_halo((c + 1) & 1);
+      if (stage) store_halo((c + 1 - c_begin) & 1);
       __syncthreads();   // also drains the weight DMA issued at the top of this step (vmcnt(0) before s_barrier)
     }
   }
 
+  if (S > 1) {   // raw fp32 partial sums; bias / time embedding / residual are applied by splitk_reduce_kernel
+    const int ncol_s = n0 + wave_n * (BN / 2) + g * 4;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      const int ml = wave_m * (BM / 2) + m * 16 + l15;
+      const int oy = oy0 + ml / TW, ox = ox0 + ml % TW;
+      if (oy >= p.Hout || ox >= p.Wout) continue;
+      const long long mrow_s = ((long long)b * p.Hout + oy) * p.Wout + ox;
+#pragma unroll
+      for (int a = 0; a < NT; ++a) {
+        const int n = ncol_s + a * 16;
+        if (n < p.N) *reinterpret_cast<f32x4*>(p.splitk_ws + ((long long)ksplit * p.M + mrow_s) * p.N + n) = acc[a][m];
+      }
+    }
+    return;
+  }
   // ---- epilogue: lane holds y[pixel = column][n = 4g + r] ----
   // All global loads of the epilogue (bias, time embedding, residual) are issued back to back BEFORE any use; a
   // load -> wait -> store chain per 16x16 tile costs a full memory round trip per tile (16-48 us per workgroup).
@@ -242,6 +260,28 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const ConvParams p) {  
   }
 }
 
+// split-K reduction + epilogue: y[m, n..n+3] = sum_s ws[s][m][n..] + bias + temb + res
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const ConvParams p) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int n4 = p.N >> 2;
+  if (i >= (long long)p.M * n4) return;
+  const long long m = i / n4;
+  const int n = (int)(i - m * n4) * 4;
+  f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int s = 0; s < p.splitk; ++s) v += *reinterpret_cast<const f32x4*>(p.splitk_ws + ((long long)s * p.M + m) * p.N + n);
+  if (p.bias) { const float4 t = *reinterpret_cast<const float4*>(p.bias + n); v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w; }
+  if (p.temb) {
+    const float4 t = *reinterpret_cast<const float4*>(p.temb + (m / ((long long)p.Hout * p.Wout)) * p.ld_temb + n);
+    v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
+  }
+  if (p.res) {
+    const f16x4 r = *reinterpret_cast<const f16x4*>(p.res + m * p.ld_res + n);
+    v[0] += (float)r[0]; v[1] += (float)r[1]; v[2] += (float)r[2]; v[3] += (float)r[3];
+  }
+  if (p.out_f32) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.y) + m * p.ldy + n) = v;
+  else *reinterpret_cast<f16x4*>(reinterpret_cast<f16*>(p.y) + m * p.ldy + n) = (f16x4){(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
+}
+
 template <int TH, int TW, int BN, bool GN>
 void launch_c3(const ConvParams& p, hipStream_t s) {
   static bool attr_set = false;
@@ -258,8 +298,14 @@ void launch_c3(const ConvParams& p, hipStream_t s) {
   const double bytes = (double)p.B * p.Hin * p.Win * (p.C1 + p.C2) * 2.0 + (double)p.N * p.K * 2.0 + (double)p.M * p.N * (p.out_f32 ? 4.0 : 2.0) +
                        (p.res ? (double)p.M * p.N * 2.0 : 0.0);
   ProfScope prof(pname.c_str(), 2.0 * p.M * (double)p.N * p.K, bytes, s);
-  hipLaunchKernelGGL(kern, dim3(tiles * ntn), dim3(256), smem, s, p);
+  const int S = p.splitk > 1 ? p.splitk : 1;
+  hipLaunchKernelGGL(kern, dim3(tiles * ntn, S), dim3(256), smem, s, p);
   HIP_CHECK(hipGetLastError());
+  if (S > 1) {
+    const long long n = (long long)p.M * (p.N >> 2);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p);
+    HIP_CHECK(hipGetLastError());
+  }
 }
 
 template <int TH, int TW, int BN>
@@ -280,7 +326,20 @@ bool conv3x3_eligible(const ConvParams& p) {
          p.Hout == (p.Hin << p.ups) && p.Wout == (p.Win << p.ups);
 }
 
+int conv3x3_splitk_plan(const ConvParams& p) {
+  // few workgroups and a long K loop (UNet 8x8 / 16x16 levels, K = 9*1280..9*2560): split the slabs so the grid fills the chip
+  const int TW = p.Wout >= 16 ? 16 : 8;
+  const int bn = (p.N % 128 != 0 && p.N % 160 == 0) ? 160 : (p.N <= 32 ? 32 : (p.N <= 64 ? 64 : 128));
+  const int wgs = p.B * ((p.Hout + 7) / 8) * ((p.Wout + TW - 1) / TW) * ((p.N + bn - 1) / bn);
+  const int nslab = (p.C1 + p.C2) / 64;
+  int S = 512 / (wgs > 0 ? wgs : 1);
+  if (S > nslab / 4) S = nslab / 4;
+  if (S > 8) S = 8;
+  return S >= 2 ? S : 1;
+}
+
 void launch_conv3x3(const ConvParams& p, hipStream_t s) {
+  LDIFF_CHECK(p.splitk <= 1 || (p.splitk_ws && !p.stats), LDIFF_ERR_INVALID, "conv3x3: split-K needs a workspace and cannot emit fused statistics");
   const bool wide = p.Wout >= 16;
   const int bn = (p.N % 128 != 0 && p.N % 160 == 0) ? 160 : (p.N <= 32 ? 32 : (p.N <= 64 ? 64 : 128));
   if (wide) {

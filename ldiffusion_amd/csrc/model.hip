@@ -264,7 +264,8 @@ Act Exec::conv(const MatW& w, const Act& x, const Act* x2, const ConvOpts& o) {
     y = new_act(x.B, p.Hout, p.Wout, C);
     if (C > p.N) HIP_CHECK(hipMemsetAsync(y.p, 0, y.bytes(), s));  // zero the pad columns
     p.y = y.p; p.ldy = C;
-    if (o.want_stats && C == p.N && p.N == w.N) {
+    if (conv3x3_eligible(p)) p.splitk = conv3x3_splitk_plan(p);
+    if (o.want_stats && C == p.N && p.N == w.N && p.splitk <= 1) {
       const int R = conv_stats_blocks_per_image(p);
       if (R > 0) {
         y.st = tmp<float>((size_t)x.B * R * p.N * 2);
@@ -274,7 +275,10 @@ Act Exec::conv(const MatW& w, const Act& x, const Act* x2, const ConvOpts& o) {
       }
     }
   }
+  if (!o.out_f32 && p.splitk > 1) p.splitk_ws = tmp<float>((size_t)p.splitk * p.M * p.N);
+  else p.splitk = 0;
   launch_igemm(p, s);
+  if (p.splitk_ws) arena.free(p.splitk_ws);   // stream-ordered reuse: safe once the launches are enqueued
   return y;
 }
 Act Exec::layernorm(const Act& x, const NormW& w) {

@@ -128,6 +128,8 @@ CONV_CASES = {
     "3x3_cout3_f32": (1, 128, 0, 32, 32, 3, 3, 1, 0, False, True, False),
     "1x1_cin8_cout8": (2, 8, 0, 8, 8, 8, 1, 1, 0, False, False, False),
     "3x3_1x1_spatial": (3, 64, 0, 1, 1, 64, 3, 1, 0, False, False, False),
+    "3x3_splitk_8x8_1280": (2, 1280, 0, 8, 8, 256, 3, 1, 0, False, True, True),
+    "3x3_splitk_concat_16x16": (1, 640, 640, 16, 16, 128, 3, 1, 0, False, True, True),
 }
 
 

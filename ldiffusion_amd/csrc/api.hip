@@ -312,6 +312,19 @@ int ldiff_op_conv(const ldiff_conv_args* a, void* stream) {
   // same split-K plan the executors use; this test/bench entry point owns a persistent scratch workspace for it
   static float* ws = nullptr;
   static size_t ws_cap = 0;
+  static f16* wpar = nullptr;
+  static size_t wpar_cap = 0;
+  if (p.ups && conv3x3_eligible(p)) {   // same algebraic 2x-upsample folding the executors use
+    const size_t need = (size_t)4 * p.Nrows * 4 * (p.C1 + p.C2) * sizeof(f16);
+    if (need > wpar_cap) {
+      if (wpar) { HIP_CHECK(hipDeviceSynchronize()); HIP_CHECK(hipFree(wpar)); wpar = nullptr; wpar_cap = 0; }
+      HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&wpar), need));
+      wpar_cap = need;
+    }
+    launch_make_parity_weights(p.w, wpar, p.Nrows, p.C1 + p.C2, (hipStream_t)stream);
+    p.w_par = wpar;
+    if (p.stats) p.stats_R = conv_stats_blocks_per_image(p);
+  }
   if (!p.stats && !p.out_f32 && conv3x3_eligible(p)) p.splitk = conv3x3_splitk_plan(p);
   if (p.splitk > 1) {
     const size_t need = (size_t)p.splitk * p.M * p.N * sizeof(float);

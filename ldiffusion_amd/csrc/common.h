@@ -66,10 +66,14 @@ struct ConvParams {
   int stats_R;            // row blocks per image of `stats`
   int splitk;             // conv3x3 only: >1 => K (input-channel slabs) split over blockIdx.y, fp32 partials to splitk_ws
   float* splitk_ws;       // [splitk][M][N] fp32 workspace (then reduced + epilogue by splitk_reduce)
+  const f16* w_par;       // conv3x3 with ups=1 only: parity weights [4][Nrows][4*Cin] (see kernels_conv3x3.hip); nullptr => 9-tap gather
 };
 void launch_igemm(const ConvParams& p, hipStream_t s);   // dispatches to the halo-tile 3x3 kernel when eligible
 bool conv3x3_eligible(const ConvParams& p);
-int conv3x3_splitk_plan(const ConvParams& p);                  // 1 = no split; >1 needs splitk_ws of splitk*M*N floats
+int conv3x3_splitk_plan(const ConvParams& p);
+// nearest-2x upsample + conv3x3 == four 2x2 convs on the source grid (one per output parity) with pre-summed taps:
+// w_par[q][n][t][c] from w[n][ky][kx][c]  (2.25x fewer MACs than gathering 9 taps from the upsampled image)
+void launch_make_parity_weights(const f16* w, f16* w_par, int Nrows, int Cin, hipStream_t s);                  // 1 = no split; >1 needs splitk_ws of splitk*M*N floats
 void launch_conv3x3(const ConvParams& p, hipStream_t s);       // kernels_conv3x3.hip
 bool gemm_dma_eligible(const ConvParams& p);
 void launch_gemm_dma(const ConvParams& p, hipStream_t s);      // kernels_gemm.hip

@@ -41,7 +41,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const ConvParams p) {  
   const int wave_m = wave >> 1, wave_n = wave & 1;
   const int g = lane >> 4, l15 = lane & 15;
   const int Cin = p.C1 + p.C2;
-  const int tiles_x = (p.Wout + TW - 1) / TW, tiles_y = (p.Hout + TH - 1) / TH;
+  // Parity mode (nearest-2x upsample folded algebraically): tiles walk the SOURCE grid; workgroup parity q = (py,px)
+  // produces output pixels (2y+py, 2x+px) from the 2x2 source neighbourhood {y+py-1, y+py} x {x+px-1, x+px} with the
+  // 3x3 taps that alias onto the same source pixel pre-summed (w_par).  4 taps per slab instead of 9.
+  const bool par = p.w_par != nullptr;
+  const int NTAPS = par ? 4 : 9;
+  const int q_par = par ? blockIdx.z : 0, py = q_par >> 1, px = q_par & 1;
+  const int Ht = par ? p.Hin : p.Hout, Wt = par ? p.Win : p.Wout;   // tile-space extent
+  const int tiles_x = (Wt + TW - 1) / TW, tiles_y = (Ht + TH - 1) / TH;
   const int ntn = (p.N + BN - 1) / BN;
 
   // XCD-aware order: blocks sharing an XCD (blockIdx % 8) walk consecutive tiles -> the n-tiles of one pixel tile
@@ -55,7 +62,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const ConvParams p) {  
   const int ty = tm % tiles_y;
   const int b = tm / tiles_y;
   const int n0 = tile_n * BN, oy0 = ty * TH, ox0 = tx * TW;
-  const int He = p.Hin << p.ups, We = p.Win << p.ups;
+  const int sh = par ? 0 : p.ups;   // halo coordinates -> source pixel shift
+  const int He = p.Hin << sh, We = p.Win << sh;
 
   // ---- halo staging: thread owns chunk column kc of halo pixels hp = tid/8 + 32*i ----
   const int kc = tid & 7;
@@ -67,7 +75,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const ConvParams p) {  
     if (hp < HP) {
       const int hy = hp / HWD, hx = hp - hy * HWD;
       const int iy = oy0 + hy - 1, ix = ox0 + hx - 1;
-      if (iy >= 0 && iy < He && ix >= 0 && ix < We) a_off[i] = ((long long)b * p.Hin + (iy >> p.ups)) * p.Win + (ix >> p.ups);
+      if (iy >= 0 && iy < He && ix >= 0 && ix < We) a_off[i] = ((long long)b * p.Hin + (iy >> sh)) * p.Win + (ix >> sh);
     }
   }
   uint4 ra[A_IT];
@@ -115,13 +123,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const ConvParams p) {  
   // ---- weight slice of step s = (slab c, tap) by LDS-DMA: LDS position q (linear) <- global chunk (row q/8, (q%8)^swz) ----
   auto issue_w = [&](int c, int tap, int buf) {
     const long long kbase = (long long)tap * Cin + c * 64;
+    const long long Kw = (long long)NTAPS * Cin;
+    const f16* wsrc = par ? p.w_par + (long long)q_par * p.Nrows * Kw : p.w;
 #pragma unroll
     for (int i = 0; i < W_IT; ++i) {
       const int q = tid + i * 256;
       const int r = q >> 3, pos = q & 7;
       int n = n0 + r;
       n = n < p.Nrows ? n : p.Nrows - 1;   // rows beyond the matrix are never stored; keep the address valid
-      const f16* gsrc = p.w + (long long)n * p.K + kbase + (swz8(r, pos)) * 8;
+      const f16* gsrc = wsrc + (long long)n * Kw + kbase + (swz8(r, pos)) * 8;
       uint4* ldst = sW + buf * BN * 8 + i * 256 + wave * 64;   // wave-uniform base; hardware adds lane*16 B
       __builtin_amdgcn_global_load_lds((gptr_t*)gsrc, (lptr_t*)ldst, 16, 0, 0);
     }
@@ -153,13 +163,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const ConvParams p) {  
   for (int c = c_begin; c < nslab; ++c) {
     const uint4* cA = sA + ((c - c_begin) & 1) * HP * 8;
 #pragma unroll 1
-    for (int tap = 0; tap < 9; ++tap, ++step) {
-      const bool more = !(c == nslab - 1 && tap == 8);
-      if (more) { if (tap == 8) issue_w(c + 1, 0, (step + 1) & 1); else issue_w(c, tap + 1, (step + 1) & 1); }
+    for (int tap = 0; tap < NTAPS; ++tap, ++step) {
+      const bool more = !(c == nslab - 1 && tap == NTAPS - 1);
+      if (more) { if (tap == NTAPS - 1) issue_w(c + 1, 0, (step + 1) & 1); else issue_w(c, tap + 1, (step + 1) & 1); }
       const bool stage = tap == 0 && c + 1 < nslab;
       if (stage) load_halo(c + 1);
       const uint4* cW = sW + (step & 1) * BN * 8;
-      const int ky = tap / 3, kx = tap - ky * 3;
+      const int ky = par ? py + (tap >> 1) : tap / 3, kx = par ? px + (tap & 1) : tap - (tap / 3) * 3;
       const int hoff = ky * HWD + kx;
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) {
@@ -190,8 +200,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const ConvParams p) {  
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
       const int ml = wave_m * (BM / 2) + m * 16 + l15;
-      const int oy = oy0 + ml / TW, ox = ox0 + ml % TW;
-      if (oy >= p.Hout || ox >= p.Wout) continue;
+      const int ty_ = oy0 + ml / TW, tx_ = ox0 + ml % TW;
+      const int oy = par ? 2 * ty_ + py : ty_, ox = par ? 2 * tx_ + px : tx_;
+      if (ty_ >= Ht || tx_ >= Wt) continue;
       const long long mrow_s = ((long long)b * p.Hout + oy) * p.Wout + ox;
 #pragma unroll
       for (int a = 0; a < NT; ++a) {
@@ -220,8 +231,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const ConvParams p) {  
 #pragma unroll
   for (int m = 0; m < MT; ++m) {
     const int ml = wave_m * (BM / 2) + m * 16 + l15;
-    const int oy = oy0 + ml / TW, ox = ox0 + ml % TW;
-    mrow[m] = (oy < p.Hout && ox < p.Wout) ? ((long long)b * p.Hout + oy) * p.Wout + ox : -1;
+    const int ty_ = oy0 + ml / TW, tx_ = ox0 + ml % TW;
+    const int oy = par ? 2 * ty_ + py : ty_, ox = par ? 2 * tx_ + px : tx_;
+    mrow[m] = (ty_ < Ht && tx_ < Wt) ? ((long long)b * p.Hout + oy) * p.Wout + ox : -1;
   }
   f16x4 rr[MT][NT];
   if (p.res) {
@@ -255,7 +267,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const ConvParams p) {  
     bool ok[MT];
 #pragma unroll
     for (int m = 0; m < MT; ++m) ok[m] = mrow[m] >= 0;
-    const long long R = p.stats_R, rblk = (ty * tiles_x + tx) * 2 + wave_m;
+    const long long R = p.stats_R, rblk = (((long long)q_par * tiles_y + ty) * tiles_x + tx) * 2 + wave_m;
     wave_stats_store<MT, NT>(acc, ok, 0, MT, p.stats + ((long long)b * p.N * R + rblk) * 2, R, p.N, ncol, l15);
   }
 }
@@ -292,14 +304,16 @@ void launch_c3(const ConvParams& p, hipStream_t s) {
     HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     attr_set = true;
   }
-  const int tiles = p.B * ((p.Hout + TH - 1) / TH) * ((p.Wout + TW - 1) / TW);
+  const bool par = p.w_par != nullptr;
+  const int Ht = par ? p.Hin : p.Hout, Wt = par ? p.Win : p.Wout;
+  const int tiles = p.B * ((Ht + TH - 1) / TH) * ((Wt + TW - 1) / TW);
   const int ntn = (p.N + BN - 1) / BN;
   static const std::string pname = std::string("conv3x3<") + std::to_string(TH) + "x" + std::to_string(TW) + "," + std::to_string(BN) + (GN ? ",gn>" : ">");
   const double bytes = (double)p.B * p.Hin * p.Win * (p.C1 + p.C2) * 2.0 + (double)p.N * p.K * 2.0 + (double)p.M * p.N * (p.out_f32 ? 4.0 : 2.0) +
                        (p.res ? (double)p.M * p.N * 2.0 : 0.0);
-  ProfScope prof(pname.c_str(), 2.0 * p.M * (double)p.N * p.K, bytes, s);
+  ProfScope prof(pname.c_str(), 2.0 * p.M * (double)p.N * p.K, bytes, s);   // algorithmic (9-tap) flops also in parity mode
   const int S = p.splitk > 1 ? p.splitk : 1;
-  hipLaunchKernelGGL(kern, dim3(tiles * ntn, S), dim3(256), smem, s, p);
+  hipLaunchKernelGGL(kern, dim3(tiles * ntn, S, par ? 4 : 1), dim3(256), smem, s, p);
   HIP_CHECK(hipGetLastError());
   if (S > 1) {
     const long long n = (long long)p.M * (p.N >> 2);
@@ -315,9 +329,36 @@ void launch_c3_gn(const ConvParams& p, hipStream_t s) {
 
 }  // namespace
 
+static inline int c3_tile_w(const ConvParams& p) { return (p.w_par ? p.Win : p.Wout) >= 16 ? 16 : 8; }
+
 int conv3x3_stats_blocks(const ConvParams& p) {
-  const int TW = p.Wout >= 16 ? 16 : 8;
-  return ((p.Hout + 7) / 8) * ((p.Wout + TW - 1) / TW) * 2;
+  const int TW = c3_tile_w(p);
+  const int Ht = p.w_par ? p.Hin : p.Hout, Wt = p.w_par ? p.Win : p.Wout;
+  return ((Ht + 7) / 8) * ((Wt + TW - 1) / TW) * 2 * (p.w_par ? 4 : 1);
+}
+
+// w_par[q][n][t][c] = sum of the 3x3 taps of w[n][ky][kx][c] that read the same source pixel for output parity q=(py,px):
+//   rows:  py=0: t_y=0 <- {ky=0},   t_y=1 <- {ky=1,2};   py=1: t_y=0 <- {ky=0,1}, t_y=1 <- {ky=2}   (same for columns)
+__global__ void make_parity_weights_kernel(const f16* __restrict__ w, f16* __restrict__ wp, int Nrows, int Cin) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long total = 4LL * Nrows * 4 * Cin;
+  if (i >= total) return;
+  const int c = (int)(i % Cin);
+  const int t = (int)((i / Cin) % 4);
+  const int n = (int)((i / (4LL * Cin)) % Nrows);
+  const int q = (int)(i / (4LL * Cin * Nrows));
+  const int py = q >> 1, px = q & 1, ty = t >> 1, tx = t & 1;
+  const int ky0 = py == 0 ? (ty == 0 ? 0 : 1) : (ty == 0 ? 0 : 2), ky1 = py == 0 ? (ty == 0 ? 0 : 2) : (ty == 0 ? 1 : 2);
+  const int kx0 = px == 0 ? (tx == 0 ? 0 : 1) : (tx == 0 ? 0 : 2), kx1 = px == 0 ? (tx == 0 ? 0 : 2) : (tx == 0 ? 1 : 2);
+  float acc = 0.f;
+  for (int ky = ky0; ky <= ky1; ++ky)
+    for (int kx = kx0; kx <= kx1; ++kx) acc += (float)w[((long long)n * 9 + ky * 3 + kx) * Cin + c];
+  wp[i] = (f16)acc;
+}
+void launch_make_parity_weights(const f16* w, f16* w_par, int Nrows, int Cin, hipStream_t s) {
+  const long long total = 4LL * Nrows * 4 * Cin;
+  hipLaunchKernelGGL(make_parity_weights_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w, w_par, Nrows, Cin);
+  HIP_CHECK(hipGetLastError());
 }
 
 bool conv3x3_eligible(const ConvParams& p) {
@@ -327,6 +368,7 @@ bool conv3x3_eligible(const ConvParams& p) {
 }
 
 int conv3x3_splitk_plan(const ConvParams& p) {
+  if (p.w_par) return 1;
   // few workgroups and a long K loop (UNet 8x8 / 16x16 levels, K = 9*1280..9*2560): split the slabs so the grid fills the chip
   const int TW = p.Wout >= 16 ? 16 : 8;
   const int bn = (p.N % 128 != 0 && p.N % 160 == 0) ? 160 : (p.N <= 32 ? 32 : (p.N <= 64 ? 64 : 128));
@@ -340,7 +382,8 @@ int conv3x3_splitk_plan(const ConvParams& p) {
 
 void launch_conv3x3(const ConvParams& p, hipStream_t s) {
   LDIFF_CHECK(p.splitk <= 1 || (p.splitk_ws && !p.stats), LDIFF_ERR_INVALID, "conv3x3: split-K needs a workspace and cannot emit fused statistics");
-  const bool wide = p.Wout >= 16;
+  LDIFF_CHECK(!p.w_par || (p.ups == 1 && p.splitk <= 1), LDIFF_ERR_INVALID, "conv3x3: parity weights need ups=1 and no split-K");
+  const bool wide = c3_tile_w(p) == 16;
   const int bn = (p.N % 128 != 0 && p.N % 160 == 0) ? 160 : (p.N <= 32 ? 32 : (p.N <= 64 ? 64 : 128));
   if (wide) {
     if (bn == 160) launch_c3_gn<8, 16, 160>(p, s);

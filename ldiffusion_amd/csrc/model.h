@@ -24,6 +24,8 @@ struct MatW {   // [Nrows][K] fp16 K-major + fp32 bias
   f16* w = nullptr;
   float* b = nullptr;  // nullptr => no bias
   int N = 0, Nrows = 0, K = 0, ks = 1, Cin = 0;  // Cin = padded input channels (K = ks*ks*Cin)
+  mutable f16* w_par = nullptr;   // upsampler convs: parity weights [4][Nrows][4*Cin], built on first use (owned by the Exec)
+  mutable int w_par_gen = -1;     // WeightStore generation the parity weights were derived from
 };
 struct NormW { float* g = nullptr; float* b = nullptr; int C = 0; };
 struct GNss { float* scale = nullptr; float* shift = nullptr; };
@@ -53,6 +55,7 @@ class WeightStore {
   void load(const char* name, const void* host, int dtype, const int64_t* shape, int ndim);
   int missing() const;
   const char* missing_name(int i) const;
+  int generation = 0;   // bumped by every load(): derived weights are rebuilt when it changes
 
  private:
   std::unordered_map<std::string, LoadSpec> specs_;
@@ -80,6 +83,8 @@ class Exec {
   hipStream_t s = nullptr;
   float* gn_partial = nullptr;
   size_t gn_partial_cap = 0;
+  std::vector<void*> owned;   // lazily built derived weights (parity weights of the upsampler convs)
+  const int* weights_gen = nullptr;   // -> WeightStore::generation of the owning model
   ~Exec();
   void ensure_gn_partial(size_t bytes);
   Act new_act(int B, int H, int W, int C);

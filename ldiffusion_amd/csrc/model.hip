@@ -178,6 +178,7 @@ void WeightStore::load(const char* name_c, const void* host, int dtype, const in
     HIP_CHECK(hipMemcpy(sp.mat + (size_t)sp.row_off * sp.K, tmp.data(), tmp.size() * sizeof(f16), hipMemcpyHostToDevice));
   }
   sp.loaded = true;
+  ++generation;
 }
 int WeightStore::missing() const {
   missing_cache_.clear();
@@ -193,6 +194,7 @@ const char* WeightStore::missing_name(int i) const {
 // ---- Exec: op helpers --------------------------------------------------------------------------
 Exec::~Exec() {
   if (gn_partial) (void)hipFree(gn_partial);
+  for (void* q : owned) (void)hipFree(q);
 }
 void Exec::ensure_gn_partial(size_t bytes) {
   if (bytes <= gn_partial_cap) return;
@@ -264,6 +266,21 @@ Act Exec::conv(const MatW& w, const Act& x, const Act* x2, const ConvOpts& o) {
     y = new_act(x.B, p.Hout, p.Wout, C);
     if (C > p.N) HIP_CHECK(hipMemsetAsync(y.p, 0, y.bytes(), s));  // zero the pad columns
     p.y = y.p; p.ldy = C;
+    if (o.ups && conv3x3_eligible(p)) {   // nearest-2x upsample folded algebraically (4 parity convs with pre-summed taps)
+      const int gen = weights_gen ? *weights_gen : 0;
+      if (!w.w_par) {
+        void* q = nullptr;
+        HIP_CHECK(hipMalloc(&q, (size_t)4 * w.Nrows * 4 * w.Cin * sizeof(f16)));
+        owned.push_back(q);
+        w.w_par = (f16*)q;
+        w.w_par_gen = -1;
+      }
+      if (w.w_par_gen != gen) {   // first use, or the checkpoint was reloaded since
+        launch_make_parity_weights(w.w, w.w_par, w.Nrows, w.Cin, s);
+        w.w_par_gen = gen;
+      }
+      p.w_par = w.w_par;
+    }
     if (conv3x3_eligible(p)) p.splitk = conv3x3_splitk_plan(p);
     if (o.want_stats && C == p.N && p.N == w.N && p.splitk <= 1) {
       const int R = conv_stats_blocks_per_image(p);
@@ -338,6 +355,7 @@ static TransformerW make_transformer(WeightStore& ws, const std::string& p, int 
 }
 
 void ldiff_unet::build() {
+  ex.weights_gen = &ws.generation;
   const int nb = cfg.n_blocks;
   const int* boc = cfg.block_out_channels;
   const int temb_dim = boc[0] * 4, ctx = cfg.cross_attention_dim, lpb = cfg.layers_per_block;
@@ -640,6 +658,7 @@ static VaeAttnW make_vae_attn(WeightStore& ws, const std::string& p, int C) {
 }
 
 void ldiff_vae::build() {
+  ex.weights_gen = &ws.generation;
   const int nb = cfg.n_blocks, lpb = cfg.layers_per_block, lat = cfg.latent_channels;
   const int* boc = cfg.block_out_channels;
   LDIFF_CHECK(nb >= 1 && nb <= LDIFF_MAX_BLOCKS, LDIFF_ERR_INVALID, "vae: n_blocks=%d out of range", nb);

@@ -12,6 +12,8 @@
 //                   transpose), B-operand = the probabilities converted in place (no LDS round trip).
 // The key order inside one 32-key MFMA step is the accumulator's native order (4g+r of tile 2s, then of
 // tile 2s+1); the V^T read uses the same order, so no permutation is ever materialised.
+#include <type_traits>
+
 #include "common.h"
 
 template <int DQK>
@@ -28,8 +30,10 @@ struct VLayout {
   static constexpr int STR_DW = ((DV / 16) % 2 == 1) ? DV / 2 : DV / 2 + 8;  // row stride in dwords, == 8*odd
 };
 
-template <int DQK, int DV, int BKV, int QT>
-__global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
+// MINW = waves per SIMD the register allocation must allow: 2 keeps the whole accumulator file in VGPRs (no
+// v_accvgpr_read/write traffic around the softmax / rescale VALU work); the large-head variants need 1.
+template <int DQK, int DV, int BKV, int QT, int MINW>
+__global__ __launch_bounds__(256, MINW) void attn_kernel(const AttnParams p) {
   using KL = KLayout<DQK>;
   constexpr int KS = DQK / 32;        // MFMA k-steps for Q K^T
   constexpr int DT = DV / 16;         // output d tiles
@@ -73,22 +77,55 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
   }
   const float sl2 = p.scale * 1.4426950408889634f;
 
-  for (int kv0 = 0; kv0 < p.Lk; kv0 += BKV) {
+  // K/V tiles are prefetched global -> registers one tile ahead (issued right after the previous tile was written to
+  // LDS, so the loads fly under the MFMA/softmax work of the current tile) and written to LDS after the next barrier.
+  constexpr int KCH = BKV * (DQK / 8), VCH = BKV * (DV / 8);
+  constexpr int KIT = (KCH + 255) / 256, VIT = (VCH + 255) / 256;
+  constexpr bool PFV = DV <= 160;   // d=512: the register file is full (O^T alone is 128 registers) -> V is staged without prefetch
+  uint4 rk[KIT], rv[PFV ? VIT : 1];
+  auto load_kv = [&](int kv0) {
+#pragma unroll
+    for (int i = 0; i < KIT; ++i) {
+      const int c = tid + i * 256, row = c / (DQK / 8), ch = c - row * (DQK / 8);
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (c < KCH && kv0 + row < p.Lk && ch * 8 < d) v = *reinterpret_cast<const uint4*>(Kp + (long long)(kv0 + row) * p.ldk + ch * 8);
+      rk[i] = v;
+    }
+    if (PFV) {
+#pragma unroll
+      for (int i = 0; i < VIT; ++i) {
+        const int c = tid + i * 256, row = c / (DV / 8), ch = c - row * (DV / 8);
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (c < VCH && kv0 + row < p.Lk && ch * 8 < d) v = *reinterpret_cast<const uint4*>(Vp + (long long)(kv0 + row) * p.ldv + ch * 8);
+        rv[i] = v;
+      }
+    }
+  };
+  auto store_kv = [&](int kv0) {
+#pragma unroll
+    for (int i = 0; i < KIT; ++i) {
+      const int c = tid + i * 256, row = c / (DQK / 8), ch = c - row * (DQK / 8);
+      if (c < KCH) sK[KL::off(row, ch)] = rk[i];
+    }
+#pragma unroll
+    for (int i = 0; i < VIT; ++i) {
+      const int c = tid + i * 256, row = c / (DV / 8), ch = c - row * (DV / 8);
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (PFV) v = rv[i];
+      else if (c < VCH && kv0 + row < p.Lk && ch * 8 < d) v = *reinterpret_cast<const uint4*>(Vp + (long long)(kv0 + row) * p.ldv + ch * 8);
+      if (c < VCH) *reinterpret_cast<uint4*>(sV + row * VSTR + ch * 4) = v;
+    }
+  };
+  load_kv(0);
+
+  // One key tile.  TAIL is static: the key mask (compares + selects on every score) exists only in the instantiation
+  // used for the last, partial tile.
+  auto tile = [&](int kv0, auto TAILC) {
+    constexpr bool TAIL = decltype(TAILC)::value;
     __syncthreads();  // previous tile fully consumed
-    // ---- stage K [BKV][DQK] (zero-padded) and V [BKV][DV] into LDS ----
-    for (int c = tid; c < BKV * (DQK / 8); c += 256) {
-      const int row = c / (DQK / 8), ch = c - row * (DQK / 8);
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (kv0 + row < p.Lk && ch * 8 < d) v = *reinterpret_cast<const uint4*>(Kp + (long long)(kv0 + row) * p.ldk + ch * 8);
-      sK[KL::off(row, ch)] = v;
-    }
-    for (int c = tid; c < BKV * (DV / 8); c += 256) {
-      const int row = c / (DV / 8), ch = c - row * (DV / 8);
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (kv0 + row < p.Lk && ch * 8 < d) v = *reinterpret_cast<const uint4*>(Vp + (long long)(kv0 + row) * p.ldv + ch * 8);
-      *reinterpret_cast<uint4*>(sV + row * VSTR + ch * 4) = v;
-    }
+    store_kv(kv0);
     __syncthreads();
+    if (kv0 + BKV < p.Lk) load_kv(kv0 + BKV);
 
     // ---- S^T = K Q^T ----
     f32x4 sacc[QT][NT];
@@ -113,11 +150,10 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
     // the fp16 convert: the running max is tracked on the RAW scores (scale > 0 keeps the order), the softmax scale
     // and log2(e) are folded into the exponent FMA, and the key mask is applied only on the (uniform) tail tile.
     f16x8 pf[QT][NT / 2];
-    const bool tail = kv0 + BKV > p.Lk;
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) {
       float mx = -1e30f;
-      if (tail) {
+      if (TAIL) {
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -169,7 +205,10 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
           oacc[qt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf[qt][s2], oacc[qt][dt], 0, 0, 0);
       }
     }
-  }
+  };
+  const int full = p.Lk / BKV * BKV;
+  for (int kv0 = 0; kv0 < full; kv0 += BKV) tile(kv0, std::false_type());
+  if (full < p.Lk) tile(full, std::true_type());
 
   // ---- normalise and store: lane holds O[q = l15][dd = 16dt + 4g + r] ----
   f16* Op = p.o + (long long)b * p.o_bstride + h * d;
@@ -188,11 +227,11 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
   }
 }
 
-template <int DQK, int DV, int BKV, int QT>
+template <int DQK, int DV, int BKV, int QT, int MINW = 2>
 static void launch_attn_cfg(const AttnParams& p, hipStream_t s) {
   static bool attr_set = false;
   const size_t smem = (size_t)BKV * KLayout<DQK>::STR * 16 + (size_t)BKV * VLayout<DV>::STR_DW * 4;
-  auto kern = attn_kernel<DQK, DV, BKV, QT>;
+  auto kern = attn_kernel<DQK, DV, BKV, QT, MINW>;
   if (!attr_set) {
     HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     attr_set = true;
@@ -217,7 +256,7 @@ void launch_attention(const AttnParams& p, hipStream_t s) {
   else if (d <= 64) launch_attn_cfg<64, 64, 64, 2>(p, s);
   else if (d <= 80) launch_attn_cfg<96, 80, 64, 2>(p, s);
   else if (d <= 96) launch_attn_cfg<96, 96, 64, 2>(p, s);
-  else if (d <= 128) launch_attn_cfg<128, 128, 64, 2>(p, s);
-  else if (d <= 160) launch_attn_cfg<160, 160, 64, 2>(p, s);
-  else launch_attn_cfg<512, 512, 32, 1>(p, s);
+  else if (d <= 128) launch_attn_cfg<128, 128, 64, 2, 1>(p, s);
+  else if (d <= 160) launch_attn_cfg<160, 160, 64, 2, 1>(p, s);
+  else launch_attn_cfg<512, 512, 32, 1, 1>(p, s);
 }

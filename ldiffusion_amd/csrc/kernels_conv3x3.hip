@@ -121,19 +121,24 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const ConvParams p) {  
     }
   };
   // ---- weight slice of step s = (slab c, tap) by LDS-DMA: LDS position q (linear) <- global chunk (row q/8, (q%8)^swz) ----
+  // Per-lane part of the source address is fixed for the whole kernel (32-bit byte offset); per step only a uniform base
+  // moves: one DMA = one scalar base + one VGPR offset, no 64-bit vector address arithmetic inside the loop.
+  const long long Kw = (long long)NTAPS * Cin;
+  const char* wsrc = reinterpret_cast<const char*>(par ? p.w_par + (long long)q_par * p.Nrows * Kw : p.w);
+  unsigned w_voff[W_IT];
+#pragma unroll
+  for (int i = 0; i < W_IT; ++i) {
+    const int q = tid + i * 256, r = q >> 3, pos = q & 7;
+    int n = n0 + r;
+    n = n < p.Nrows ? n : p.Nrows - 1;   // rows beyond the matrix are never stored; keep the address valid
+    w_voff[i] = (unsigned)(((long long)n * Kw + swz8(r, pos) * 8) * 2);
+  }
   auto issue_w = [&](int c, int tap, int buf) {
-    const long long kbase = (long long)tap * Cin + c * 64;
-    const long long Kw = (long long)NTAPS * Cin;
-    const f16* wsrc = par ? p.w_par + (long long)q_par * p.Nrows * Kw : p.w;
+    const char* wbase = wsrc + ((long long)tap * Cin + c * 64) * 2;   // uniform
 #pragma unroll
     for (int i = 0; i < W_IT; ++i) {
-      const int q = tid + i * 256;
-      const int r = q >> 3, pos = q & 7;
-      int n = n0 + r;
-      n = n < p.Nrows ? n : p.Nrows - 1;   // rows beyond the matrix are never stored; keep the address valid
-      const f16* gsrc = wsrc + (long long)n * Kw + kbase + (swz8(r, pos)) * 8;
       uint4* ldst = sW + buf * BN * 8 + i * 256 + wave * 64;   // wave-uniform base; hardware adds lane*16 B
-      __builtin_amdgcn_global_load_lds((gptr_t*)gsrc, (lptr_t*)ldst, 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t*)(wbase + w_voff[i]), (lptr_t*)ldst, 16, 0, 0);
     }
   };
 
@@ -363,7 +368,7 @@ void launch_make_parity_weights(const f16* w, f16* w_par, int Nrows, int Cin, hi
 
 bool conv3x3_eligible(const ConvParams& p) {
   const int Cin = p.C1 + p.C2;
-  return p.ks == 3 && p.stride == 1 && p.pad_t == 1 && p.pad_l == 1 && Cin % 64 == 0 && p.C1 % 64 == 0 &&
+  return p.ks == 3 && p.stride == 1 && p.pad_t == 1 && p.pad_l == 1 && Cin % 64 == 0 && p.C1 % 64 == 0 && (long long)p.Nrows * 9 * Cin * 2 < (1LL << 32) &&
          p.Hout == (p.Hin << p.ups) && p.Wout == (p.Win << p.ups);
 }
 

@@ -38,14 +38,14 @@ __global__ __launch_bounds__(256, 2) void gemm_dma_kernel(const ConvParams p) {
   const int m0 = (sw / ntn) * BM, n0 = (sw % ntn) * BN;
 
   // per-lane source offsets (bytes); rows beyond M / N are clamped (their results are never stored)
-  unsigned a_voff1[A_IT], a_voff2[A_IT], w_voff[W_IT];
+  unsigned a_row[A_IT], a_sw[A_IT], w_voff[W_IT];   // A offset = row * (bytes per row of the current concat source) + swizzled chunk
 #pragma unroll
   for (int i = 0; i < A_IT; ++i) {
     const int q = tid + i * 256, r = q >> 3, pos = q & 7;
     int m = m0 + r;
     m = m < p.M ? m : p.M - 1;
-    a_voff1[i] = (unsigned)(((long long)m * p.C1 + swz8(r, pos) * 8) * 2);
-    a_voff2[i] = (unsigned)(((long long)m * p.C2 + swz8(r, pos) * 8) * 2);
+    a_row[i] = (unsigned)m;
+    a_sw[i] = (unsigned)(swz8(r, pos) * 16);
   }
 #pragma unroll
   for (int i = 0; i < W_IT; ++i) {
@@ -60,10 +60,11 @@ __global__ __launch_bounds__(256, 2) void gemm_dma_kernel(const ConvParams p) {
     const char* abase = second ? reinterpret_cast<const char*>(p.x2) + (long long)(kbase - p.C1) * 2
                                : reinterpret_cast<const char*>(p.x) + (long long)kbase * 2;
     const char* wbase = reinterpret_cast<const char*>(p.w) + (long long)kbase * 2;
+    const unsigned row_bytes = (unsigned)(second ? p.C2 : p.C1) * 2u;   // uniform; one v_mad_u32_u24 per DMA (rows < 2^24)
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) {
       uint4* ldst = sA + buf * BM * 8 + i * 256 + wave * 64;
-      __builtin_amdgcn_global_load_lds((gptr_t*)(abase + (second ? a_voff2[i] : a_voff1[i])), (lptr_t*)ldst, 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t*)(abase + (__umul24(a_row[i], row_bytes) + a_sw[i])), (lptr_t*)ldst, 16, 0, 0);
     }
 #pragma unroll
     for (int i = 0; i < W_IT; ++i) {
@@ -184,7 +185,7 @@ void launch_g(const ConvParams& p, hipStream_t s) {
 
 bool gemm_dma_eligible(const ConvParams& p) {
   return p.ks == 1 && p.stride == 1 && p.ups == 0 && p.pad_t == 0 && p.pad_l == 0 && !p.gn_scale && !p.temb && p.K % 64 == 0 && p.C1 % 64 == 0 &&
-         p.Hout == p.Hin && p.Wout == p.Win && (long long)p.M * (p.C1 > p.C2 ? p.C1 : p.C2) * 2 < (1LL << 32) && (long long)p.Nrows * p.K * 2 < (1LL << 32);
+         p.Hout == p.Hin && p.Wout == p.Win && p.M < (1 << 24) && (p.C1 > p.C2 ? p.C1 : p.C2) * 2 < (1 << 24) && (long long)p.M * (p.C1 > p.C2 ? p.C1 : p.C2) * 2 < (1LL << 32) && (long long)p.Nrows * p.K * 2 < (1LL << 32);
 }
 
 void launch_gemm_dma(const ConvParams& p, hipStream_t s) {

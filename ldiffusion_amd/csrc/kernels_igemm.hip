@@ -44,7 +44,7 @@ __device__ __forceinline__ uint4 gn_apply8(uint4 raw, const float* __restrict__ 
 }
 
 template <int BM, int BN, bool FAST, bool GN>
-__global__ __launch_bounds__(256) void igemm_kernel(const ConvParams p) {
+__global__ __launch_bounds__(256, 2) void igemm_kernel(const ConvParams p) {   // 2 waves/SIMD: accumulators stay in VGPRs
   constexpr int MT = BM / 32, NT = BN / 32;       // 16x16 tiles per wave along m / n (wave tile = BM/2 x BN/2)
   constexpr int A_IT = BM * CPR / 256, B_IT = BN * CPR / 256;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];

@@ -47,6 +47,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU oracle timing (rank 0, N=1)")
     ap.add_argument("--no-prof", action="store_true", help="skip the per-launch HIP-event profile")
+    ap.add_argument("--no-unet-step", action="store_true", help="skip the separate UNet-step timing (used under rocprofv3 so that the\n                    kernel mix of the whole process equals the mix of the timed region)")
     ap.add_argument("--tiny", action="store_true", help="reduced-width graph + 64x64 patches (plumbing check only; not a valid bench line)")
     return ap.parse_args()
 
@@ -62,6 +63,17 @@ def usable_cpus() -> int:
     except (OSError, ValueError):
         pass
     return max(1, n)
+
+
+def pmc_traffic(kernel_name):
+    """HBM bytes per launch of `kernel_name` from the committed rocprofv3 PMC passes over this same workload
+    (profiles/r01_pmc_traffic.json: (2*FETCH_SIZE + WRITE_SIZE)*1024, see its _note); None when no profile is committed.
+    PMC counters cannot be read from inside the process, so this is the offline measurement, not a live one."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+            return json.load(f)["kernels"][kernel_name]["traffic_bytes"]
+    except (OSError, KeyError, ValueError):
+        return None
 
 
 def cpu_baseline(ucfg, vcfg, usd, vsd, img, n_passes):
@@ -159,16 +171,18 @@ def main():
     assert masks.shape[0] == total and masks.dtype == torch.uint8
 
     # ---- UNet step alone (the metric's second half: UNet-step HBM GB/s vs peak), HIP events on the launch stream ----
-    lat = torch.randn((PATCHES_PER_GPU, 4, img // 8, img // 8), device=dev)
-    pipe.unet(lat, 501, ctx)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    reps = 5
-    e0.record()
-    for _ in range(reps):
-        pipe.unet(lat, 501, ctx)   # launched on torch's current stream, the same one the events are recorded on
-    e1.record()
-    torch.cuda.synchronize()
-    unet_ms = e0.elapsed_time(e1) / reps
+    unet_ms = None
+    if not args.no_unet_step:
+        lat = torch.randn((PATCHES_PER_GPU, 4, img // 8, img // 8), device=dev)
+        pipe.unet(lat, 501, ctx)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        reps = 5
+        e0.record()
+        for _ in range(reps):
+            pipe.unet(lat, 501, ctx)   # launched on torch's current stream, the same one the events are recorded on
+        e1.record()
+        torch.cuda.synchronize()
+        unet_ms = e0.elapsed_time(e1) / reps
 
     if rank != 0:
         if dist is not None:
@@ -192,14 +206,14 @@ def main():
         tot_ms = sum(r["ms"] for r in rows)
         ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
         result["roofline"] = {"bound": "mfma", "kernel": dom["name"], "achieved": ach, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                              "frac": ach / MFMA_PEAK_TFLOPS, "traffic": None,
+                              "frac": ach / MFMA_PEAK_TFLOPS, "traffic": pmc_traffic(dom["name"]),
                               "launches": dom["launches"], "avg_launch_us": 1e3 * dom["ms"] / dom["launches"],
                               "algorithmic_GBps": dom["bytes"] / (dom["ms"] * 1e-3) / 1e9,
                               "share_of_profiled_time": dom["ms"] / tot_ms}
         result["kernels"] = [{"name": r["name"], "launches": r["launches"], "ms": round(r["ms"], 3),
                               "tflops": round(r["flops"] / (r["ms"] * 1e-3) / 1e12, 1), "GBps": round(r["bytes"] / (r["ms"] * 1e-3) / 1e9, 1)}
                              for r in sorted(rows, key=lambda r: -r["ms"])]
-    if not args.tiny:
+    if not args.tiny and unet_ms is not None:
         ub = UNET_WEIGHT_BYTES + PATCHES_PER_GPU * UNET_ACT_BYTES_PER_SAMPLE
         uf = PATCHES_PER_GPU * UNET_FLOP_PER_SAMPLE
         result["unet_step"] = {"ms": unet_ms, "batch": PATCHES_PER_GPU,

@@ -277,6 +277,291 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const ConvParams p) {  
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Wide-tile kernel (8 x 16 pixels x BN channels): the algorithm of conv3x3_kernel with the per-step instruction stream
+// cut down.  Counters of the generic loop on MI355X (profiles/r01_conv3x3_issue_profile.md): a wave spends 41 % of its
+// lifetime ISSUING (VALU 23 %, SALU 12 %), 22 % issue-stalled and 36 % parked, and one workgroup alone on a CU still
+// needs ~1900 cycles per tap for 512 cycles of MFMA: the loop is bound by its own serial instruction stream.  So:
+//   * the taps are fully unrolled (template on the parity mode): ky, kx and every tap offset are immediates;
+//   * the halo image is swizzled by the COLUMN hx of the halo pixel (not its linear index), so the X fragment address
+//     of tap (ky,kx), m-tile m is base[kx] + (m+ky)*18*128: three per-lane bases per slab, m and ky in the ds_read
+//     offset field (conflict-free because a 16x16x32 operand row block is 16 consecutive pixels of ONE halo row);
+//   * weight slices by `buffer_load_dwordx4 ... lds`: one descriptor, per-lane voffsets fixed for the kernel, a step
+//     moves only the scalar soffset; the pieces of a wave are contiguous in LDS, so one M0 serves them through the
+//     instruction offset (the hardware adds it to BOTH the memory and the LDS address: the voffset is pre-compensated);
+//   * operand reads as inline asm with counted lgkmcnt waits (hipcc only ever emits lgkmcnt(0) there);
+//   * halo staging without exec masking (clamped source address, AND mask, dump slot for the lanes beyond the halo),
+//     GroupNorm+SiLU of chunk i spread over taps 1.., SiLU chosen by one uniform branch per chunk.
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) { f(std::integral_constant<int, I>{}); static_for<I + 1, N>(f); }
+}
+template <int OFF>
+__device__ __forceinline__ void lds_read128(f16x8& d, unsigned addr) {
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF) : "memory");
+}
+// s_waitcnt lgkmcnt(CNT); the fragments it covers are in/out operands so no MFMA consuming them can move above it
+template <int CNT>
+__device__ __forceinline__ void lds_wait(f16x8& a) { asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(a) : "n"(CNT)); }
+template <int CNT>
+__device__ __forceinline__ void lds_wait(f16x8& a, f16x8& b, f16x8& c, f16x8& d, f16x8& e) {
+  asm volatile("s_waitcnt lgkmcnt(%5)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e) : "n"(CNT));
+}
+
+template <int BN, bool GN>
+__global__ __launch_bounds__(256, BN > 128 ? 1 : 2) void conv3x3w_kernel(const ConvParams p) {
+  constexpr int TH = 8, TW = 16, BM = 128, HWD = 18, HP = 180, MT = 4, NT = BN / 32, A_IT = 6, NP = BN / 32;
+  constexpr int ROWB = HWD * 128;                                  // bytes per halo row
+  constexpr unsigned W_OFF = 2 * HP * 128, W_BYTES = BN * 128;     // LDS map: halo[2] | weights[2] | dump
+  constexpr unsigned DUMP = W_OFF + 2 * W_BYTES;                   // 96 lanes x 16 B: stores of lanes beyond the halo
+  constexpr int NF = NT + MT;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave_m = wave >> 1, wave_n = wave & 1;
+  const int g = lane >> 4, l15 = lane & 15;
+  const int Cin = p.C1 + p.C2;
+  const bool par = p.w_par != nullptr;
+  const int q_par = par ? blockIdx.z : 0, py = q_par >> 1, px = q_par & 1;
+  const int Ht = par ? p.Hin : p.Hout, Wt = par ? p.Win : p.Wout;
+  const int tiles_x = (Wt + TW - 1) / TW, tiles_y = (Ht + TH - 1) / TH;
+  const int ntn = (p.N + BN - 1) / BN;
+  int nwg = gridDim.x, id = blockIdx.x;
+  int q8 = nwg >> 3, r8 = nwg & 7, xcd = id & 7, idx = id >> 3;
+  int sw = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
+  const int tile_n = sw % ntn;
+  int tm = sw / ntn;
+  const int tx = tm % tiles_x; tm /= tiles_x;
+  const int ty = tm % tiles_y;
+  const int b = tm / tiles_y;
+  const int n0 = tile_n * BN, oy0 = ty * TH, ox0 = tx * TW;
+  const int sh = par ? 0 : p.ups;
+  const int He = p.Hin << sh, We = p.Win << sh;
+  const unsigned lds0 = (unsigned)(size_t)(lptr_t*)smem_raw;
+
+  // ---- halo staging: thread owns chunk column kc of halo pixels hp = tid/8 + 32*i ----
+  const int kc = tid & 7;
+  unsigned a_pix[A_IT], a_msk[A_IT], a_lds[A_IT];
+#pragma unroll
+  for (int i = 0; i < A_IT; ++i) {
+    const int hp = (tid >> 3) + i * 32;
+    const int hy = hp / HWD, hx = hp - hy * HWD;
+    const int iy = oy0 + hy - 1, ix = ox0 + hx - 1;
+    const bool inb = hp < HP && iy >= 0 && iy < He && ix >= 0 && ix < We;
+    a_pix[i] = inb ? (unsigned)(((b * p.Hin + (iy >> sh)) * p.Win) + (ix >> sh)) : 0u;
+    a_msk[i] = inb ? 0xffffffffu : 0u;   // zero padding applies to the NORMALISED tensor: padding chunks are exactly 0
+    a_lds[i] = hp < HP ? (unsigned)(hp * 128 + ((kc ^ ((hx >> 1) & 7)) << 4)) : DUMP + (unsigned)((tid - 160) * 16);
+  }
+  uint4 ra[A_IT];
+  float4 gs0, gs1, gt0, gt1;
+  auto load_halo = [&](int c) {
+    const int cb = c * 64;
+    const f16* src; int cs, Cs;
+    if (cb < p.C1) { src = p.x; cs = cb; Cs = p.C1; } else { src = p.x2; cs = cb - p.C1; Cs = p.C2; }
+    src += cs + kc * 8;
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) ra[i] = *reinterpret_cast<const uint4*>(src + (size_t)a_pix[i] * (unsigned)Cs);
+    if (GN) {
+      const float* sc = p.gn_scale + (long long)b * Cin + cb + kc * 8;
+      const float* st = p.gn_shift + (long long)b * Cin + cb + kc * 8;
+      gs0 = *reinterpret_cast<const float4*>(sc); gs1 = *reinterpret_cast<const float4*>(sc + 4);
+      gt0 = *reinterpret_cast<const float4*>(st); gt1 = *reinterpret_cast<const float4*>(st + 4);
+    }
+  };
+  const bool silu = p.silu_in != 0;
+  auto xform_store = [&](auto ic, unsigned bufoff) {   // chunk i of the staged slab -> LDS (normalised, activated, masked)
+    constexpr int i = decltype(ic)::value;
+    uint4 v = ra[i];
+    if (GN) {
+      const float sv[8] = {gs0.x, gs0.y, gs0.z, gs0.w, gs1.x, gs1.y, gs1.z, gs1.w};
+      const float tv[8] = {gt0.x, gt0.y, gt0.z, gt0.w, gt1.x, gt1.y, gt1.z, gt1.w};
+      const f16x8 h = __builtin_bit_cast(f16x8, v);
+      float f[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) f[j] = (float)h[j] * sv[j] + tv[j];
+      if (silu) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[j] = silu_f(f[j]);
+      }
+      f16x8 o;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = (f16)f[j];
+      v = __builtin_bit_cast(uint4, o);
+    }
+    v.x &= a_msk[i]; v.y &= a_msk[i]; v.z &= a_msk[i]; v.w &= a_msk[i];
+    *reinterpret_cast<uint4*>(smem_raw + bufoff + a_lds[i]) = v;
+  };
+
+  // ---- weight slices: wave w owns rows [w*BN/4, (w+1)*BN/4) of the [BN][64] slice = NP pieces of 8 rows (1 KiB) ----
+  const long long Kw = (long long)(par ? 4 : 9) * Cin;
+  const f16* wsrc = par ? p.w_par + (long long)q_par * p.Nrows * Kw : p.w;
+  const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)wsrc, 0, (int)((long long)p.Nrows * Kw * 2), 0x00020000);
+  int w_voff[NP];
+#pragma unroll
+  for (int i = 0; i < NP; ++i) {
+    const int r = wave * (BN / 4) + i * 8 + (lane >> 3), pos = lane & 7;
+    int n = n0 + r;
+    n = n < p.Nrows ? n : p.Nrows - 1;   // rows beyond the matrix are never stored; keep the address in range
+    w_voff[i] = (int)(((long long)n * Kw + swz8(r, pos) * 8) * 2) - (i & 3) * 1024;
+  }
+  auto issue_w = [&](int soff, unsigned slot) {   // soff: byte offset of (tap, slab) inside a weight row
+    unsigned char* dst = smem_raw + W_OFF + slot * W_BYTES + wave * (BN * 32);
+    static_for<0, NP>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+#if defined(__HIP_DEVICE_COMPILE__)   // the host pass rejects this builtin (target feature) and then silently drops the kernel stub
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (lptr_t*)(dst + (i >> 2) * 4096), 16, w_voff[i], soff, (i & 3) * 1024, 0);
+#endif
+    });
+  };
+
+  f32x4 acc[NT][MT];
+#pragma unroll
+  for (int a = 0; a < NT; ++a)
+#pragma unroll
+    for (int m = 0; m < MT; ++m) acc[a][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // per-lane operand addresses (k-half 0): X base of column shift j (kx = j, or px + j in parity mode), W row of slot 0
+  unsigned xb[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const int hx = l15 + (par ? px + (j & 1) : j);
+    xb[j] = lds0 + (unsigned)(((wave_m * 4 + (par ? py : 0)) * HWD + hx) * 128 + ((g ^ ((hx >> 1) & 7)) << 4));
+  }
+  const int wrow = wave_n * (BN / 2) + l15;   // + a*16: same swizzle phase, +2048 B per a
+  const unsigned w_lane = lds0 + W_OFF + (unsigned)(wrow * 128 + ((g ^ ((wrow >> 1) & 7)) << 4));
+
+  const int nslab_all = Cin / 64, S = p.splitk > 1 ? p.splitk : 1, ksplit = blockIdx.y;
+  const int c_begin = ksplit * nslab_all / S, nslab = (ksplit + 1) * nslab_all / S;
+  load_halo(c_begin);
+  issue_w(c_begin * 128, 0);
+  static_for<0, A_IT>([&](auto ic) { xform_store(ic, 0u); });
+  __syncthreads();
+
+  // one (slab, tap) step; T, PAR static.  sp = LDS weight slot of the slab's tap 0.
+  auto run = [&](auto parc) {
+    constexpr bool PAR = decltype(parc)::value;
+    constexpr int NTAPS = PAR ? 4 : 9, CPT = PAR ? 2 : 1;   // chunks of the next slab transformed per tap
+    unsigned sp = 0;
+    for (int c = c_begin; c < nslab; ++c) {
+      const unsigned hbuf = (unsigned)((c - c_begin) & 1) * (HP * 128);
+      const bool stage = c + 1 < nslab;
+      unsigned xc[3], xc1[3], wc[2], wc1[2];
+#pragma unroll
+      for (int j = 0; j < 3; ++j) { xc[j] = xb[j] + hbuf; xc1[j] = xc[j] ^ 64u; }   // chunk bit 2 = k-half: XOR commutes with the swizzle
+      wc[0] = w_lane + sp * W_BYTES; wc[1] = w_lane + (sp ^ 1u) * W_BYTES;
+      wc1[0] = wc[0] ^ 64u; wc1[1] = wc[1] ^ 64u;
+      static_for<0, NTAPS>([&](auto tc) {
+        constexpr int T = decltype(tc)::value;
+        constexpr int kyi = PAR ? (T >> 1) : T / 3, kxi = PAR ? (T & 1) : T % 3;
+        constexpr bool LAST = T == NTAPS - 1;
+        // next step's weight slice -> the other slot (read last in the previous step)
+        if (!LAST) issue_w(((T + 1) * Cin + c * 64) * 2, sp ^ (unsigned)((T + 1) & 1));
+        else if (stage) issue_w((c + 1) * 128, sp ^ (unsigned)(NTAPS & 1));
+        if (T == 0 && stage) load_halo(c + 1);
+        f16x8 wf[2][NT], xf[2][MT];
+        static_for<0, MT>([&](auto mc) { constexpr int m = decltype(mc)::value; lds_read128<(m + kyi) * ROWB>(xf[0][m], xc[kxi]); });
+        static_for<0, NT>([&](auto ac) { constexpr int a = decltype(ac)::value; lds_read128<a * 2048>(wf[0][a], wc[T & 1]); });
+        static_for<0, MT>([&](auto mc) { constexpr int m = decltype(mc)::value; lds_read128<(m + kyi) * ROWB>(xf[1][m], xc1[kxi]); });
+        static_for<0, NT>([&](auto ac) { constexpr int a = decltype(ac)::value; lds_read128<a * 2048>(wf[1][a], wc1[T & 1]); });
+        static_for<0, 2 * NT>([&](auto ic) {
+          constexpr int kk = decltype(ic)::value / NT, a = decltype(ic)::value % NT;
+          constexpr int pending = (1 - kk) * NF + (NT - 1 - a);   // reads issued after W_a of this k-half
+          if constexpr (a == 0) lds_wait<pending>(xf[kk][0], xf[kk][1], xf[kk][2], xf[kk][3], wf[kk][0]);
+          else lds_wait<pending>(wf[kk][a]);
+#pragma unroll
+          for (int m = 0; m < MT; ++m)
+            acc[a][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[kk][a], xf[kk][m], acc[a][m], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+        });
+        if constexpr (T >= 1 && (T - 1) * CPT < A_IT) {
+          if (stage) static_for<(T - 1) * CPT, ((T * CPT < A_IT) ? T * CPT : A_IT)>([&](auto ic) { xform_store(ic, (unsigned)(HP * 128) - hbuf); });
+        }
+        __syncthreads();   // drains this step's weight DMA (vmcnt(0)) and publishes it
+      });
+      sp ^= (unsigned)(NTAPS & 1);
+    }
+  };
+  if (par) run(std::true_type{}); else run(std::false_type{});
+
+  if (S > 1) {   // raw fp32 partial sums; bias / time embedding / residual are applied by splitk_reduce_kernel
+    const int ncol_s = n0 + wave_n * (BN / 2) + g * 4;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      const int ml = wave_m * (BM / 2) + m * 16 + l15;
+      const int ty_ = oy0 + ml / TW, tx_ = ox0 + ml % TW;
+      const int oy = par ? 2 * ty_ + py : ty_, ox = par ? 2 * tx_ + px : tx_;
+      if (ty_ >= Ht || tx_ >= Wt) continue;
+      const long long mrow_s = ((long long)b * p.Hout + oy) * p.Wout + ox;
+#pragma unroll
+      for (int a = 0; a < NT; ++a) {
+        const int n = ncol_s + a * 16;
+        if (n < p.N) *reinterpret_cast<f32x4*>(p.splitk_ws + ((long long)ksplit * p.M + mrow_s) * p.N + n) = acc[a][m];
+      }
+    }
+    return;
+  }
+  // ---- epilogue: lane holds y[pixel = column][n = 4g + r] ----
+  // All global loads of the epilogue (bias, time embedding, residual) are issued back to back BEFORE any use; a
+  // load -> wait -> store chain per 16x16 tile costs a full memory round trip per tile (16-48 us per workgroup).
+  const int ncol = n0 + wave_n * (BN / 2) + g * 4;
+  f32x4 bt[NT];
+#pragma unroll
+  for (int a = 0; a < NT; ++a) {
+    const int n = ncol + a * 16;
+    float4 bb = make_float4(0.f, 0.f, 0.f, 0.f), tt = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (n < p.N) {
+      if (p.bias) bb = *reinterpret_cast<const float4*>(p.bias + n);
+      if (p.temb) tt = *reinterpret_cast<const float4*>(p.temb + (long long)b * p.ld_temb + n);
+    }
+    bt[a] = (f32x4){bb.x + tt.x, bb.y + tt.y, bb.z + tt.z, bb.w + tt.w};
+  }
+  long long mrow[MT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+    const int ml = wave_m * (BM / 2) + m * 16 + l15;
+    const int ty_ = oy0 + ml / TW, tx_ = ox0 + ml % TW;
+    const int oy = par ? 2 * ty_ + py : ty_, ox = par ? 2 * tx_ + px : tx_;
+    mrow[m] = (ty_ < Ht && tx_ < Wt) ? ((long long)b * p.Hout + oy) * p.Wout + ox : -1;
+  }
+  f16x4 rr[MT][NT];
+  if (p.res) {
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int a = 0; a < NT; ++a) {
+        rr[m][a] = (f16x4){(f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f};
+        if (mrow[m] >= 0 && ncol + a * 16 < p.N) rr[m][a] = *reinterpret_cast<const f16x4*>(p.res + mrow[m] * p.ld_res + ncol + a * 16);
+      }
+  }
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+    if (mrow[m] < 0) continue;
+#pragma unroll
+    for (int a = 0; a < NT; ++a) {
+      const int n = ncol + a * 16;
+      if (n >= p.N) continue;
+      f32x4 v = acc[a][m] + bt[a];
+      if (p.res) { v[0] += (float)rr[m][a][0]; v[1] += (float)rr[m][a][1]; v[2] += (float)rr[m][a][2]; v[3] += (float)rr[m][a][3]; }
+      if (p.out_f32) {
+        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.y) + mrow[m] * p.ldy + n) = v;
+      } else {
+        f16x4 o = {(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
+        *reinterpret_cast<f16x4*>(reinterpret_cast<f16*>(p.y) + mrow[m] * p.ldy + n) = o;
+        if (p.stats) acc[a][m] = (f32x4){(float)o[0], (float)o[1], (float)o[2], (float)o[3]};   // what the consumer will read
+      }
+    }
+  }
+  if (p.stats) {   // fused GroupNorm statistics of this half tile (common.h)
+    bool ok[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) ok[m] = mrow[m] >= 0;
+    const long long R = p.stats_R, rblk = (((long long)q_par * tiles_y + ty) * tiles_x + tx) * 2 + wave_m;
+    wave_stats_store<MT, NT>(acc, ok, 0, MT, p.stats + ((long long)b * p.N * R + rblk) * 2, R, p.N, ncol, l15);
+  }
+}
+
+
 // split-K reduction + epilogue: y[m, n..n+3] = sum_s ws[s][m][n..] + bias + temb + res
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const ConvParams p) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -325,6 +610,38 @@ void launch_c3(const ConvParams& p, hipStream_t s) {
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p);
     HIP_CHECK(hipGetLastError());
   }
+}
+
+template <int BN, bool GN>
+void launch_c3w(const ConvParams& p, hipStream_t s) {
+  static bool attr_set = false;
+  constexpr int TH = 8, TW = 16, HP = 180;
+  const size_t smem = (size_t)2 * HP * 128 + 2 * BN * 128 + 1536;
+  auto kern = conv3x3w_kernel<BN, GN>;
+  if (!attr_set) {
+    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    attr_set = true;
+  }
+  const bool par = p.w_par != nullptr;
+  const int Ht = par ? p.Hin : p.Hout, Wt = par ? p.Win : p.Wout;
+  const int tiles = p.B * ((Ht + TH - 1) / TH) * ((Wt + TW - 1) / TW);
+  const int ntn = (p.N + BN - 1) / BN;
+  static const std::string pname = std::string("conv3x3<8x16,") + std::to_string(BN) + (GN ? ",gn>" : ">");
+  const double bytes = (double)p.B * p.Hin * p.Win * (p.C1 + p.C2) * 2.0 + (double)p.N * p.K * 2.0 + (double)p.M * p.N * (p.out_f32 ? 4.0 : 2.0) +
+                       (p.res ? (double)p.M * p.N * 2.0 : 0.0);
+  ProfScope prof(pname.c_str(), 2.0 * p.M * (double)p.N * p.K, bytes, s);   // algorithmic (9-tap) flops also in parity mode
+  const int S = p.splitk > 1 ? p.splitk : 1;
+  hipLaunchKernelGGL(kern, dim3(tiles * ntn, S, par ? 4 : 1), dim3(256), smem, s, p);
+  HIP_CHECK(hipGetLastError());
+  if (S > 1) {
+    const long long n = (long long)p.M * (p.N >> 2);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p);
+    HIP_CHECK(hipGetLastError());
+  }
+}
+template <int BN>
+void launch_c3w_gn(const ConvParams& p, hipStream_t s) {
+  if (p.gn_scale) launch_c3w<BN, true>(p, s); else launch_c3w<BN, false>(p, s);
 }
 
 template <int TH, int TW, int BN>
@@ -391,10 +708,10 @@ void launch_conv3x3(const ConvParams& p, hipStream_t s) {
   const bool wide = c3_tile_w(p) == 16;
   const int bn = (p.N % 128 != 0 && p.N % 160 == 0) ? 160 : (p.N <= 32 ? 32 : (p.N <= 64 ? 64 : 128));
   if (wide) {
-    if (bn == 160) launch_c3_gn<8, 16, 160>(p, s);
-    else if (bn == 64) launch_c3_gn<8, 16, 64>(p, s);
-    else if (bn == 32) launch_c3_gn<8, 16, 32>(p, s);
-    else launch_c3_gn<8, 16, 128>(p, s);
+    if (bn == 160) launch_c3w_gn<160>(p, s);
+    else if (bn == 64) launch_c3w_gn<64>(p, s);
+    else if (bn == 32) launch_c3w_gn<32>(p, s);
+    else launch_c3w_gn<128>(p, s);
   } else {
     if (bn == 160) launch_c3_gn<8, 8, 160>(p, s);
     else if (bn == 64) launch_c3_gn<8, 8, 64>(p, s);

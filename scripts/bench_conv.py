@@ -66,6 +66,8 @@ def time_it(fn, iters):
 def main():
     flt = [a for a in sys.argv[1:] if not a.startswith("--")]
     iters = int(sys.argv[sys.argv.index("--iters") + 1]) if "--iters" in sys.argv else 10
+    if os.environ.get("LDIFF_LIB"):   # diagnostic builds (ablations): never the product library
+        _lib.LIB_PATH = os.path.abspath(os.environ["LDIFF_LIB"])
     lib = _lib.load()
     sp = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     for name, (B, C1, C2, H, W, Cout, ks, stride, ups, gn) in SHAPES.items():

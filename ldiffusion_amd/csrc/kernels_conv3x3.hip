@@ -438,14 +438,33 @@ __global__ __launch_bounds__(256, BN > 128 ? 1 : 2) void conv3x3w_kernel(const C
   static_for<0, A_IT>([&](auto ic) { xform_store(ic, 0u); });
   __syncthreads();
 
-  // one (slab, tap) step; T, PAR static.  sp = LDS weight slot of the slab's tap 0.
-  auto run = [&](auto parc) {
+  // GroupNorm(+SiLU) of ONE element of a staged chunk; issued between the MFMAs of the k-half-1 groups so that its
+  // VALU/transcendental issue slots fall into the shadow of the matrix pipe (an MFMA holds the vector issue port for 8 of
+  // its 16 cycles) and the k-half-0 fragments' registers are free for its temporaries
+  auto xform_elem = [&](auto ic, auto jc, auto siluc) -> float {
+    constexpr int i = decltype(ic)::value, j = decltype(jc)::value;
+    const float sv[8] = {gs0.x, gs0.y, gs0.z, gs0.w, gs1.x, gs1.y, gs1.z, gs1.w};
+    const float tv[8] = {gt0.x, gt0.y, gt0.z, gt0.w, gt1.x, gt1.y, gt1.z, gt1.w};
+    const f16x8 h = __builtin_bit_cast(f16x8, ra[i]);
+    float f = (float)h[j] * sv[j] + tv[j];
+    if constexpr (decltype(siluc)::value) f = silu_f(f);
+    return f;
+  };
+  auto mask_store = [&](auto ic, uint4 v, unsigned bufoff) {
+    constexpr int i = decltype(ic)::value;
+    v.x &= a_msk[i]; v.y &= a_msk[i]; v.z &= a_msk[i]; v.w &= a_msk[i];
+    *reinterpret_cast<uint4*>(smem_raw + bufoff + a_lds[i]) = v;
+  };
+
+  // the (slab, tap) loop; PAR (parity mode) and SILU static.  sp = LDS weight slot of the slab's tap 0.
+  auto run = [&](auto parc, auto siluc) {
     constexpr bool PAR = decltype(parc)::value;
     constexpr int NTAPS = PAR ? 4 : 9, CPT = PAR ? 2 : 1;   // chunks of the next slab transformed per tap
     unsigned sp = 0;
-    for (int c = c_begin; c < nslab; ++c) {
+    // one slab; STAGE = another slab follows (its halo is fetched, normalised and stored during this one)
+    auto slab = [&](int c, auto stagec) {
+      constexpr bool STAGE = decltype(stagec)::value, stage = STAGE;
       const unsigned hbuf = (unsigned)((c - c_begin) & 1) * (HP * 128);
-      const bool stage = c + 1 < nslab;
       unsigned xc[3], xc1[3], wc[2], wc1[2];
 #pragma unroll
       for (int j = 0; j < 3; ++j) { xc[j] = xb[j] + hbuf; xc1[j] = xc[j] ^ 64u; }   // chunk bit 2 = k-half: XOR commutes with the swizzle
@@ -455,15 +474,22 @@ __global__ __launch_bounds__(256, BN > 128 ? 1 : 2) void conv3x3w_kernel(const C
         constexpr int T = decltype(tc)::value;
         constexpr int kyi = PAR ? (T >> 1) : T / 3, kxi = PAR ? (T & 1) : T % 3;
         constexpr bool LAST = T == NTAPS - 1;
-        // next step's weight slice -> the other slot (read last in the previous step)
-        if (!LAST) issue_w(((T + 1) * Cin + c * 64) * 2, sp ^ (unsigned)((T + 1) & 1));
-        else if (stage) issue_w((c + 1) * 128, sp ^ (unsigned)(NTAPS & 1));
-        if (T == 0 && stage) load_halo(c + 1);
+        // chunks [C0, C1) of the NEXT slab are normalised during this tap
+        constexpr int C0 = T >= 1 ? (T - 1) * CPT : A_IT, C1 = T >= 1 ? (T * CPT < A_IT ? T * CPT : A_IT) : A_IT;
+        constexpr int NE = GN && STAGE && C0 < C1 ? (C1 - C0) * 8 : 0, EPG = (NE + NT - 1) / NT;
+        float fx = 0.f;                       // even element waiting for its odd neighbour
+        unsigned pk[NE > 0 ? NE / 2 : 1];     // normalised elements, packed f16 pairs
         f16x8 wf[2][NT], xf[2][MT];
         static_for<0, MT>([&](auto mc) { constexpr int m = decltype(mc)::value; lds_read128<(m + kyi) * ROWB>(xf[0][m], xc[kxi]); });
         static_for<0, NT>([&](auto ac) { constexpr int a = decltype(ac)::value; lds_read128<a * 2048>(wf[0][a], wc[T & 1]); });
         static_for<0, MT>([&](auto mc) { constexpr int m = decltype(mc)::value; lds_read128<(m + kyi) * ROWB>(xf[1][m], xc1[kxi]); });
         static_for<0, NT>([&](auto ac) { constexpr int a = decltype(ac)::value; lds_read128<a * 2048>(wf[1][a], wc1[T & 1]); });
+        __builtin_amdgcn_sched_barrier(0);
+        // next step's weight slice -> the other slot (read last in the previous step); issued while the operand reads fly
+        if (!LAST) issue_w(((T + 1) * Cin + c * 64) * 2, sp ^ (unsigned)((T + 1) & 1));
+        else if (stage) issue_w((c + 1) * 128, sp ^ (unsigned)(NTAPS & 1));
+        if (T == 0 && stage) load_halo(c + 1);
+        __builtin_amdgcn_sched_barrier(0);
         static_for<0, 2 * NT>([&](auto ic) {
           constexpr int kk = decltype(ic)::value / NT, a = decltype(ic)::value % NT;
           constexpr int pending = (1 - kk) * NF + (NT - 1 - a);   // reads issued after W_a of this k-half
@@ -472,17 +498,31 @@ __global__ __launch_bounds__(256, BN > 128 ? 1 : 2) void conv3x3w_kernel(const C
 #pragma unroll
           for (int m = 0; m < MT; ++m)
             acc[a][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[kk][a], xf[kk][m], acc[a][m], 0, 0, 0);
+          static_for<(kk == 1 ? a * EPG : NE), (kk == 1 ? ((a + 1) * EPG < NE ? (a + 1) * EPG : NE) : NE)>([&](auto ec) {
+            constexpr int e = decltype(ec)::value;
+            const float f = xform_elem(std::integral_constant<int, C0 + e / 8>{}, std::integral_constant<int, e % 8>{}, siluc);
+            if constexpr (e & 1) {
+              const f16x2 h2 = {(f16)fx, (f16)f};
+              pk[e / 2] = __builtin_bit_cast(unsigned, h2);
+            } else fx = f;
+          });
           __builtin_amdgcn_sched_barrier(0);
         });
-        if constexpr (T >= 1 && (T - 1) * CPT < A_IT) {
-          if (stage) static_for<(T - 1) * CPT, ((T * CPT < A_IT) ? T * CPT : A_IT)>([&](auto ic) { xform_store(ic, (unsigned)(HP * 128) - hbuf); });
-        }
+        if constexpr (STAGE) static_for<C0, C1>([&](auto ic) {
+          constexpr int i = decltype(ic)::value;
+          uint4 v = ra[i];
+          if constexpr (GN) v = make_uint4(pk[(i - C0) * 4], pk[(i - C0) * 4 + 1], pk[(i - C0) * 4 + 2], pk[(i - C0) * 4 + 3]);
+          mask_store(ic, v, (unsigned)(HP * 128) - hbuf);
+        });
         __syncthreads();   // drains this step's weight DMA (vmcnt(0)) and publishes it
       });
       sp ^= (unsigned)(NTAPS & 1);
-    }
+    };
+    for (int c = c_begin; c + 1 < nslab; ++c) slab(c, std::true_type{});
+    slab(nslab - 1, std::false_type{});
   };
-  if (par) run(std::true_type{}); else run(std::false_type{});
+  if (GN && silu) { if (par) run(std::true_type{}, std::true_type{}); else run(std::false_type{}, std::true_type{}); }
+  else { if (par) run(std::true_type{}, std::false_type{}); else run(std::false_type{}, std::false_type{}); }
 
   if (S > 1) {   // raw fp32 partial sums; bias / time embedding / residual are applied by splitk_reduce_kernel
     const int ncol_s = n0 + wave_n * (BN / 2) + g * 4;

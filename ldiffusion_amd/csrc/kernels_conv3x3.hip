@@ -308,6 +308,14 @@ __device__ __forceinline__ void lds_wait(f16x8& a, f16x8& b, f16x8& c, f16x8& d,
   asm volatile("s_waitcnt lgkmcnt(%5)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e) : "n"(CNT));
 }
 
+// Column swizzle of the halo image: 16-byte chunk c of halo pixel (hy, hx) sits at position c ^ swzx(hx) of its 128-B row.
+// A 16x16x32 operand fetch reads 16 consecutive pixels of one halo row starting at column kx = 0, 1 or 2; its four
+// ds_read_b128 lane groups mix chunks c (8 lanes) and c^1 (8 lanes).  The table (one 3-bit entry per column PAIR, found by
+// exhaustive search against the bank model of MI355X_MICROARCH.md, LDS) makes all three starts conflict-free; the plain
+// (hx>>1)&7 is conflict-free only for kx = 0 and costs 2x on the other two thirds of the taps (SQ_LDS_BANK_CONFLICT = 26 %
+// of the LDS-active cycles).  The position is an XOR of the chunk index, so k-half 1 is still byte address ^ 64.
+__device__ __forceinline__ int swzx(int hx) { return (0xcb5888 >> (3 * (hx >> 1))) & 7; }
+
 template <int BN, bool GN>
 __global__ __launch_bounds__(256, BN > 128 ? 1 : 2) void conv3x3w_kernel(const ConvParams p) {
   constexpr int TH = 8, TW = 16, BM = 128, HWD = 18, HP = 180, MT = 4, NT = BN / 32, A_IT = 6, NP = BN / 32;
@@ -351,7 +359,7 @@ __global__ __launch_bounds__(256, BN > 128 ? 1 : 2) void conv3x3w_kernel(const C
     const bool inb = hp < HP && iy >= 0 && iy < He && ix >= 0 && ix < We;
     a_pix[i] = inb ? (unsigned)(((b * p.Hin + (iy >> sh)) * p.Win) + (ix >> sh)) : 0u;
     a_msk[i] = inb ? 0xffffffffu : 0u;   // zero padding applies to the NORMALISED tensor: padding chunks are exactly 0
-    a_lds[i] = hp < HP ? (unsigned)(hp * 128 + ((kc ^ ((hx >> 1) & 7)) << 4)) : DUMP + (unsigned)((tid - 160) * 16);
+    a_lds[i] = hp < HP ? (unsigned)(hp * 128 + ((kc ^ swzx(hx)) << 4)) : DUMP + (unsigned)((tid - 160) * 16);
   }
   uint4 ra[A_IT];
   float4 gs0, gs1, gt0, gt1;
@@ -426,7 +434,7 @@ __global__ __launch_bounds__(256, BN > 128 ? 1 : 2) void conv3x3w_kernel(const C
 #pragma unroll
   for (int j = 0; j < 3; ++j) {
     const int hx = l15 + (par ? px + (j & 1) : j);
-    xb[j] = lds0 + (unsigned)(((wave_m * 4 + (par ? py : 0)) * HWD + hx) * 128 + ((g ^ ((hx >> 1) & 7)) << 4));
+    xb[j] = lds0 + (unsigned)(((wave_m * 4 + (par ? py : 0)) * HWD + hx) * 128 + ((g ^ swzx(hx)) << 4));
   }
   const int wrow = wave_n * (BN / 2) + l15;   // + a*16: same swizzle phase, +2048 B per a
   const unsigned w_lane = lds0 + W_OFF + (unsigned)(wrow * 128 + ((g ^ ((wrow >> 1) & 7)) << 4));

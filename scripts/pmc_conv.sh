@@ -11,6 +11,6 @@ for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE
   i=$((i+1))
   timeout 120 rocprofv3 --pmc $set --kernel-trace --output-format csv -d "$O/p$i" -- python3 scripts/bench_conv.py "$S" --iters 3 > "$O/p$i.log" 2>&1 || echo "pass $i failed: $(tail -2 $O/p$i.log)"
 done
-python3 scripts/pmc_summary.py "$O" conv3x3_kernel > "$O/summary.txt" 2>&1
+python3 scripts/pmc_summary.py "$O" conv3x3 > "$O/summary.txt" 2>&1
 cat "$O/summary.txt"
 find "$O" -name "*.csv" -delete; find "$O" -name "*.db" -delete

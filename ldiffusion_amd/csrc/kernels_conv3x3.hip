@@ -582,6 +582,36 @@ __global__ __launch_bounds__(256, BN > 128 ? 1 : 2) void conv3x3w_kernel(const C
         if (mrow[m] >= 0 && ncol + a * 16 < p.N) rr[m][a] = *reinterpret_cast<const f16x4*>(p.res + mrow[m] * p.ld_res + ncol + a * 16);
       }
   }
+  // 16-byte stores: lanes g and g+1 hold adjacent 4-channel groups of the SAME pixel.  One v_permlane16_swap per dword
+  // between the packed values of two m-tiles P, Q leaves lanes with even g holding channels 4g..4g+7 of pixel P and lanes
+  // with odd g channels 4(g-1)..4(g-1)+7 of pixel Q: half as many store instructions for the same bytes (the store tail of an
+  // MFMA epilogue is issue-bound per instruction).
+  if (!p.out_f32 && (p.N & 7) == 0 && (p.ldy & 7) == 0) {
+#pragma unroll
+    for (int mp = 0; mp < MT; mp += 2) {
+      // this lane's pixel after the swap, from arithmetic (a select between mrow[] entries becomes a scratch-indexed load)
+      const int mls = wave_m * (BM / 2) + (mp + (g & 1)) * 16 + l15;
+      const int tys = oy0 + mls / TW, txs = ox0 + mls % TW;
+      const long long row = (tys < Ht && txs < Wt) ? ((long long)b * p.Hout + (par ? 2 * tys + py : tys)) * p.Wout + (par ? 2 * txs + px : txs) : -1;
+#pragma unroll
+      for (int a = 0; a < NT; ++a) {
+        uint2 pq[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int m = mp + h;
+          f32x4 v = acc[a][m] + bt[a];
+          if (p.res) { v[0] += (float)rr[m][a][0]; v[1] += (float)rr[m][a][1]; v[2] += (float)rr[m][a][2]; v[3] += (float)rr[m][a][3]; }
+          const f16x4 o = {(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
+          if (p.stats) acc[a][m] = (f32x4){(float)o[0], (float)o[1], (float)o[2], (float)o[3]};   // what the consumer will read
+          pq[h] = __builtin_bit_cast(uint2, o);
+        }
+        auto r0 = __builtin_amdgcn_permlane16_swap(pq[0].x, pq[1].x, false, false);
+        auto r1 = __builtin_amdgcn_permlane16_swap(pq[0].y, pq[1].y, false, false);
+        const int nb = n0 + wave_n * (BN / 2) + a * 16 + (g & ~1) * 4;
+        if (row >= 0 && nb < p.N) *reinterpret_cast<uint4*>(reinterpret_cast<f16*>(p.y) + row * p.ldy + nb) = make_uint4(r0[0], r1[0], r0[1], r1[1]);
+      }
+    }
+  } else
 #pragma unroll
   for (int m = 0; m < MT; ++m) {
     if (mrow[m] < 0) continue;

@@ -18,13 +18,32 @@ __device__ __forceinline__ int swz8(int row, int chunk) { return chunk ^ ((row >
 typedef __attribute__((address_space(1))) const void gptr_t;
 typedef __attribute__((address_space(3))) void lptr_t;
 
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) { f(std::integral_constant<int, I>{}); static_for<I + 1, N>(f); }
+}
+// operand reads as inline asm + counted lgkmcnt waits (hipcc only emits lgkmcnt(0)); see kernels_conv3x3.hip
+template <int OFF>
+__device__ __forceinline__ void lds_read128(f16x8& d, unsigned addr) {
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF) : "memory");
+}
+template <int CNT>
+__device__ __forceinline__ void lds_wait(f16x8& a) { asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(a) : "n"(CNT)); }
+template <int CNT>
+__device__ __forceinline__ void lds_wait(f16x8& a, f16x8& b, f16x8& c) { asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(a), "+v"(b), "+v"(c) : "n"(CNT)); }
+template <int CNT>
+__device__ __forceinline__ void lds_wait(f16x8& a, f16x8& b, f16x8& c, f16x8& d) {
+  asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(CNT));
+}
+template <int CNT>
+__device__ __forceinline__ void lds_wait(f16x8& a, f16x8& b, f16x8& c, f16x8& d, f16x8& e) {
+  asm volatile("s_waitcnt lgkmcnt(%5)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e) : "n"(CNT));
+}
+
 template <int BM, int BN>
 __global__ __launch_bounds__(256, 2) void gemm_dma_kernel(const ConvParams p) {
   constexpr int MT = BM / 32, NT = BN / 32;
-  constexpr int A_IT = BM * 8 / 256, W_IT = BN * 8 / 256;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  uint4* sA = reinterpret_cast<uint4*>(smem_raw);   // [2][BM*8]
-  uint4* sW = sA + 2 * BM * 8;                      // [2][BN*8]
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -37,40 +56,54 @@ __global__ __launch_bounds__(256, 2) void gemm_dma_kernel(const ConvParams p) {
   int sw = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
   const int m0 = (sw / ntn) * BM, n0 = (sw % ntn) * BN;
 
-  // per-lane source offsets (bytes); rows beyond M / N are clamped (their results are never stored)
-  unsigned a_row[A_IT], a_sw[A_IT], w_voff[W_IT];   // A offset = row * (bytes per row of the current concat source) + swizzled chunk
+  // ---- operand slices by `buffer_load_dwordx4 ... lds` (see the wide conv3x3 kernel): wave w owns rows [w*B/4, (w+1)*B/4)
+  // of each [B][64] slice = B/32 pieces of 8 rows (1 KiB); per-lane voffsets are fixed, a step moves only the scalar soffset;
+  // the pieces of a wave are contiguous in LDS, so one M0 per operand serves them through the instruction offset, which the
+  // hardware adds to BOTH the memory and the LDS address (voffset pre-compensated).  Rows beyond M / N are clamped (their
+  // results are never stored).
+  constexpr int A_NP = BM / 32, W_NP = BN / 32;
+  constexpr unsigned A_BYTES = BM * 128, W_BYTES = BN * 128, W_OFF = 2 * A_BYTES;   // LDS map: A[2] | W[2]
+  int a_row[A_NP], a_sw[A_NP], a_voff[A_NP], w_voff[W_NP];
 #pragma unroll
-  for (int i = 0; i < A_IT; ++i) {
-    const int q = tid + i * 256, r = q >> 3, pos = q & 7;
+  for (int i = 0; i < A_NP; ++i) {
+    const int r = wave * (BM / 4) + i * 8 + (lane >> 3), pos = lane & 7;
     int m = m0 + r;
-    m = m < p.M ? m : p.M - 1;
-    a_row[i] = (unsigned)m;
-    a_sw[i] = (unsigned)(swz8(r, pos) * 16);
+    a_row[i] = m < p.M ? m : p.M - 1;
+    a_sw[i] = swz8(r, pos) * 16 - (i & 3) * 1024;
+    a_voff[i] = a_row[i] * (p.C1 * 2) + a_sw[i];
   }
 #pragma unroll
-  for (int i = 0; i < W_IT; ++i) {
-    const int q = tid + i * 256, r = q >> 3, pos = q & 7;
+  for (int i = 0; i < W_NP; ++i) {
+    const int r = wave * (BN / 4) + i * 8 + (lane >> 3), pos = lane & 7;
     int n = n0 + r;
     n = n < p.Nrows ? n : p.Nrows - 1;
-    w_voff[i] = (unsigned)(((long long)n * p.K + swz8(r, pos) * 8) * 2);
+    w_voff[i] = (int)(((long long)n * p.K + swz8(r, pos) * 8) * 2) - (i & 3) * 1024;
   }
-  auto issue = [&](int kt, int buf) {
-    const int kbase = kt * 64;
-    const bool second = kbase >= p.C1;                                   // uniform: which concat source this slab is in
-    const char* abase = second ? reinterpret_cast<const char*>(p.x2) + (long long)(kbase - p.C1) * 2
-                               : reinterpret_cast<const char*>(p.x) + (long long)kbase * 2;
-    const char* wbase = reinterpret_cast<const char*>(p.w) + (long long)kbase * 2;
-    const unsigned row_bytes = (unsigned)(second ? p.C2 : p.C1) * 2u;   // uniform; one v_mad_u32_u24 per DMA (rows < 2^24)
+  const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)((long long)p.M * p.C1 * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs2 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x2 ? p.x2 : p.x), 0, (int)((long long)p.M * (p.x2 ? p.C2 : p.C1) * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, (int)((long long)p.Nrows * p.K * 2), 0x00020000);
+  const int kt2 = p.C1 / 64;   // first K-step of the second concat source
+  auto issue = [&](int kt, auto bufc) {
+    constexpr int buf = decltype(bufc)::value;
+    const bool second = kt >= kt2;
+    if (kt == kt2) {   // the row pitch changes with the source: new voffsets, once
 #pragma unroll
-    for (int i = 0; i < A_IT; ++i) {
-      uint4* ldst = sA + buf * BM * 8 + i * 256 + wave * 64;
-      __builtin_amdgcn_global_load_lds((gptr_t*)(abase + (__umul24(a_row[i], row_bytes) + a_sw[i])), (lptr_t*)ldst, 16, 0, 0);
+      for (int i = 0; i < A_NP; ++i) a_voff[i] = a_row[i] * (p.C2 * 2) + a_sw[i];
     }
-#pragma unroll
-    for (int i = 0; i < W_IT; ++i) {
-      uint4* ldst = sW + buf * BN * 8 + i * 256 + wave * 64;
-      __builtin_amdgcn_global_load_lds((gptr_t*)(wbase + w_voff[i]), (lptr_t*)ldst, 16, 0, 0);
-    }
+    unsigned char* adst = smem_raw + buf * A_BYTES + wave * (BM * 32);
+    unsigned char* wdst = smem_raw + W_OFF + buf * W_BYTES + wave * (BN * 32);
+    const int asoff = (second ? kt - kt2 : kt) * 128, wsoff = kt * 128;
+#if defined(__HIP_DEVICE_COMPILE__)   // the host pass rejects this builtin and then silently drops the kernel stub
+    static_for<0, A_NP>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      if (second) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs2, (lptr_t*)(adst + (i >> 2) * 4096), 16, a_voff[i], asoff, (i & 3) * 1024, 0);
+      else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, (lptr_t*)(adst + (i >> 2) * 4096), 16, a_voff[i], asoff, (i & 3) * 1024, 0);
+    });
+    static_for<0, W_NP>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lptr_t*)(wdst + (i >> 2) * 4096), 16, w_voff[i], wsoff, (i & 3) * 1024, 0);
+    });
+#endif
   };
 
   f32x4 acc[NT][MT];
@@ -79,34 +112,49 @@ __global__ __launch_bounds__(256, 2) void gemm_dma_kernel(const ConvParams p) {
 #pragma unroll
     for (int m = 0; m < MT; ++m) acc[a][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  int w_addr[NT], x_addr[MT];
-#pragma unroll
-  for (int a = 0; a < NT; ++a) { const int row = wave_n * (BN / 2) + a * 16 + l15; w_addr[a] = row * 8 + swz8(row, g); }
-#pragma unroll
-  for (int m = 0; m < MT; ++m) { const int row = wave_m * (BM / 2) + m * 16 + l15; x_addr[m] = row * 8 + swz8(row, g); }
+  // per-lane operand addresses: stage, k-half, m / a all go into the ds_read offset field or an XOR of 64
+  const unsigned lds0 = (unsigned)(size_t)(lptr_t*)smem_raw;
+  const int xrow = wave_m * (BM / 2) + l15, wrow = wave_n * (BN / 2) + l15;
+  const unsigned xa = lds0 + (unsigned)(xrow * 128 + ((g ^ ((xrow >> 1) & 7)) << 4)), xa1 = xa ^ 64u;
+  const unsigned wa = lds0 + W_OFF + (unsigned)(wrow * 128 + ((g ^ ((wrow >> 1) & 7)) << 4)), wa1 = wa ^ 64u;
+  constexpr int NF = NT + MT;
 
   const int nk = p.K / 64;
-  issue(0, 0);
+  issue(0, std::integral_constant<int, 0>{});
   __syncthreads();
-  for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
-    if (kt + 1 < nk) issue(kt + 1, cur ^ 1);
-    const uint4* cA = sA + cur * BM * 8;
-    const uint4* cW = sW + cur * BN * 8;
+  auto step = [&](int kt, auto bufc) {
+    constexpr int buf = decltype(bufc)::value;
+    f16x8 wf[2][NT], xf[2][MT];
+    constexpr bool DMA_FIRST = BM * BN < 128 * 128;   // short steps (8-16 MFMA per wave): the DMA needs the whole step to land
+    if (DMA_FIRST && kt + 1 < nk) issue(kt + 1, std::integral_constant<int, buf ^ 1>{});
+    if (DMA_FIRST) __builtin_amdgcn_sched_barrier(0);
+    static_for<0, MT>([&](auto mc) { constexpr int m = decltype(mc)::value; lds_read128<buf * (int)A_BYTES + m * 2048>(xf[0][m], xa); });
+    static_for<0, NT>([&](auto ac) { constexpr int a = decltype(ac)::value; lds_read128<buf * (int)W_BYTES + a * 2048>(wf[0][a], wa); });
+    static_for<0, MT>([&](auto mc) { constexpr int m = decltype(mc)::value; lds_read128<buf * (int)A_BYTES + m * 2048>(xf[1][m], xa1); });
+    static_for<0, NT>([&](auto ac) { constexpr int a = decltype(ac)::value; lds_read128<buf * (int)W_BYTES + a * 2048>(wf[1][a], wa1); });
+    __builtin_amdgcn_sched_barrier(0);
+    if (!DMA_FIRST && kt + 1 < nk) issue(kt + 1, std::integral_constant<int, buf ^ 1>{});   // into the stage read last in the previous step
+    __builtin_amdgcn_sched_barrier(0);
+    static_for<0, 2 * NT>([&](auto ic) {
+      constexpr int kk = decltype(ic)::value / NT, a = decltype(ic)::value % NT;
+      constexpr int pending = (1 - kk) * NF + (NT - 1 - a);   // LDS reads issued after W_a of this k-half
+      if constexpr (MT == 4) {
+        if constexpr (a == 0) lds_wait<pending>(xf[kk][0], xf[kk][1], xf[kk][2], xf[kk][3], wf[kk][0]);
+        else lds_wait<pending>(wf[kk][a]);
+      } else if constexpr (a == 0) {   // 64 x 64 tile: groups of 2 MFMA are too short for a wait each: one per k-half
+        static_assert(NT == 2, "64-row tiles come with 64 columns");
+        lds_wait<(1 - kk) * NF>(xf[kk][0], xf[kk][1], wf[kk][0], wf[kk][1]);
+      }
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      f16x8 wf[NT], xf[MT];
-#pragma unroll
-      for (int a = 0; a < NT; ++a) wf[a] = __builtin_bit_cast(f16x8, cW[w_addr[a] ^ (kk * 4)]);
-#pragma unroll
-      for (int m = 0; m < MT; ++m) xf[m] = __builtin_bit_cast(f16x8, cA[x_addr[m] ^ (kk * 4)]);
-#pragma unroll
-      for (int a = 0; a < NT; ++a)
-#pragma unroll
-        for (int m = 0; m < MT; ++m)
-          acc[a][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[a], xf[m], acc[a][m], 0, 0, 0);
-    }
-    __syncthreads();   // drains the DMA issued at the top of this step (vmcnt(0)) and protects the buffer swap
+      for (int m = 0; m < MT; ++m)
+        acc[a][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[kk][a], xf[kk][m], acc[a][m], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    });
+    __syncthreads();   // drains the DMA issued in this step (vmcnt(0)) and protects the stage swap
+  };
+  for (int kt = 0; kt < nk; kt += 2) {
+    step(kt, std::integral_constant<int, 0>{});
+    if (kt + 1 < nk) step(kt + 1, std::integral_constant<int, 1>{});
   }
 
   // ---- epilogue (all loads issued before any use) ----
@@ -134,6 +182,31 @@ __global__ __launch_bounds__(256, 2) void gemm_dma_kernel(const ConvParams p) {
         if (mrow[m] >= 0 && ncol + a * 16 < p.N) rr[m][a] = *reinterpret_cast<const f16x4*>(p.res + (long long)mrow[m] * p.ld_res + ncol + a * 16);
       }
   }
+  // 16-byte stores (see kernels_conv3x3.hip): one v_permlane16_swap per dword between the packed values of two m-tiles
+  // leaves even-g lanes with channels 4g..4g+7 of the first tile's row and odd-g lanes with 4(g-1)..4(g-1)+7 of the second's
+  if (!p.out_f32 && (p.N & 7) == 0 && (p.ldy & 7) == 0) {
+#pragma unroll
+    for (int mp = 0; mp < MT; mp += 2) {
+      const int mms = m0 + wave_m * (BM / 2) + (mp + (g & 1)) * 16 + l15;   // this lane's row after the swap
+#pragma unroll
+      for (int a = 0; a < NT; ++a) {
+        uint2 pq[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int m = mp + h;
+          f32x4 v = acc[a][m] + bb[a];
+          if (p.res) { v[0] += (float)rr[m][a][0]; v[1] += (float)rr[m][a][1]; v[2] += (float)rr[m][a][2]; v[3] += (float)rr[m][a][3]; }
+          const f16x4 o = {(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
+          if (p.stats) acc[a][m] = (f32x4){(float)o[0], (float)o[1], (float)o[2], (float)o[3]};
+          pq[h] = __builtin_bit_cast(uint2, o);
+        }
+        auto r0 = __builtin_amdgcn_permlane16_swap(pq[0].x, pq[1].x, false, false);
+        auto r1 = __builtin_amdgcn_permlane16_swap(pq[0].y, pq[1].y, false, false);
+        const int nb = n0 + wave_n * (BN / 2) + a * 16 + (g & ~1) * 4;
+        if (mms < p.M && nb < p.N) *reinterpret_cast<uint4*>(reinterpret_cast<f16*>(p.y) + (long long)mms * p.ldy + nb) = make_uint4(r0[0], r1[0], r0[1], r1[1]);
+      }
+    }
+  } else
 #pragma unroll
   for (int m = 0; m < MT; ++m) {
     if (mrow[m] < 0) continue;

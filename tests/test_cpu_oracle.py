@@ -209,3 +209,35 @@ def test_weights_layout_roundtrip(tmp_path):
         weights.load_model_dir(str(tmp_path / "vae"))
     with pytest.raises(ValueError):
         configs.validate_unet_config(dict(configs.SD15_UNET, block_out_channels=[100, 200, 400, 400]))
+
+
+def test_tiling_matches_reference_helpers():
+    """oracle/tiling.py and the product's host-side tiling against the outputs of the reference's own nnU-Net helpers
+    (tests/golden/reference_tiling.json, scripts/gen_golden_tiling.py)."""
+    import json
+    from ldiffusion_amd import tiling as ptiling
+    from oracle import tiling as otiling
+    with open(os.path.join(GOLD, "reference_tiling.json")) as f:
+        d = json.load(f)
+    for c in d["steps"]:
+        assert otiling.steps_for_sliding_window(c["image_size"], c["tile_size"], c["tile_step_size"]) == c["steps"]
+        assert ptiling.compute_steps_for_sliding_window(c["image_size"], c["tile_size"], c["tile_step_size"]) == c["steps"]
+    assert otiling.tile_origins((1024, 1024), (512, 512), 1.0) == [(0, 0), (0, 512), (512, 0), (512, 512)]   # BASELINE configs[3]
+    g = np.array(d["gaussian"]["values"])
+    assert np.abs(otiling.gaussian_importance((64, 48), 0.125, 10) - g).max() < 2e-6
+    assert np.abs(ptiling.compute_gaussian((64, 48), 0.125, 10, torch.float64).numpy() - g).max() < 2e-6
+    # merge: product (torch) == oracle (numpy) on random overlapping tiles; edge cases
+    rng = np.random.default_rng(0)
+    origins = otiling.tile_origins((96, 80), (64, 48), 0.5)
+    tiles = rng.standard_normal((len(origins), 3, 64, 48)).astype(np.float32)
+    a = otiling.merge_logits(tiles, origins, (96, 80))
+    b = ptiling.merge_tile_logits(torch.from_numpy(tiles), origins, (96, 80)).numpy()
+    assert np.abs(a - b).max() < 1e-5
+    with pytest.raises(ValueError):
+        ptiling.compute_steps_for_sliding_window((100, 100), (128, 128), 0.5)
+    with pytest.raises(ValueError):
+        ptiling.compute_steps_for_sliding_window((256, 256), (128, 128), 0.0)
+    with pytest.raises(RuntimeError):
+        ptiling.merge_tile_logits(torch.zeros((1, 2, 8, 8)), [(0, 0)], (16, 16))
+    t, o = ptiling.split_tiles(torch.arange(3 * 16 * 16, dtype=torch.float32).reshape(3, 16, 16), (8, 8), 1.0)
+    assert t.shape == (4, 3, 8, 8) and o == [(0, 0), (0, 8), (8, 0), (8, 8)] and torch.equal(t[3], torch.arange(3 * 256.).reshape(3, 16, 16)[:, 8:, 8:])

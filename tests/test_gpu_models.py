@@ -265,3 +265,67 @@ def test_sd15_width_unet_and_vae_against_oracle():
     e_d = rel_err(vae.decode(z.to(DEV)).sample, ovae.decode(z).sample)
     print(f"SD15 widths: unet rel err {e_u:.3e}, vae encode {e_e:.3e}, vae decode {e_d:.3e}")
     assert e_u < 1e-2 and e_e < 1e-2 and e_d < 1e-2
+
+
+def _probe_head(num_classes, n_feat, seed):
+    """Deterministic linear probe [classes, passes] + bias on the per-pixel latent vectors (stand-in for the tissue head)."""
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn((num_classes, n_feat), generator=g) / 255.0, torch.randn((num_classes,), generator=g) * 0.1
+
+
+@pytest.mark.parametrize("step", [1.0, 0.5])
+def test_config4_tiled_roi_20_passes_6_classes(tiny, step):
+    """BASELINE.json configs[3] at reduced size (oracle in seconds): ROI -> tiles (nnU-Net origins) -> 20-pass sampler per tile
+    -> 6-class logits per pixel -> Gaussian-weighted merge -> arg-max mask, against the CPU oracle run tile by tile."""
+    from ldiffusion_amd import tiling
+    from oracle import tiling as otiling
+    N, C = 20, 6
+    g = torch.Generator().manual_seed(4)
+    roi = torch.rand((3, 128, 128), generator=g)
+    ctx = torch.randn((1, 6, 64), generator=g) * 0.5
+    tiles, origins = tiling.split_tiles(roi.to(DEV), (64, 64), step)
+    assert origins == otiling.tile_origins((128, 128), (64, 64), step) and tiles.shape[0] == (4 if step == 1.0 else 9)
+    s = LaplaceSampler(tiny["pipe"])
+    assert len(s.timesteps(N)) == N
+    out = s.sample(tiles, ctx.to(DEV), N)
+    W, bias = _probe_head(C, N, 5)
+    feats = out["features"].float()                                                   # [n, N, 64, 64]
+    logits = torch.einsum("cn,bnhw->bchw", W.to(DEV), feats) + bias.to(DEV)[None, :, None, None]
+    merged = tiling.merge_tile_logits(logits, origins, (128, 128))
+    mask = argmax_mask(merged[None])[0].cpu().numpy()
+    # oracle, tile by tile
+    ref = op.sample_v6(tiny["opipe"], tiles.cpu(), ctx, N)
+    assert tiny["opipe"].unet.calls[-N:] == s.timesteps(N)
+    e = rel_err(out["latents"], ref["latents"][-1])
+    fd = np.abs(out["features"].cpu().numpy().astype(int) - ref["features"].astype(int))
+    rlogits = np.einsum("cn,bnhw->bchw", W.numpy().astype(np.float64), ref["features"].astype(np.float64)) + bias.numpy()[None, :, None, None]
+    rmerged = otiling.merge_logits(rlogits, origins, (128, 128))
+    rmask = noise_post.argmax_mask(torch.from_numpy(rmerged)[None].float())[0]
+    # the merge itself, on identical inputs, must agree to fp32 round-off
+    m2 = otiling.merge_logits(logits.cpu().numpy().astype(np.float64), origins, (128, 128))
+    assert np.abs(merged.cpu().numpy() - m2).max() <= 1e-4 * np.abs(m2).max()
+    agree = (mask == np.asarray(rmask)).mean()
+    print(f"config4 step={step}: {tiles.shape[0]} tiles x {N} passes; latents rel err {e:.3e}; luma max diff {fd.max()} (>1: {(fd > 1).mean():.4f}); "
+          f"mask agreement {agree:.4f}")
+    assert mask.shape == (128, 128) and mask.max() < C
+    assert e < 3e-2 and (fd > 2).mean() < 0.01 and agree > 0.97
+    if step == 1.0:   # non-overlapping: the merged mask is the tile masks side by side
+        tm = argmax_mask(logits)
+        assert torch.equal(tiling.merge_tile_masks(tm, origins, (128, 128)).cpu(), torch.from_numpy(mask))
+
+
+def test_tiles_are_independent_units(tiny):
+    """Tiles shard like patches: a tile sampled alone equals the same tile inside a batch (no cross-sample coupling), so
+    ranks can take disjoint tile ranges (parallel.shard_range) with no data-path collective."""
+    from ldiffusion_amd import parallel, tiling
+    g = torch.Generator().manual_seed(6)
+    roi = torch.rand((3, 128, 128), generator=g).to(DEV)
+    ctx = (torch.randn((1, 6, 64), generator=g) * 0.5).to(DEV)
+    tiles, origins = tiling.split_tiles(roi, (64, 64), 1.0)
+    s = LaplaceSampler(tiny["pipe"])
+    full = s.sample(tiles, ctx, 5)["features"]
+    parts = []
+    for r in range(2):
+        lo, hi = parallel.shard_range(tiles.shape[0], r, 2)
+        parts.append(s.sample(tiles[lo:hi].contiguous(), ctx, 5)["features"])
+    assert torch.equal(torch.cat(parts, 0), full)

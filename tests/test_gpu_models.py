@@ -329,3 +329,19 @@ def test_tiles_are_independent_units(tiny):
         lo, hi = parallel.shard_range(tiles.shape[0], r, 2)
         parts.append(s.sample(tiles[lo:hi].contiguous(), ctx, 5)["features"])
     assert torch.equal(torch.cat(parts, 0), full)
+
+
+@pytest.mark.timeout(900)
+def test_one_pass_1024_roi_against_oracle(tiny):
+    """the reference-faithful single-pass form (segmentor.py:86-112, 490-545) on a full 1024x1024 ROI:
+    128x128 latents, 16,384 tokens in the level-0 self-attention."""
+    g = torch.Generator().manual_seed(8)
+    x = torch.rand((1, 3, 1024, 1024), generator=g)
+    ctx = torch.randn((1, 6, 64), generator=g) * 0.5
+    out = LaplaceSampler(tiny["pipe"]).sample(x.to(DEV), ctx.to(DEV), 1)
+    ref = op.sample_one_pass(tiny["opipe"], x, ctx)
+    e = rel_err(out["latents"], ref["latents"])
+    rd = np.abs(out["rgb"].cpu().numpy().astype(int) - ref["rgb_u8"].astype(int))
+    print(f"1024^2 one pass: latents rel err {e:.3e}; rgb max diff {rd.max()} (>1: {(rd > 1).mean():.5f})")
+    assert out["rgb"].shape == (1, 1024, 1024, 3) or out["rgb"].shape[1:3] == (1024, 1024)
+    assert e < 2e-2 and (rd > 1).mean() < 0.01

@@ -174,9 +174,13 @@ int ldiff_op_nchw_to_nhwc(const void* x_f32, void* y_f16, int B, int C, int H, i
  * Live measurement for bench.py's roofline line: when enabled, every conv/linear, attention and
  * GroupNorm-statistics launch is bracketed by two HIP events recorded on the launch stream.
  * ldiff_prof_collect waits for them and returns one row per kernel (time, launches, algorithmic flops/bytes).
+ * Two events per launch cost ~6 % of a sampler step when every launch carries them, so ldiff_prof_set_filter(name)
+ * restricts the brackets to launches of ONE kernel (exact row name, e.g. "conv3x3<8x16,128,gn>"; NULL = all):
+ * bench.py profiles every kernel in an untimed warm-up step and only the dominant one inside the timed region.
  * ---------------------------------------------------------------------------------------------- */
 typedef struct { char name[64]; int64_t launches; double ms, flops, bytes; } ldiff_prof_row;
 int ldiff_prof_enable(int on);
+int ldiff_prof_set_filter(const char* kernel_name_or_null);
 int ldiff_prof_collect(ldiff_prof_row* rows, int cap); /* returns the number of rows (may exceed cap) or <0 */
 
 #ifdef __cplusplus

@@ -76,6 +76,7 @@ SIGNATURES = {
     "ldiff_op_geglu": (I, [P, P, I64, I, P]),
     "ldiff_op_nchw_to_nhwc": (I, [P, P, I, I, I, I, I, P]),
     "ldiff_prof_enable": (I, [I]),
+    "ldiff_prof_set_filter": (I, [C.c_char_p]),
     "ldiff_prof_collect": (I, [P, I]),
 }
 

@@ -140,12 +140,12 @@ class Arena {
 // ---- optional per-launch profiling with HIP events (prof.hip) ---------------------------------
 // When enabled (ldiff_prof_enable), every wrapped launch is bracketed by two events recorded on the
 // launch stream; ldiff_prof_collect sums elapsed time / algorithmic flops / algorithmic bytes per kernel name.
-bool prof_on();
+bool prof_on(const char* name);
 void prof_begin(const char* name, double flops, double bytes, hipStream_t s);
 void prof_end(hipStream_t s);
 struct ProfScope {
   hipStream_t s; bool on;
-  ProfScope(const char* name, double flops, double bytes, hipStream_t st) : s(st), on(prof_on()) { if (on) prof_begin(name, flops, bytes, s); }
+  ProfScope(const char* name, double flops, double bytes, hipStream_t st) : s(st), on(prof_on(name)) { if (on) prof_begin(name, flops, bytes, s); }
   ~ProfScope() { if (on) prof_end(s); }
 };
 

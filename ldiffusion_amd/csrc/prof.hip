@@ -7,6 +7,7 @@
 namespace {
 struct Rec { std::string name; hipEvent_t e0, e1; double flops, bytes; };
 bool g_on = false;
+std::string g_filter;   // empty = every profiled launch
 std::vector<Rec> g_recs;
 std::vector<hipEvent_t> g_pool;
 hipEvent_t get_event() {
@@ -17,7 +18,7 @@ hipEvent_t get_event() {
 }
 }  // namespace
 
-bool prof_on() { return g_on; }
+bool prof_on(const char* name) { return g_on && (g_filter.empty() || g_filter == name); }
 void prof_begin(const char* name, double flops, double bytes, hipStream_t s) {
   Rec r;
   r.name = name; r.flops = flops; r.bytes = bytes;
@@ -29,6 +30,10 @@ void prof_end(hipStream_t s) { HIP_CHECK(hipEventRecord(g_recs.back().e1, s)); }
 
 extern "C" int ldiff_prof_enable(int on) {
   g_on = on != 0;
+  return LDIFF_OK;
+}
+extern "C" int ldiff_prof_set_filter(const char* kernel_name_or_null) {
+  g_filter = kernel_name_or_null ? kernel_name_or_null : "";
   return LDIFF_OK;
 }
 extern "C" int ldiff_prof_collect(ldiff_prof_row* rows, int cap) {

@@ -109,15 +109,15 @@ except ValueError:
     pass
 dist.barrier()
 dist.destroy_process_group()
-print("rank", rank, "ok")
+open(os.path.join({out!r}, "rank%d.ok" % rank), "w").write("ok")   # one file per rank: the two stdouts interleave
 """
 
 
 def test_gather_masks_world_size_2_gloo(tmp_path):
     script = tmp_path / "worker.py"
-    script.write_text(_WORKER.format(root=ROOT))
+    script.write_text(_WORKER.format(root=ROOT, out=str(tmp_path)))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
            "--master-port", "29541", str(script)]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=240, env=dict(os.environ, OMP_NUM_THREADS="1"))
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    assert "rank 0 ok" in r.stdout and "rank 1 ok" in r.stdout
+    assert (tmp_path / "rank0.ok").exists() and (tmp_path / "rank1.ok").exists(), r.stdout[-2000:] + r.stderr[-2000:]

@@ -36,6 +36,12 @@ SHAPES = {
     "lin_L0_ff1_320_2560": (1, 320, 0, 1, 32768, 2560, 1, 1, 0, 0),
     "lin_L0_ff2_1280_320": (1, 1280, 0, 1, 32768, 320, 1, 1, 0, 0),
     "lin_L1_ff1_640_5120": (1, 640, 0, 1, 8192, 5120, 1, 1, 0, 0),
+    "lin_L1_qkv_640_1920": (1, 640, 0, 1, 8192, 1920, 1, 1, 0, 0),
+    "lin_L1_out_640_640": (1, 640, 0, 1, 8192, 640, 1, 1, 0, 0),
+    "lin_L1_ff2_2560_640": (1, 2560, 0, 1, 8192, 640, 1, 1, 0, 0),
+    "lin_L2_qkv_1280_3840": (1, 1280, 0, 1, 2048, 3840, 1, 1, 0, 0),
+    "lin_L2_out_1280_1280": (1, 1280, 0, 1, 2048, 1280, 1, 1, 0, 0),
+    "lin_L0_out_320_320": (1, 320, 0, 1, 32768, 320, 1, 1, 0, 0),
     "lin_L2_ff1_1280_10240": (1, 1280, 0, 1, 2048, 10240, 1, 1, 0, 0),
     "lin_L2_ff2_5120_1280": (1, 5120, 0, 1, 2048, 1280, 1, 1, 0, 0),
     "conv1x1_L0_320_320_gn": (8, 320, 0, 64, 64, 320, 1, 1, 0, 1),

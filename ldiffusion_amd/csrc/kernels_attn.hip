@@ -245,6 +245,248 @@ static void launch_attn_cfg(const AttnParams& p, hipStream_t s) {
   HIP_CHECK(hipGetLastError());
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Large head dims (the VAE mid block: one head of 512): "d-split" variant.  The generic kernel gives every wave 16 queries
+// and the whole head dim, so each wave re-reads the complete K and V tiles from LDS (1 KiB of LDS per MFMA: the LDS array,
+// not the matrix pipe, bounds it at ~215 TFLOP/s).  Here a workgroup still owns 64 queries, but
+//   * S^T = K Q^T and the online softmax stay per wave on 16 queries (all 32 keys of the step);
+//   * the probabilities (fp16) and the rescale factors go through LDS once;
+//   * O^T += V^T P^T is split over the HEAD DIM: wave w accumulates d in [128w, 128w+128) for all 64 queries, so every
+//     V^T fragment read from LDS feeds four MFMAs (one per query tile) and a wave reads a quarter of the V tile.
+// LDS per wave and step: 32 KiB of K + 8 KiB of V + 4 KiB of P for 64 MFMAs (0.69 KiB per MFMA).
+
+// Hand-scheduled LDS fetches for the d-split kernel (one wave per SIMD: nothing else hides an LDS round trip).  hipcc emits
+// "ds_read; s_waitcnt lgkmcnt(0); v_mfma" per fragment, i.e. 32 exposed round trips per tile in S^T = K Q^T alone; the reads
+// are therefore issued in batches as inline asm and waited for with counted lgkmcnt (the wait names its fragment as an
+// in/out operand so the consuming MFMA cannot move above it).
+template <int I, int N, class F>
+__device__ __forceinline__ void attn_static_for(F&& f) {
+  if constexpr (I < N) { f(std::integral_constant<int, I>{}); attn_static_for<I + 1, N>(f); }
+}
+template <int OFF>
+__device__ __forceinline__ void attn_lds_read128(f16x8& d, unsigned addr) {
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF) : "memory");
+}
+template <int OFF>
+__device__ __forceinline__ void attn_lds_read_tr(f16x4& d, unsigned addr) {
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF) : "memory");
+}
+template <int CNT>
+__device__ __forceinline__ void attn_lds_wait(f16x8& a) { asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(a) : "n"(CNT)); }
+template <int CNT>
+__device__ __forceinline__ void attn_lds_wait(f16x4& a, f16x4& b) { asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "n"(CNT)); }
+
+template <int BKV>
+__global__ __launch_bounds__(256, 1) void attn_dsplit_kernel(const AttnParams p) {
+  constexpr int D = 512, KS = D / 32, NT = BKV / 16, DTW = 8, PSTR = BKV * 2 + 16;   // P row stride in bytes (16-B aligned, odd multiple of 16)
+  static_assert(BKV == 32, "one 32-key MFMA step per tile");
+  using KL = KLayout<D>;
+  constexpr int VSTR = VLayout<D>::STR_DW;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  uint4* sK = reinterpret_cast<uint4*>(smem_raw);                        // [BKV][KL::STR] chunks
+  unsigned* sV = reinterpret_cast<unsigned*>(sK + BKV * KL::STR);        // [BKV][VSTR] dwords
+  unsigned char* sP = reinterpret_cast<unsigned char*>(sV + BKV * VSTR); // [64][PSTR] bytes: P[q][key] fp16
+  float* sAl = reinterpret_cast<float*>(sP + 64 * PSTR);                 // [64] rescale factor of the step / final row sums
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = lane >> 4, l15 = lane & 15;
+  // XCD-aware order over the linearised (query block, head, batch) grid: the workgroups sharing an XCD (blockIdx % 8) take a
+  // contiguous range, i.e. the query blocks of ONE (batch, head) at a time, and stream its K/V (8 MB at 4,096 tokens: twice
+  // the 4 MB L2 of an XCD) roughly in step, so a tile is fetched from HBM once per XCD instead of once per workgroup
+  // (measured before: 4.7 TB/s of K/V re-reads, the kernel was HBM-bound).
+  const int nqb = (p.Lq + 63) / 64, nwg = gridDim.x, id = blockIdx.x;
+  const int q8 = nwg >> 3, r8 = nwg & 7, xcd = id & 7, idx = id >> 3;
+  int sw = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
+  const int qb = sw % nqb; sw /= nqb;
+  const int h = sw % p.heads, b = sw / p.heads;
+  const int d = p.d;
+  const int q0 = qb * 64, qown = q0 + wave * 16 + l15;   // this lane's query in the softmax phase
+
+  const f16* Qp = p.q + (long long)b * p.q_bstride + h * d;
+  const f16* Kp = p.k + (long long)b * p.kv_bstride + h * d;
+  const f16* Vp = p.v + (long long)b * p.kv_bstride + h * d;
+
+  f16x8 qf[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    const int dd = ks * 32 + g * 8;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (qown < p.Lq && dd < d) v = *reinterpret_cast<const uint4*>(Qp + (long long)qown * p.ldq + dd);
+    qf[ks] = __builtin_bit_cast(f16x8, v);
+  }
+  f32x4 oacc[4][DTW];   // [query tile][d tile of this wave's slice]
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int dt = 0; dt < DTW; ++dt) oacc[j][dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float mrun = -1e30f, lrun = 0.f;
+  const float sl2 = p.scale * 1.4426950408889634f;
+  typedef __attribute__((address_space(3))) void lds_void;
+  const unsigned lds0 = (unsigned)(size_t)(lds_void*)smem_raw;
+  const unsigned kbase = lds0 + (unsigned)(l15 * 1024 + ((g ^ l15) << 4));                       // K fragment, tile 0, k-step 0
+  const unsigned vbase = lds0 + (unsigned)(BKV * KL::STR * 16 + ((g * 8 + (l15 >> 2)) * VSTR + wave * DTW * 8 + (l15 & 3) * 2) * 4);   // V^T fragment, d tile 0
+
+  constexpr int KCH = BKV * (D / 8), KIT = KCH / 256;
+  // K and V tiles are prefetched global -> registers one tile ahead (issued right after the previous tile went to LDS, so
+  // the loads fly under this tile's MFMA / softmax work) and written to LDS after the next barrier
+  uint4 rk[KIT], rv[KIT];
+  auto load_k = [&](int kv0) {
+#pragma unroll
+    for (int i = 0; i < KIT; ++i) {
+      const int c = tid + i * 256, row = c / (D / 8), ch = c - row * (D / 8);
+      uint4 v = make_uint4(0, 0, 0, 0), u = make_uint4(0, 0, 0, 0);
+      if (kv0 + row < p.Lk && ch * 8 < d) {
+        v = *reinterpret_cast<const uint4*>(Kp + (long long)(kv0 + row) * p.ldk + ch * 8);
+        u = *reinterpret_cast<const uint4*>(Vp + (long long)(kv0 + row) * p.ldv + ch * 8);
+      }
+      rk[i] = v; rv[i] = u;
+    }
+  };
+  auto store_kv = [&](int kv0) {
+#pragma unroll
+    for (int i = 0; i < KIT; ++i) {
+      const int c = tid + i * 256, row = c / (D / 8), ch = c - row * (D / 8);
+      sK[KL::off(row, ch)] = rk[i];
+      *reinterpret_cast<uint4*>(sV + row * VSTR + ch * 4) = rv[i];
+    }
+  };
+  load_k(0);
+
+  auto tile = [&](int kv0, auto TAILC) {
+    constexpr bool TAIL = decltype(TAILC)::value;
+    __syncthreads();   // previous tile fully consumed (K, V, P, alpha)
+    store_kv(kv0);
+    __syncthreads();
+    if (kv0 + BKV < p.Lk) load_k(kv0 + BKV);
+
+    // ---- S^T = K Q^T for this wave's 16 queries: K fragments in batches of 8 reads, counted waits ----
+    // K[row = 16t + l15][chunk 4ks + g] sits at chunk position (4ks + g) ^ l15 = (g ^ l15) ^ 4ks: byte address = kbase ^ 64ks
+    f32x4 sacc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) sacc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    attn_static_for<0, NT * KS / 8>([&](auto bc) {
+      constexpr int t = decltype(bc)::value / (KS / 8), k0 = (decltype(bc)::value % (KS / 8)) * 8;
+      f16x8 kf[8];
+      attn_static_for<0, 8>([&](auto ic) { constexpr int i = decltype(ic)::value; attn_lds_read128<t * 16 * 1024>(kf[i], kbase ^ (unsigned)((k0 + i) * 64)); });
+      attn_static_for<0, 8>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        attn_lds_wait<7 - i>(kf[i]);
+        sacc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[i], qf[k0 + i], sacc[t], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      });
+    });
+    // ---- online softmax (lane: query l15, keys 16t + 4g + r); P and alpha to LDS ----
+    if (TAIL) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (kv0 + t * 16 + g * 4 + r >= p.Lk) sacc[t][r] = -1e30f;
+    }
+    float mx = -1e30f;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) mx = fmaxf(mx, sacc[t][r]);
+    mx = fmaxf(mx, __shfl_xor(mx, 16));
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    const float mnew = fmaxf(mrun, mx);
+    const float alpha = __builtin_amdgcn_exp2f((mrun - mnew) * sl2);
+    const float moff = -mnew * sl2;
+    float rs = 0.f;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      f16x4 ph;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float pv = __builtin_amdgcn_exp2f(fmaf(sacc[t][r], sl2, moff));
+        rs += pv;
+        ph[r] = (f16)pv;
+      }
+      *reinterpret_cast<f16x4*>(sP + (wave * 16 + l15) * PSTR + (t * 16 + g * 4) * 2) = ph;   // P[q][key], keys in natural order
+    }
+    rs += __shfl_xor(rs, 16);
+    rs += __shfl_xor(rs, 32);
+    lrun = lrun * alpha + rs;
+    mrun = mnew;
+    if (g == 0) sAl[wave * 16 + l15] = alpha;
+    __syncthreads();
+
+    // ---- O^T[d slice of this wave][64 queries] = alpha * O^T + V^T P^T ----
+    // The rescale is skipped (exactly: alpha == 1 means the running maximum did not move) unless some query of the workgroup
+    // raised its maximum in this step; after the first tiles that is rare.
+    f16x8 pf[4];
+    float al[4];
+    bool moved = false;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      al[j] = sAl[j * 16 + l15];
+      moved |= al[j] != 1.0f;
+      pf[j] = *reinterpret_cast<const f16x8*>(sP + (j * 16 + l15) * PSTR + g * 16);   // B operand: query 16j+l15, keys 8g..8g+7
+    }
+    if (__builtin_amdgcn_ballot_w64(moved) != 0) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int dt = 0; dt < DTW; ++dt) { oacc[j][dt][0] *= al[j]; oacc[j][dt][1] *= al[j]; oacc[j][dt][2] *= al[j]; oacc[j][dt][3] *= al[j]; }
+    }
+    // V^T fragments: all 16 transposed reads of the step are issued first (lane 4q+p of its 16-lane group addresses key row
+    // 8g+q (+4), d columns 4p..4p+3 of d tile dt), then 8 x 4 MFMAs with counted waits
+    f16x4 vlo[DTW], vhi[DTW];
+    attn_static_for<0, DTW>([&](auto dc) {
+      constexpr int dt = decltype(dc)::value;
+      attn_lds_read_tr<dt * 32>(vlo[dt], vbase);                    // keys 8g .. 8g+3
+      attn_lds_read_tr<dt * 32 + 4 * VSTR * 4>(vhi[dt], vbase);     // keys 8g+4 .. 8g+7
+    });
+    attn_static_for<0, DTW>([&](auto dc) {
+      constexpr int dt = decltype(dc)::value;
+      attn_lds_wait<2 * (DTW - 1 - dt)>(vlo[dt], vhi[dt]);
+      const f16x8 vf = {vlo[dt][0], vlo[dt][1], vlo[dt][2], vlo[dt][3], vhi[dt][0], vhi[dt][1], vhi[dt][2], vhi[dt][3]};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) oacc[j][dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf[j], oacc[j][dt], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    });
+  };
+  const int full = p.Lk / BKV * BKV;
+  for (int kv0 = 0; kv0 < full; kv0 += BKV) tile(kv0, std::false_type());
+  if (full < p.Lk) tile(full, std::true_type());
+
+  // ---- normalise and store: lane holds O[q = 16j + l15][dd = 128 wave + 16 dt + 4g + r] ----
+  __syncthreads();
+  if (g == 0) sAl[wave * 16 + l15] = lrun;
+  __syncthreads();
+  f16* Op = p.o + (long long)b * p.o_bstride + h * d;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int qi = q0 + j * 16 + l15;
+    const float inv = 1.0f / sAl[j * 16 + l15];
+#pragma unroll
+    for (int dt = 0; dt < DTW; ++dt) {
+      const int dd = (wave * DTW + dt) * 16 + g * 4;
+      if (qi < p.Lq && dd < d) {
+        const f16x4 o = {(f16)(oacc[j][dt][0] * inv), (f16)(oacc[j][dt][1] * inv), (f16)(oacc[j][dt][2] * inv), (f16)(oacc[j][dt][3] * inv)};
+        *reinterpret_cast<f16x4*>(Op + (long long)qi * p.ldo + dd) = o;
+      }
+    }
+  }
+}
+
+static void launch_attn_dsplit(const AttnParams& p, hipStream_t s) {
+  constexpr int BKV = 32;
+  static bool attr_set = false;
+  const size_t smem = (size_t)BKV * KLayout<512>::STR * 16 + (size_t)BKV * VLayout<512>::STR_DW * 4 + 64 * (BKV * 2 + 16) + 64 * 4;
+  auto kern = attn_dsplit_kernel<BKV>;
+  if (!attr_set) {
+    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    attr_set = true;
+  }
+  dim3 grid(((p.Lq + 63) / 64) * p.heads * p.B);
+  const double bh = (double)p.B * p.heads;
+  ProfScope prof("attn<512,512>", 4.0 * bh * p.Lq * p.Lk * p.d, 2.0 * bh * p.d * (2.0 * p.Lq + 2.0 * p.Lk * (p.kv_bstride ? 1.0 : 1.0 / p.B)), s);
+  hipLaunchKernelGGL(kern, grid, dim3(256), smem, s, p);
+  HIP_CHECK(hipGetLastError());
+}
+
 void launch_attention(const AttnParams& p, hipStream_t s) {
   LDIFF_CHECK(p.d % 8 == 0 && p.d > 0 && p.d <= 512, LDIFF_ERR_INVALID, "attention: head dim %d must be a multiple of 8 and <= 512", p.d);
   LDIFF_CHECK(p.ldq % 8 == 0 && p.ldk % 8 == 0 && p.ldv % 8 == 0 && p.ldo % 4 == 0, LDIFF_ERR_INVALID, "attention: row strides must be multiples of 8");
@@ -258,5 +500,5 @@ void launch_attention(const AttnParams& p, hipStream_t s) {
   else if (d <= 96) launch_attn_cfg<96, 96, 64, 2>(p, s);
   else if (d <= 128) launch_attn_cfg<128, 128, 64, 2, 1>(p, s);
   else if (d <= 160) launch_attn_cfg<160, 160, 64, 2, 1>(p, s);
-  else launch_attn_cfg<512, 512, 32, 1, 1>(p, s);
+  else launch_attn_dsplit(p, s);
 }

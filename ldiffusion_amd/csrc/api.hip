@@ -174,7 +174,17 @@ int ldiff_pipeline_create(ldiff_pipeline** out, ldiff_unet* u, ldiff_vae* v) {
   p->unet = u;
   p->vae = v;
   pndm_alphas_cumprod(p->abar);
+  HIP_CHECK(hipSetDevice(u->device));
+  HIP_CHECK(hipStreamCreateWithFlags(&p->decode_stream, hipStreamNonBlocking));   // (stream priorities made no difference: 46.1-46.3 patches/s)
+  HIP_CHECK(hipEventCreateWithFlags(&p->ev_latents, hipEventDisableTiming));
+  HIP_CHECK(hipEventCreateWithFlags(&p->ev_decoded, hipEventDisableTiming));
   *out = p;
+  API_END
+}
+int ldiff_pipeline_set_overlap(ldiff_pipeline* p, int on) {
+  API_BEGIN
+  LDIFF_CHECK(p, LDIFF_ERR_INVALID, "set_overlap: null pipeline");
+  p->overlap = on != 0;
   API_END
 }
 int ldiff_pipeline_set_alphas_cumprod(ldiff_pipeline* p, const float* abar_host, int n) {
@@ -202,8 +212,8 @@ int ldiff_sample(ldiff_pipeline* p, const void* images, int B, int H, int W, int
   LDIFF_CHECK(B >= 1 && H >= f && W >= f && H % f == 0 && W % f == 0, LDIFF_ERR_INVALID, "sample: bad batch/image size (B=%d, %dx%d)", B, H, W);
   const int h = H / f, w = W / f;
   const size_t nlat = (size_t)B * lat * h * w;
-  // workspace: moments (2x), latents ping-pong (2), cur_sample, eps history (4), fresh eps
-  p->arena.reserve((2 + 2 + 1 + 4 + 1) * nlat * sizeof(float) + 16 * 256);
+  // workspace: moments (2x), latents ping-pong (2), cur_sample, eps history (4), fresh eps, one latent snapshot per pass
+  p->arena.reserve((2 + 2 + 1 + 4 + 1 + (size_t)nts) * nlat * sizeof(float) + (16 + (size_t)nts) * 256);
   p->arena.reset();
   auto buf = [&]() { return (float*)p->arena.alloc(nlat * sizeof(float)); };
   float* moments = (float*)p->arena.alloc(2 * nlat * sizeof(float));
@@ -217,6 +227,14 @@ int ldiff_sample(ldiff_pipeline* p, const void* images, int B, int H, int W, int
   v->ex.arena.reset();
   v->encode((const float*)images, B, H, W, moments, s);
   HIP_CHECK(hipMemcpy2DAsync(z, (size_t)lat * h * w * 4, moments, (size_t)2 * lat * h * w * 4, (size_t)lat * h * w * 4, B, hipMemcpyDeviceToDevice, s));
+
+  // Two streams: the UNet / PLMS chain stays on the caller's stream; the VAE decode of pass k (it only feeds the feature
+  // tensor, nothing downstream in the loop) runs on the pipeline's side stream beside the UNet pass k+1, whose deep levels
+  // (16x16 / 8x8 maps: tens of workgroups per launch) leave most CUs idle.  Each decode reads its own snapshot of the
+  // latents, so the chain never waits for it; the caller's stream joins the side stream before returning.
+  const bool overlap = p->overlap;
+  hipStream_t sd = overlap ? p->decode_stream : s;
+  bool decoded_any = false;
 
   const int n_sched = n_passes == 1 ? 1 : n_passes - 1;
   const int ratio = 1000 / n_sched;
@@ -273,9 +291,22 @@ int ldiff_sample(ldiff_pipeline* p, const void* images, int B, int H, int W, int
     // ---- decode_latents + numpy_to_pil + convert("L") ----
     const bool last = i == nts - 1;
     if (features_u8 || (last && rgb_u8)) {
-      v->ex.arena.reset();
-      v->decode(z, B, h, w, 1.0f / v->cfg.scaling_factor, nullptr, nullptr, last ? (uint8_t*)rgb_u8 : nullptr, (uint8_t*)features_u8, nts, i, s);
+      const float* zdec = z;
+      if (overlap) {
+        float* snap = buf();
+        HIP_CHECK(hipMemcpyAsync(snap, z, nlat * sizeof(float), hipMemcpyDeviceToDevice, s));
+        HIP_CHECK(hipEventRecord(p->ev_latents, s));
+        HIP_CHECK(hipStreamWaitEvent(sd, p->ev_latents, 0));   // also orders the first decode behind the encode (same VAE workspace)
+        zdec = snap;
+      }
+      v->ex.arena.reset();   // all decodes run on one stream: the workspace is reused in stream order
+      v->decode(zdec, B, h, w, 1.0f / v->cfg.scaling_factor, nullptr, nullptr, last ? (uint8_t*)rgb_u8 : nullptr, (uint8_t*)features_u8, nts, i, sd);
+      decoded_any = true;
     }
+  }
+  if (overlap && decoded_any) {
+    HIP_CHECK(hipEventRecord(p->ev_decoded, sd));
+    HIP_CHECK(hipStreamWaitEvent(s, p->ev_decoded, 0));
   }
   if (latents_out) HIP_CHECK(hipMemcpyAsync(latents_out, z, nlat * sizeof(float), hipMemcpyDeviceToDevice, s));
   API_END
@@ -283,6 +314,9 @@ int ldiff_sample(ldiff_pipeline* p, const void* images, int B, int H, int W, int
 void ldiff_pipeline_destroy(ldiff_pipeline* p) {
   if (!p) return;
   (void)hipDeviceSynchronize();
+  if (p->ev_latents) (void)hipEventDestroy(p->ev_latents);
+  if (p->ev_decoded) (void)hipEventDestroy(p->ev_decoded);
+  if (p->decode_stream) (void)hipStreamDestroy(p->decode_stream);
   delete p;
 }
 

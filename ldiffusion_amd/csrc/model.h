@@ -161,6 +161,10 @@ struct ldiff_pipeline {
   ldiff_vae* vae;
   Arena arena;   // latents / eps history
   float abar[1000];
+  // decode side stream: the VAE decode of pass k (needed only for the features) runs beside the UNet pass k+1
+  bool overlap = true;
+  hipStream_t decode_stream = nullptr;
+  hipEvent_t ev_latents = nullptr, ev_decoded = nullptr;
 };
 
 void pndm_alphas_cumprod(float* out1000);

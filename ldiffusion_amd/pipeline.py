@@ -79,6 +79,10 @@ class LaplaceSampler:
         abar = pipeline.scheduler.alphas_cumprod.detach().to("cpu", torch.float32).contiguous()
         _lib.check(self._lib.ldiff_pipeline_set_alphas_cumprod(self._h, C.cast(abar.data_ptr(), C.POINTER(C.c_float)), abar.numel()))
 
+    def set_overlap(self, on: bool):
+        """VAE decode of pass k on a side stream beside the UNet pass k+1 (default on; identical results either way)."""
+        _lib.check(self._lib.ldiff_pipeline_set_overlap(self._h, 1 if on else 0))
+
     def timesteps(self, num_inference_steps: int):
         buf = (C.c_int64 * 1024)()
         n = self._lib.ldiff_plms_timesteps(int(num_inference_steps), buf, 1024)

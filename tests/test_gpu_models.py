@@ -345,3 +345,20 @@ def test_one_pass_1024_roi_against_oracle(tiny):
     print(f"1024^2 one pass: latents rel err {e:.3e}; rgb max diff {rd.max()} (>1: {(rd > 1).mean():.5f})")
     assert out["rgb"].shape == (1, 1024, 1024, 3) or out["rgb"].shape[1:3] == (1024, 1024)
     assert e < 2e-2 and (rd > 1).mean() < 0.01
+
+
+def test_decode_side_stream_changes_nothing(tiny):
+    """ldiff_sample with the VAE decodes on the side stream (default) == everything on the caller's stream, bit for bit, and
+    back-to-back calls on one pipeline do not race on the shared VAE workspace."""
+    g = torch.Generator().manual_seed(11)
+    x = torch.rand((3, 3, 64, 64), generator=g).to(DEV)
+    ctx = (torch.randn((1, 6, 64), generator=g) * 0.5).to(DEV)
+    s = LaplaceSampler(tiny["pipe"])
+    a1 = s.sample(x, ctx, 6)
+    a2 = s.sample(x, ctx, 6)          # immediately again: the next encode must wait for the previous decodes
+    s.set_overlap(False)
+    b = s.sample(x, ctx, 6)
+    s.set_overlap(True)
+    torch.cuda.synchronize()
+    for k in ("latents", "features", "rgb"):
+        assert torch.equal(a1[k], b[k]) and torch.equal(a2[k], b[k]), k

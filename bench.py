@@ -139,11 +139,21 @@ def main():
     head_w = (torch.randn((N_CLASSES, N_PASSES), generator=hg) / N_PASSES ** 0.5).to(dev)  # stand-in for the out-of-scope segmentor head
     head_b = (0.1 * torch.randn(N_CLASSES, generator=hg)).to(dev)
 
-    def step():
-        out = sampler.sample(images, ctx, N_PASSES, want_features=True, want_rgb=True)
+    def finish(out):
         logits = torch.einsum("cn,bnhw->bchw", head_w, out["features"].float() * (1.0 / 255.0)) + head_b[None, :, None, None]
         mask = argmax_mask(logits)
         return gather_masks(mask, total) if world > 1 else mask
+
+    def step():
+        return finish(sampler.sample(images, ctx, N_PASSES, want_features=True, want_rgb=True))
+
+    def run_steps(n):
+        # (Deferring the side-stream join across batches -- ldiff_pipeline_set_overlap mode 2, batch k+1 enqueued before batch k
+        # is joined -- was measured at +0.5-0.9 % and is not used here: every step joins its own decodes.)
+        m = None
+        for _ in range(n):
+            m = step()
+        return m
 
     def sync():
         if dist is not None:
@@ -152,8 +162,7 @@ def main():
 
     prof = not args.no_prof
     lib = _lib.load()
-    for _ in range(max(args.warmup - 1, 0)):
-        step()
+    run_steps(max(args.warmup - 1, 0))
     # Per-launch HIP events on every contraction launch cost ~6 % of a step, so the full per-kernel table comes from one
     # untimed step (the last warm-up step, or an extra one when --warmup 0), and inside the timed region only the launches
     # of the dominant kernel found there carry events (260 of ~3,000 launches per step): its average launch duration is
@@ -163,14 +172,14 @@ def main():
     # durations are stretched by the sharing and say less about the kernel.
     rows_all = []
     if prof:
-        sampler.set_overlap(False)
+        sampler.set_overlap(0)
         lib.ldiff_prof_set_filter(None)
         lib.ldiff_prof_enable(1)
         step()
         torch.cuda.synchronize()
         lib.ldiff_prof_enable(0)
         rows_all = _lib.prof_collect()
-        sampler.set_overlap(True)
+        sampler.set_overlap(1)
         lib.ldiff_prof_set_filter(max(rows_all, key=lambda r: r["ms"])["name"].encode())
     elif args.warmup > 0:
         step()
@@ -178,8 +187,7 @@ def main():
     if prof:
         lib.ldiff_prof_enable(1)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        masks = step()
+    masks = run_steps(args.steps)
     sync()
     elapsed = time.perf_counter() - t0
     lib.ldiff_prof_enable(0)

@@ -131,10 +131,14 @@ int ldiff_pipeline_create(ldiff_pipeline** out, ldiff_unet*, ldiff_vae*); /* bor
 /* Replace the built-in alphas_cumprod table (1000 float32, host) with the caller's scheduler.alphas_cumprod
  * (ldiffusion.py:198,234 reads that attribute); the built-in one agrees with torch's to ~2 ulp. */
 int ldiff_pipeline_set_alphas_cumprod(ldiff_pipeline*, const float* abar_host, int n);
-/* ldiff_sample runs the VAE decode of pass k (it only feeds the feature tensor) on a side stream beside the UNet pass k+1
- * (+7 % patches/s: the UNet's 16x16 / 8x8 levels leave most CUs idle); on = 0 keeps everything on the caller's stream
- * (results are identical; per-kernel timings are only meaningful that way). Default: on. */
-int ldiff_pipeline_set_overlap(ldiff_pipeline*, int on);
+/* ldiff_sample runs the VAE decode of pass k (it only feeds the feature tensor) on the VAE's side stream beside the UNet
+ * pass k+1 (+7 % patches/s: the UNet's 16x16 / 8x8 levels leave most CUs idle).  mode 0: everything on the caller's stream;
+ * mode 1 (default): side stream, the caller's stream joins before ldiff_sample returns; mode 2: side stream, join deferred:
+ * features / rgb of that call may only be read after ldiff_pipeline_join(p, stream) -- with two pipelines on the same
+ * unet/vae used alternately, the encoder and UNet passes of batch k+1 then run under the trailing decodes of batch k.
+ * Results are bit-identical in all modes. */
+int ldiff_pipeline_set_overlap(ldiff_pipeline*, int mode);
+int ldiff_pipeline_join(ldiff_pipeline*, void* stream);
 /* images [B,3,H,W] f32.  n_passes = number of UNet passes N (set_timesteps(N-1) for N >= 3, set_timesteps(1) for N = 1;
  * N = 2 is rejected: the reference's set_timesteps(1) then yields a single pass, pixel_latent_vector.py:74).
  * Outputs (any may be NULL): latents_out [B,latent,H/8,W/8] f32 (after the last pass),

@@ -65,6 +65,7 @@ SIGNATURES = {
     "ldiff_pipeline_create": (I, [C.POINTER(P), P, P]),
     "ldiff_pipeline_set_alphas_cumprod": (I, [P, C.POINTER(F), I]),
     "ldiff_pipeline_set_overlap": (I, [P, I]),
+    "ldiff_pipeline_join": (I, [P, P]),
     "ldiff_sample": (I, [P, P, I, I, I, I, P, P, P, P]),
     "ldiff_plms_timesteps": (I, [I, C.POINTER(I64), I]),
     "ldiff_pipeline_destroy": (None, [P]),

@@ -95,7 +95,6 @@ const char* ldiff_vae_missing_name(ldiff_vae* v, int i) { return v ? v->ws.missi
 int ldiff_vae_encode(ldiff_vae* v, const void* x_dev, int B, int H, int W, void* moments_dev, void* stream) {
   API_BEGIN
   LDIFF_CHECK(v, LDIFF_ERR_INVALID, "vae_encode: null handle");
-  v->ex.arena.reset();
   v->encode((const float*)x_dev, B, H, W, (float*)moments_dev, (hipStream_t)stream);
   API_END
 }
@@ -103,7 +102,7 @@ int ldiff_vae_decode(ldiff_vae* v, const void* z_dev, int B, int h, int w, float
                      void* luma_u8, int n_slots, int slot, void* stream) {
   API_BEGIN
   LDIFF_CHECK(v, LDIFF_ERR_INVALID, "vae_decode: null handle");
-  v->ex.arena.reset();
+  v->wait_side((hipStream_t)stream);   // a sampler with a deferred join may still be decoding on the side stream (same workspace)
   v->decode((const float*)z_dev, B, h, w, z_scale, (float*)sample_nchw, (float*)image_nhwc, (uint8_t*)rgb_u8, (uint8_t*)luma_u8, n_slots, slot,
             (hipStream_t)stream);
   API_END
@@ -112,6 +111,8 @@ void ldiff_vae_destroy(ldiff_vae* v) {
   if (!v) return;
   (void)hipSetDevice(v->device);
   (void)hipDeviceSynchronize();
+  if (v->ev_side) (void)hipEventDestroy(v->ev_side);
+  if (v->side_stream) (void)hipStreamDestroy(v->side_stream);
   delete v;
 }
 
@@ -175,16 +176,30 @@ int ldiff_pipeline_create(ldiff_pipeline** out, ldiff_unet* u, ldiff_vae* v) {
   p->vae = v;
   pndm_alphas_cumprod(p->abar);
   HIP_CHECK(hipSetDevice(u->device));
-  HIP_CHECK(hipStreamCreateWithFlags(&p->decode_stream, hipStreamNonBlocking));   // (stream priorities made no difference: 46.1-46.3 patches/s)
+  if (!v->side_stream) {   // one side stream per VAE: all feature-only decodes of all samplers on it serialise (one decoder workspace)
+    HIP_CHECK(hipStreamCreateWithFlags(&v->side_stream, hipStreamNonBlocking));   // (stream priorities made no difference: 46.1-46.3 patches/s)
+    HIP_CHECK(hipEventCreateWithFlags(&v->ev_side, hipEventDisableTiming));
+  }
   HIP_CHECK(hipEventCreateWithFlags(&p->ev_latents, hipEventDisableTiming));
   HIP_CHECK(hipEventCreateWithFlags(&p->ev_decoded, hipEventDisableTiming));
   *out = p;
   API_END
 }
-int ldiff_pipeline_set_overlap(ldiff_pipeline* p, int on) {
+int ldiff_pipeline_set_overlap(ldiff_pipeline* p, int mode) {
   API_BEGIN
-  LDIFF_CHECK(p, LDIFF_ERR_INVALID, "set_overlap: null pipeline");
-  p->overlap = on != 0;
+  LDIFF_CHECK(p && mode >= 0 && mode <= 2, LDIFF_ERR_INVALID, "set_overlap: mode must be 0, 1 or 2");
+  LDIFF_CHECK(!p->join_pending, LDIFF_ERR_STATE, "set_overlap: a deferred join is pending; call ldiff_pipeline_join first");
+  p->overlap = mode;
+  API_END
+}
+int ldiff_pipeline_join(ldiff_pipeline* p, void* stream) {
+  API_BEGIN
+  LDIFF_CHECK(p, LDIFF_ERR_INVALID, "join: null pipeline");
+  if (p->join_pending) {
+    HIP_CHECK(hipSetDevice(p->unet->device));
+    HIP_CHECK(hipStreamWaitEvent((hipStream_t)stream, p->ev_decoded, 0));
+    p->join_pending = false;
+  }
   API_END
 }
 int ldiff_pipeline_set_alphas_cumprod(ldiff_pipeline* p, const float* abar_host, int n) {
@@ -223,8 +238,10 @@ int ldiff_sample(ldiff_pipeline* p, const void* images, int B, int H, int W, int
   float* ets[4] = {buf(), buf(), buf(), buf()};
   float* eps_new = buf();
 
+  // this pipeline's previous call may still be decoding from its latent snapshots (deferred join): its buffers are reused now
+  if (p->join_pending) { HIP_CHECK(hipStreamWaitEvent(s, p->ev_decoded, 0)); p->join_pending = false; }
+  if (p->overlap == 0) v->wait_side(s);   // decodes on the caller's stream share the decoder workspace with the side stream
   // z = vae.encode(x).latent_dist.mean   (no scaling_factor: pixel_latent_vector.py:73)
-  v->ex.arena.reset();
   v->encode((const float*)images, B, H, W, moments, s);
   HIP_CHECK(hipMemcpy2DAsync(z, (size_t)lat * h * w * 4, moments, (size_t)2 * lat * h * w * 4, (size_t)lat * h * w * 4, B, hipMemcpyDeviceToDevice, s));
 
@@ -232,8 +249,8 @@ int ldiff_sample(ldiff_pipeline* p, const void* images, int B, int H, int W, int
   // tensor, nothing downstream in the loop) runs on the pipeline's side stream beside the UNet pass k+1, whose deep levels
   // (16x16 / 8x8 maps: tens of workgroups per launch) leave most CUs idle.  Each decode reads its own snapshot of the
   // latents, so the chain never waits for it; the caller's stream joins the side stream before returning.
-  const bool overlap = p->overlap;
-  hipStream_t sd = overlap ? p->decode_stream : s;
+  const bool overlap = p->overlap != 0;
+  hipStream_t sd = overlap ? v->side_stream : s;
   bool decoded_any = false;
 
   const int n_sched = n_passes == 1 ? 1 : n_passes - 1;
@@ -299,14 +316,16 @@ int ldiff_sample(ldiff_pipeline* p, const void* images, int B, int H, int W, int
         HIP_CHECK(hipStreamWaitEvent(sd, p->ev_latents, 0));   // also orders the first decode behind the encode (same VAE workspace)
         zdec = snap;
       }
-      v->ex.arena.reset();   // all decodes run on one stream: the workspace is reused in stream order
       v->decode(zdec, B, h, w, 1.0f / v->cfg.scaling_factor, nullptr, nullptr, last ? (uint8_t*)rgb_u8 : nullptr, (uint8_t*)features_u8, nts, i, sd);
       decoded_any = true;
     }
   }
   if (overlap && decoded_any) {
     HIP_CHECK(hipEventRecord(p->ev_decoded, sd));
-    HIP_CHECK(hipStreamWaitEvent(s, p->ev_decoded, 0));
+    HIP_CHECK(hipEventRecord(v->ev_side, sd));
+    v->side_used = true;
+    if (p->overlap == 1) HIP_CHECK(hipStreamWaitEvent(s, p->ev_decoded, 0));
+    else p->join_pending = true;   // mode 2: the caller joins (ldiff_pipeline_join) before it reads features / rgb
   }
   if (latents_out) HIP_CHECK(hipMemcpyAsync(latents_out, z, nlat * sizeof(float), hipMemcpyDeviceToDevice, s));
   API_END
@@ -316,7 +335,6 @@ void ldiff_pipeline_destroy(ldiff_pipeline* p) {
   (void)hipDeviceSynchronize();
   if (p->ev_latents) (void)hipEventDestroy(p->ev_latents);
   if (p->ev_decoded) (void)hipEventDestroy(p->ev_decoded);
-  if (p->decode_stream) (void)hipStreamDestroy(p->decode_stream);
   delete p;
 }
 

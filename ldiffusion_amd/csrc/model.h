@@ -136,7 +136,16 @@ struct ldiff_vae {
   ldiff_vae_cfg cfg;
   int device = 0;
   WeightStore ws;
-  Exec ex;
+  // Two workspaces: the decoder's and the encoder's.  A pipelined sampler decodes batch k on the side stream while the encoder
+  // of batch k+1 already runs on the caller's stream; ex() is the one the running graph builder uses.
+  Exec ex_dec, ex_enc;
+  Exec* cur = &ex_dec;
+  Exec& ex() { return *cur; }
+  // side stream for decodes that only feed the feature tensor (ldiff_sample); ev_side = "everything queued on it so far is done"
+  hipStream_t side_stream = nullptr;
+  hipEvent_t ev_side = nullptr;
+  bool side_used = false;
+  void wait_side(hipStream_t s);   // make s wait for the side stream's queued work (no-op if it was never used)
   // encoder
   MatW e_conv_in, e_conv_out, quant;
   std::vector<std::vector<ResnetW>> e_res;
@@ -162,8 +171,10 @@ struct ldiff_pipeline {
   Arena arena;   // latents / eps history
   float abar[1000];
   // decode side stream: the VAE decode of pass k (needed only for the features) runs beside the UNet pass k+1
-  bool overlap = true;
-  hipStream_t decode_stream = nullptr;
+  // 0: everything on the caller's stream; 1: decodes on the VAE's side stream, the caller's stream joins before ldiff_sample
+  // returns (default); 2: as 1 but the join is deferred to ldiff_pipeline_join (lets the next batch start under the decodes)
+  int overlap = 1;
+  bool join_pending = false;
   hipEvent_t ev_latents = nullptr, ev_decoded = nullptr;
 };
 

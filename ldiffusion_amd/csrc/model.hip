@@ -657,8 +657,13 @@ static VaeAttnW make_vae_attn(WeightStore& ws, const std::string& p, int C) {
   return a;
 }
 
+void ldiff_vae::wait_side(hipStream_t s) {
+  if (side_used && ev_side) HIP_CHECK(hipStreamWaitEvent(s, ev_side, 0));
+}
+
 void ldiff_vae::build() {
-  ex.weights_gen = &ws.generation;
+  ex_dec.weights_gen = &ws.generation;
+  ex_enc.weights_gen = &ws.generation;
   const int nb = cfg.n_blocks, lpb = cfg.layers_per_block, lat = cfg.latent_channels;
   const int* boc = cfg.block_out_channels;
   LDIFF_CHECK(nb >= 1 && nb <= LDIFF_MAX_BLOCKS, LDIFF_ERR_INVALID, "vae: n_blocks=%d out of range", nb);
@@ -704,43 +709,43 @@ void ldiff_vae::build() {
 
 Act ldiff_vae::resnet(const ResnetW& r, const Act& x) {
   const int G = cfg.norm_num_groups;
-  GNss g1 = ex.gn(x, nullptr, r.n1, G, 1e-6f);
+  GNss g1 = ex().gn(x, nullptr, r.n1, G, 1e-6f);
   ConvOpts o1;
   o1.gn = &g1; o1.silu = 1; o1.want_stats = true;
-  Act h = ex.conv(r.c1, x, nullptr, o1);
-  ex.release(g1);
-  GNss g2 = ex.gn(h, nullptr, r.n2, G, 1e-6f);
+  Act h = ex().conv(r.c1, x, nullptr, o1);
+  ex().release(g1);
+  GNss g2 = ex().gn(h, nullptr, r.n2, G, 1e-6f);
   Act sc;
   const Act* resp = &x;
-  if (r.has_sc) { sc = ex.conv(r.sc, x, nullptr, ConvOpts()); resp = &sc; }
+  if (r.has_sc) { sc = ex().conv(r.sc, x, nullptr, ConvOpts()); resp = &sc; }
   ConvOpts o2;
   o2.gn = &g2; o2.silu = 1; o2.res = resp; o2.want_stats = true;
-  Act out = ex.conv(r.c2, h, nullptr, o2);
-  ex.release(g2);
-  ex.release(h);
-  if (r.has_sc) ex.release(sc);
+  Act out = ex().conv(r.c2, h, nullptr, o2);
+  ex().release(g2);
+  ex().release(h);
+  if (r.has_sc) ex().release(sc);
   return out;
 }
 
 Act ldiff_vae::mid_attention(const VaeAttnW& a, const Act& x) {
   const int C = a.C, L = x.H * x.W;
-  GNss g = ex.gn(x, nullptr, a.gn, cfg.norm_num_groups, 1e-6f);
+  GNss g = ex().gn(x, nullptr, a.gn, cfg.norm_num_groups, 1e-6f);
   ConvOpts oq;
   oq.gn = &g; oq.silu = 0;
-  Act qkv = ex.conv(a.qkv, x, nullptr, oq);
-  ex.release(g);
-  Act o = ex.new_act(x.B, x.H, x.W, C);
+  Act qkv = ex().conv(a.qkv, x, nullptr, oq);
+  ex().release(g);
+  Act o = ex().new_act(x.B, x.H, x.W, C);
   AttnParams ap;
   ap.q = qkv.p; ap.ldq = 3 * C; ap.k = qkv.p + C; ap.ldk = 3 * C; ap.v = qkv.p + 2 * C; ap.ldv = 3 * C;
   ap.o = o.p; ap.ldo = C; ap.B = x.B; ap.heads = 1; ap.Lq = L; ap.Lk = L; ap.d = C;
   ap.q_bstride = (long long)L * 3 * C; ap.kv_bstride = ap.q_bstride; ap.o_bstride = (long long)L * C;
   ap.scale = 1.0f / sqrtf((float)C);
-  launch_attention(ap, ex.s);
-  ex.release(qkv);
+  launch_attention(ap, ex().s);
+  ex().release(qkv);
   ConvOpts oo;
   oo.res = &x; oo.want_stats = true;
-  Act out = ex.conv(a.out, o, nullptr, oo);
-  ex.release(o);
+  Act out = ex().conv(a.out, o, nullptr, oo);
+  ex().release(o);
   return out;
 }
 
@@ -750,44 +755,46 @@ void ldiff_vae::encode(const float* x, int B, int H, int W, float* moments, hipS
   LDIFF_CHECK(H >= f && W >= f && H % f == 0 && W % f == 0, LDIFF_ERR_INVALID, "vae_encode: image size %dx%d must be a positive multiple of %d", H, W, f);
   LDIFF_CHECK(ws.missing() == 0, LDIFF_ERR_STATE, "vae: %d weight tensors not loaded (first: %s)", ws.missing(), ws.missing_name(0));
   HIP_CHECK(hipSetDevice(device));
-  ex.s = s;
+  struct UseEnc { ldiff_vae* v; UseEnc(ldiff_vae* v_) : v(v_) { v->cur = &v->ex_enc; } ~UseEnc() { v->cur = &v->ex_dec; } } use_enc(this);
+  ex().arena.reset();
+  ex().s = s;
   const int* boc = cfg.block_out_channels;
   int Cmax = 0;
   for (int i = 0; i < nb; ++i) Cmax = std::max(Cmax, boc[i]);
-  ex.arena.reserve((size_t)B * H * W * boc[0] * 2 * 10 + (size_t)B * (H / f) * (W / f) * Cmax * 2 * 24 + (64u << 20));
-  ex.ensure_gn_partial(std::max(gn_partial_bytes(B, H * W, boc[0]), gn_partial_bytes(B, (H / f) * (W / f), Cmax)));
-  for (int i = 0; i < nb; ++i) ex.ensure_gn_partial(gn_partial_bytes(B, (H >> i) * (W >> i), boc[i]));
+  ex().arena.reserve((size_t)B * H * W * boc[0] * 2 * 10 + (size_t)B * (H / f) * (W / f) * Cmax * 2 * 24 + (64u << 20));
+  ex().ensure_gn_partial(std::max(gn_partial_bytes(B, H * W, boc[0]), gn_partial_bytes(B, (H / f) * (W / f), Cmax)));
+  for (int i = 0; i < nb; ++i) ex().ensure_gn_partial(gn_partial_bytes(B, (H >> i) * (W >> i), boc[i]));
 
-  Act x16 = ex.new_act(B, H, W, 8);
+  Act x16 = ex().new_act(B, H, W, 8);
   launch_nchw_f32_to_nhwc_f16(x, x16.p, B, cfg.in_channels, H, W, 8, s);
   ConvOpts oci;
   oci.want_stats = true;
-  Act cur = ex.conv(e_conv_in, x16, nullptr, oci);
-  ex.release(x16);
-  auto advance = [&](Act nxt) { ex.release(cur); cur = nxt; };
+  Act cur = ex().conv(e_conv_in, x16, nullptr, oci);
+  ex().release(x16);
+  auto advance = [&](Act nxt) { ex().release(cur); cur = nxt; };
   for (int i = 0; i < nb; ++i) {
     for (auto& r : e_res[i]) advance(resnet(r, cur));
     if (i != nb - 1) {
       ConvOpts o;  // Downsample2D(padding=0): F.pad(x,(0,1,0,1)) then stride-2 conv without padding
       o.stride = 2; o.pad_t = 0; o.pad_l = 0; o.Hout = cur.H / 2; o.Wout = cur.W / 2; o.want_stats = true;
-      advance(ex.conv(e_down[i], cur, nullptr, o));
+      advance(ex().conv(e_down[i], cur, nullptr, o));
     }
   }
   advance(resnet(e_mid[0], cur));
   advance(mid_attention(e_attn, cur));
   advance(resnet(e_mid[1], cur));
-  GNss g = ex.gn(cur, nullptr, e_norm_out, cfg.norm_num_groups, 1e-6f);
+  GNss g = ex().gn(cur, nullptr, e_norm_out, cfg.norm_num_groups, 1e-6f);
   ConvOpts oc;
   oc.gn = &g; oc.silu = 1;
-  Act m = ex.conv(e_conv_out, cur, nullptr, oc);   // [B,h,w,8] (2*latent channels, zero padded)
-  ex.release(g);
-  ex.release(cur);
+  Act m = ex().conv(e_conv_out, cur, nullptr, oc);   // [B,h,w,8] (2*latent channels, zero padded)
+  ex().release(g);
+  ex().release(cur);
   const int Nst = roundup(2 * cfg.latent_channels, 4);
-  float* q32 = ex.tmp<float>((size_t)m.rows() * Nst);
-  { ConvOpts o; o.out_f32 = q32; o.ldy_f32 = Nst; ex.conv(quant, m, nullptr, o); }
+  float* q32 = ex().tmp<float>((size_t)m.rows() * Nst);
+  { ConvOpts o; o.out_f32 = q32; o.ldy_f32 = Nst; ex().conv(quant, m, nullptr, o); }
   launch_nhwc_f32_to_nchw_f32(q32, moments, B, 2 * cfg.latent_channels, m.H, m.W, Nst, s);
-  ex.arena.free(q32);
-  ex.release(m);
+  ex().arena.free(q32);
+  ex().release(m);
 }
 
 void ldiff_vae::decode(const float* z, int B, int h, int w, float z_scale, float* sample_nchw, float* image_nhwc, uint8_t* rgb, uint8_t* luma,
@@ -797,30 +804,31 @@ void ldiff_vae::decode(const float* z, int B, int h, int w, float z_scale, float
   LDIFF_CHECK(ws.missing() == 0, LDIFF_ERR_STATE, "vae: %d weight tensors not loaded (first: %s)", ws.missing(), ws.missing_name(0));
   LDIFF_CHECK(!luma || (slot >= 0 && slot < n_slots), LDIFF_ERR_INVALID, "vae_decode: luma slot %d out of range [0,%d)", slot, n_slots);
   HIP_CHECK(hipSetDevice(device));
-  ex.s = s;
+  ex().arena.reset();   // decodes of one VAE run on one stream at a time: the workspace is reused in stream order
+  ex().s = s;
   const int* boc = cfg.block_out_channels;
   const int H = h * f, W = w * f;
   int Cmax = 0;
   for (int i = 0; i < nb; ++i) Cmax = std::max(Cmax, boc[i]);
-  ex.arena.reserve((size_t)B * H * W * boc[0] * 2 * 10 + (size_t)B * h * w * Cmax * 2 * 24 + (64u << 20));
-  for (int i = 0; i < nb; ++i) ex.ensure_gn_partial(gn_partial_bytes(B, (H >> i) * (W >> i), boc[std::min(i + 1, nb - 1)]));
-  ex.ensure_gn_partial(gn_partial_bytes(B, h * w, Cmax));
+  ex().arena.reserve((size_t)B * H * W * boc[0] * 2 * 10 + (size_t)B * h * w * Cmax * 2 * 24 + (64u << 20));
+  for (int i = 0; i < nb; ++i) ex().ensure_gn_partial(gn_partial_bytes(B, (H >> i) * (W >> i), boc[std::min(i + 1, nb - 1)]));
+  ex().ensure_gn_partial(gn_partial_bytes(B, h * w, Cmax));
 
   const long long nz = (long long)B * cfg.latent_channels * h * w;
-  float* zs = ex.tmp<float>((size_t)nz);
+  float* zs = ex().tmp<float>((size_t)nz);
   launch_scale_f32(z, zs, z_scale, nz, s);
-  Act z16 = ex.new_act(B, h, w, 8);
+  Act z16 = ex().new_act(B, h, w, 8);
   launch_nchw_f32_to_nhwc_f16(zs, z16.p, B, cfg.latent_channels, h, w, 8, s);
-  ex.arena.free(zs);
+  ex().arena.free(zs);
   ConvOpts opq;
   opq.N_override = 8; opq.ldy = 8;   // rows >= latent_channels are zero => pad channels come out zero
-  Act pq = ex.conv(post_quant, z16, nullptr, opq);
-  ex.release(z16);
+  Act pq = ex().conv(post_quant, z16, nullptr, opq);
+  ex().release(z16);
   ConvOpts odi;
   odi.want_stats = true;
-  Act cur = ex.conv(d_conv_in, pq, nullptr, odi);
-  ex.release(pq);
-  auto advance = [&](Act nxt) { ex.release(cur); cur = nxt; };
+  Act cur = ex().conv(d_conv_in, pq, nullptr, odi);
+  ex().release(pq);
+  auto advance = [&](Act nxt) { ex().release(cur); cur = nxt; };
   advance(resnet(d_mid[0], cur));
   advance(mid_attention(d_attn, cur));
   advance(resnet(d_mid[1], cur));
@@ -829,21 +837,21 @@ void ldiff_vae::decode(const float* z, int B, int h, int w, float z_scale, float
     if (i != nb - 1) {
       ConvOpts o;
       o.ups = 1; o.want_stats = true;
-      advance(ex.conv(d_up[i], cur, nullptr, o));
+      advance(ex().conv(d_up[i], cur, nullptr, o));
     }
   }
-  GNss g = ex.gn(cur, nullptr, d_norm_out, cfg.norm_num_groups, 1e-6f);
+  GNss g = ex().gn(cur, nullptr, d_norm_out, cfg.norm_num_groups, 1e-6f);
   const int Nst = 4;
-  float* o32 = ex.tmp<float>((size_t)B * H * W * Nst);
-  { ConvOpts o; o.gn = &g; o.silu = 1; o.out_f32 = o32; o.ldy_f32 = Nst; ex.conv(d_conv_out, cur, nullptr, o); }
-  ex.release(g);
-  ex.release(cur);
+  float* o32 = ex().tmp<float>((size_t)B * H * W * Nst);
+  { ConvOpts o; o.gn = &g; o.silu = 1; o.out_f32 = o32; o.ldy_f32 = Nst; ex().conv(d_conv_out, cur, nullptr, o); }
+  ex().release(g);
+  ex().release(cur);
   if (sample_nchw) launch_nhwc_f32_to_nchw_f32(o32, sample_nchw, B, cfg.out_channels, H, W, Nst, s);
   if (image_nhwc || rgb || luma) {
     LDIFF_CHECK(cfg.out_channels == 3, LDIFF_ERR_INVALID, "vae_decode: image outputs need 3 output channels");
     launch_decode_post(o32, Nst, B, H, W, image_nhwc, rgb, luma, n_slots, slot, s);
   }
-  ex.arena.free(o32);
+  ex().arena.free(o32);
 }
 
 // ================================================================================================

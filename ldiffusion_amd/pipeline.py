@@ -79,9 +79,15 @@ class LaplaceSampler:
         abar = pipeline.scheduler.alphas_cumprod.detach().to("cpu", torch.float32).contiguous()
         _lib.check(self._lib.ldiff_pipeline_set_alphas_cumprod(self._h, C.cast(abar.data_ptr(), C.POINTER(C.c_float)), abar.numel()))
 
-    def set_overlap(self, on: bool):
-        """VAE decode of pass k on a side stream beside the UNet pass k+1 (default on; identical results either way)."""
-        _lib.check(self._lib.ldiff_pipeline_set_overlap(self._h, 1 if on else 0))
+    def set_overlap(self, mode):
+        """0 / False: everything on the current stream; 1 / True (default): VAE decode of pass k on a side stream beside the UNet
+        pass k+1, joined before sample() returns; 2: the same with the join deferred to join() -- features / rgb of a sample()
+        call must not be read before it (lets the next batch start under the trailing decodes).  Identical results in all modes."""
+        _lib.check(self._lib.ldiff_pipeline_set_overlap(self._h, int(mode)))
+
+    def join(self):
+        """Make the current stream wait for the decodes of this sampler's last sample() call (mode 2)."""
+        _lib.check(self._lib.ldiff_pipeline_join(self._h, _lib.stream_ptr()))
 
     def timesteps(self, num_inference_steps: int):
         buf = (C.c_int64 * 1024)()

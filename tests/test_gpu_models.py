@@ -356,9 +356,48 @@ def test_decode_side_stream_changes_nothing(tiny):
     s = LaplaceSampler(tiny["pipe"])
     a1 = s.sample(x, ctx, 6)
     a2 = s.sample(x, ctx, 6)          # immediately again: the next encode must wait for the previous decodes
-    s.set_overlap(False)
+    s.set_overlap(0)
     b = s.sample(x, ctx, 6)
-    s.set_overlap(True)
+    s.set_overlap(1)
     torch.cuda.synchronize()
     for k in ("latents", "features", "rgb"):
         assert torch.equal(a1[k], b[k]) and torch.equal(a2[k], b[k]), k
+
+
+def test_deferred_join_pipelines_batches(tiny):
+    """Mode 2: two samplers on the same unet / vae used alternately, join deferred -- the encoder and UNet passes of batch k+1
+    run under the trailing decodes of batch k.  Every batch must equal its serial result bit for bit; a standalone
+    decode_latents in between (same decoder workspace) must not race either."""
+    g = torch.Generator().manual_seed(12)
+    batches = [torch.rand((2, 3, 64, 64), generator=g).to(DEV) for _ in range(5)]
+    ctx = (torch.randn((1, 6, 64), generator=g) * 0.5).to(DEV)
+    ref_s = LaplaceSampler(tiny["pipe"])
+    ref_s.set_overlap(0)
+    refs = [ref_s.sample(x, ctx, 5) for x in batches]
+    zs = torch.randn((1, 4, 8, 8), generator=g).to(DEV)
+    ref_img = tiny["pipe"].decode_latents(zs)
+    torch.cuda.synchronize()
+    ss = [LaplaceSampler(tiny["pipe"]), LaplaceSampler(tiny["pipe"])]
+    for s in ss:
+        s.set_overlap(2)
+    outs, pending = [], None
+    for k, x in enumerate(batches):
+        cur = (ss[k % 2], ss[k % 2].sample(x, ctx, 5))
+        if k == 2:
+            img = tiny["pipe"].decode_latents(zs)     # standalone decode while sampler decodes are in flight
+            assert np.array_equal(img, ref_img)
+        if pending is not None:
+            pending[0].join()
+            outs.append({k2: v.clone() for k2, v in pending[1].items()})
+        pending = cur
+    pending[0].join()
+    outs.append(pending[1])
+    torch.cuda.synchronize()
+    for o, r in zip(outs, refs):
+        for k2 in ("latents", "features", "rgb"):
+            assert torch.equal(o[k2], r[k2]), k2
+    with pytest.raises(RuntimeError):
+        ss[0].sample(batches[0], ctx, 5)
+        ss[0].set_overlap(1)                          # a join is pending: changing the mode is refused
+    ss[0].join()
+    ss[0].set_overlap(1)

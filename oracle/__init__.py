@@ -20,6 +20,9 @@ PARITY PINNING STATUS
     - metrics / label LUTs / sampler call order
                                      vs the reference's own python, imported
                                         with stubbed third-party modules
+    - ROI tile origins / Gaussian importance map (BASELINE config 4)
+                                     vs the reference's vendored nnU-Net helpers
+                                        (tests/golden/reference_tiling.json)
 * PARITY UNPINNED for everything that lives in diffusers (UNet2DConditionModel,
   AutoencoderKL, PNDMScheduler, decode_latents): diffusers is not in
   /root/reference, not installed, there is no network and no SD-v1.5

@@ -130,6 +130,12 @@ CONV_CASES = {
     "3x3_1x1_spatial": (3, 64, 0, 1, 1, 64, 3, 1, 0, False, False, False),
     "3x3_splitk_8x8_1280": (2, 1280, 0, 8, 8, 256, 3, 1, 0, False, True, True),
     "3x3_splitk_concat_16x16": (1, 640, 640, 16, 16, 128, 3, 1, 0, False, True, True),
+    # wide-tile kernel (8x16 pixel tiles) on maps that are not multiples of the tile, with and without the 16-byte store path
+    "3x3_wide_ragged_20x27_gn": (2, 64, 0, 20, 27, 96, 3, 1, 0, False, True, True),
+    "3x3_wide_ragged_upsample_9x11": (2, 128, 0, 9, 11, 64, 3, 1, 1, False, False, True),
+    "3x3_wide_cout20_8byte_stores": (1, 128, 0, 24, 40, 20, 3, 1, 0, False, True, True),
+    "3x3_wide_160_tile_ragged": (1, 64, 0, 17, 33, 320, 3, 1, 0, False, True, False),
+    "1x1_linear_N328_16byte_tail": (1, 64, 0, 1, 200, 328, 1, 1, 0, False, False, True),
 }
 
 
@@ -151,6 +157,17 @@ def test_conv(lib, name):
     res = torch.randn((B, Cout, Ho, Wo), generator=g) if extras else None
     got, ref = run_conv(lib, x, w, bias, x2, stride, (ks // 2, ks // 2), ups, gn, 1 if use_gn else 0, temb, res, out_f32, asym)
     assert_close(got, ref, name)
+
+
+def test_conv_groupnorm_without_silu(lib):
+    """GroupNorm prologue with silu_in = 0 (the instantiation without the activation) on the wide-tile kernel."""
+    g = torch.Generator().manual_seed(3)
+    B, C, H, W, Cout = 2, 128, 16, 32, 64
+    x = torch.randn((B, C, H, W), generator=g)
+    w = torch.randn((Cout, C, 3, 3), generator=g) / math.sqrt(9 * C)
+    gn = (1.0 + 0.2 * torch.randn((B, C), generator=g), 0.2 * torch.randn((B, C), generator=g))
+    got, ref = run_conv(lib, x, w, None, None, 1, (1, 1), 0, gn, 0, None, None, False, False)
+    assert_close(got, ref, "gn_no_silu")
 
 
 def test_conv_zero_padding_is_applied_after_groupnorm(lib):

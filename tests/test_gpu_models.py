@@ -401,3 +401,16 @@ def test_deferred_join_pipelines_batches(tiny):
         ss[0].set_overlap(1)                          # a join is pending: changing the mode is refused
     ss[0].join()
     ss[0].set_overlap(1)
+
+
+def test_sampler_non_square_padded_prompt_per_sample_context(tiny):
+    """Non-square patches (64 x 192), the padded 77-token prompt and one context per sample through the fused sampler."""
+    g = torch.Generator().manual_seed(21)
+    x = torch.rand((3, 3, 64, 192), generator=g)
+    ctx = torch.randn((3, 77, 64), generator=g) * 0.5
+    out = LaplaceSampler(tiny["pipe"]).sample(x.to(DEV), ctx.to(DEV), 4)
+    ref = op.sample_v6(tiny["opipe"], x, ctx, 4)
+    e = rel_err(out["latents"], ref["latents"][-1])
+    fd = np.abs(out["features"].cpu().numpy().astype(int) - ref["features"].astype(int))
+    print(f"sampler 64x192, L=77, per-sample ctx: latents rel err {e:.3e}; luma max diff {fd.max()} (>1: {(fd > 1).mean():.4f})")
+    assert out["features"].shape == (3, 4, 64, 192) and e < 2e-2 and (fd > 1).mean() < 0.01

@@ -119,6 +119,9 @@ int ldiff_laplace_add(const void* z0, float scale, const void* u_or_null, uint64
 int ldiff_argmax_u8(const void* logits, int B, int C, int H, int W, void* mask_u8, void* stream);
 /* rgb [B,3,H,W] f32 -> gray [B,1,H,W] f32 = (rgb*[0.2989,0.5870,0.1140]).sum(1)  (ldiffusion.py:241-242) */
 int ldiff_luma_float(const void* rgb_nchw, void* gray, int B, int H, int W, void* stream);
+/* F.interpolate(x, size=(out_h,out_w), mode="bilinear", align_corners=False) on fp32 NCHW (ldiffusion.py:240,250: the decoded
+ * image is resized to 64x64 before the float luma of the training-time features). */
+int ldiff_bilinear_resize(const void* x_nchw_f32, void* y_nchw_f32, int B, int C, int H, int W, int out_h, int out_w, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Fused sampler  --  replaces the whole per-image loop body of

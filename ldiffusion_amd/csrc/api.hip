@@ -163,6 +163,13 @@ int ldiff_luma_float(const void* rgb_nchw, void* gray, int B, int H, int W, void
   launch_luma_float((const float*)rgb_nchw, (float*)gray, B, H, W, (hipStream_t)stream);
   API_END
 }
+int ldiff_bilinear_resize(const void* x_nchw, void* y_nchw, int B, int C, int H, int W, int out_h, int out_w, void* stream) {
+  API_BEGIN
+  LDIFF_CHECK(x_nchw && y_nchw, LDIFF_ERR_INVALID, "bilinear_resize: null argument");
+  LDIFF_CHECK(B >= 0 && C >= 1 && H >= 1 && W >= 1 && out_h >= 1 && out_w >= 1, LDIFF_ERR_INVALID, "bilinear_resize: bad shape");
+  launch_bilinear_resize((const float*)x_nchw, (float*)y_nchw, B, C, H, W, out_h, out_w, (hipStream_t)stream);
+  API_END
+}
 
 // ---- fused sampler ----
 int ldiff_pipeline_create(ldiff_pipeline** out, ldiff_unet* u, ldiff_vae* v) {

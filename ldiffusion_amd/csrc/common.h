@@ -115,6 +115,7 @@ void launch_decode_post(const float* x, int ldx, int B, int H, int W, float* img
                         uint8_t* rgb_u8 /*[B,H,W,3] or null*/, uint8_t* luma /*base of [B,N,H,W] or null*/, int n_slots, int slot,
                         hipStream_t s);
 void launch_argmax_u8(const float* logits, int B, int C, int H, int W, uint8_t* mask, hipStream_t s);
+void launch_bilinear_resize(const float* x, float* y, int B, int C, int H, int W, int oh, int ow, hipStream_t s);
 void launch_luma_float(const float* rgb_nchw, float* gray, int B, int H, int W, hipStream_t s);
 
 // ---- device arena: bump/free-list allocator over one hipMalloc'd slab ------------------------

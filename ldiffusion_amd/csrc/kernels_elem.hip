@@ -242,3 +242,30 @@ void launch_luma_float(const float* rgb_nchw, float* gray, int B, int H, int W, 
   hipLaunchKernelGGL(luma_float_kernel, dim3(nblocks(n)), dim3(256), 0, s, rgb_nchw, gray, B, H * W);
   HIP_CHECK(hipGetLastError());
 }
+
+
+// ---- bilinear resize, align_corners = False (F.interpolate(mode="bilinear"), /root/reference/ldiffusion.py:240,250) ----
+// fp32 NCHW -> fp32 NCHW; source index = (dst + 0.5) * in/out - 0.5 clamped at 0, neighbours clamped at in-1, no antialiasing
+// (exactly ATen's upsample_bilinear2d: at 512 -> 64 it samples a 2x2 neighbourhood every 8 pixels).
+__global__ void bilinear_resize_kernel(const float* __restrict__ x, float* __restrict__ y, long long planes, int H, int W, int oh, int ow,
+                                       float sy, float sx) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long total = planes * oh * ow;
+  if (i >= total) return;
+  const int ox = (int)(i % ow), oy = (int)((i / ow) % oh);
+  const long long pl = i / ((long long)ow * oh);
+  float fy = ((float)oy + 0.5f) * sy - 0.5f, fx = ((float)ox + 0.5f) * sx - 0.5f;
+  fy = fy < 0.f ? 0.f : fy; fx = fx < 0.f ? 0.f : fx;
+  const int y0 = (int)fy, x0 = (int)fx;
+  const int y1 = y0 + (y0 < H - 1 ? 1 : 0), x1 = x0 + (x0 < W - 1 ? 1 : 0);
+  const float ly = fy - (float)y0, lx = fx - (float)x0, hy = 1.f - ly, hx = 1.f - lx;
+  const float* p = x + pl * H * W;
+  y[i] = hy * (hx * p[(long long)y0 * W + x0] + lx * p[(long long)y0 * W + x1]) + ly * (hx * p[(long long)y1 * W + x0] + lx * p[(long long)y1 * W + x1]);
+}
+void launch_bilinear_resize(const float* x, float* y, int B, int C, int H, int W, int oh, int ow, hipStream_t s) {
+  const long long total = (long long)B * C * oh * ow;
+  if (total == 0) return;
+  hipLaunchKernelGGL(bilinear_resize_kernel, dim3(nblocks(total)), dim3(256), 0, s, x, y, (long long)B * C, H, W, oh, ow, (float)H / (float)oh,
+                     (float)W / (float)ow);
+  HIP_CHECK(hipGetLastError());
+}

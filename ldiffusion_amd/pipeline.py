@@ -157,3 +157,36 @@ def luma_float(rgb: torch.Tensor) -> torch.Tensor:
     out = torch.empty((B, 1, H, W), device=x.device, dtype=torch.float32)
     _lib.check(_lib.load().ldiff_luma_float(_lib.ptr(x), _lib.ptr(out), B, H, W, _lib.stream_ptr()))
     return out
+
+
+def bilinear_resize(x: torch.Tensor, size) -> torch.Tensor:
+    """F.interpolate(x, size=size, mode="bilinear", align_corners=False) for fp32 [B,C,H,W] (ldiffusion.py:240,250)."""
+    _lib.require_gpu()
+    if x.dim() != 4:
+        raise ValueError("bilinear_resize takes [B,C,H,W]")
+    x = x.detach().to(dtype=torch.float32).contiguous()
+    B, Cc, H, W = x.shape
+    oh, ow = (int(size), int(size)) if isinstance(size, int) else (int(size[0]), int(size[1]))
+    out = torch.empty((B, Cc, oh, ow), device=x.device, dtype=torch.float32)
+    _lib.check(_lib.load().ldiff_bilinear_resize(_lib.ptr(x), _lib.ptr(out), B, Cc, H, W, oh, ow, _lib.stream_ptr()))
+    return out
+
+
+def laplace_features(pipeline: StableDiffusionImg2ImgPipeline, images: torch.Tensor, text_embeddings: torch.Tensor, num_inference_steps: int,
+                     u_list=None, seed: int = 0, out_hw: int = 64):
+    """The forward part of the reference's training step (ldiffusion.py:228-247): z0 = encode(x).mean is kept
+    fixed; per scheduler timestep x_t = z0 + Laplace(0, sqrt(1 - abar_t)), eps = unet(x_t, t, ctx), the UNet output is decoded
+    directly, resized to out_hw x out_hw (bilinear) and reduced to a float luma plane; the planes are concatenated.
+    `u_list[i]` (optional) is the uniform draw of step i (parity is defined given u); otherwise the device Philox stream."""
+    vae, unet, sch = pipeline.vae, pipeline.unet, pipeline.scheduler
+    z0 = vae.encode(images).latent_dist.mean.to(dtype=torch.float32)
+    sch.set_timesteps(num_inference_steps, device=z0.device)
+    grays, rgb = [], None
+    for i, t in enumerate(sch.timesteps):
+        lat = sch.scale_model_input(z0, t)
+        scale = float(torch.sqrt(1 - sch.alphas_cumprod[int(t)]))
+        noisy = laplace_noise(lat, scale, u=None if u_list is None else u_list[i], seed=seed, offset=i * lat.numel())
+        den = unet(noisy, t, text_embeddings).sample
+        rgb = bilinear_resize(vae.decode(den).sample, out_hw)
+        grays.append(luma_float(rgb))
+    return dict(gray=torch.cat(grays, dim=1), rgb=rgb)

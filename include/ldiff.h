@@ -166,6 +166,9 @@ typedef struct {
   const void* res; int ld_res;                      /* f16 [M, ld_res] or NULL */
   void* y; int ldy; int out_f32;
   void* stats;                                      /* optional f32 [B][N][R][2]: fused GroupNorm partial sums of y (R from ldiff_op_conv_stats_blocks) */
+  int geglu;                                        /* 1x1 / linear only: the weight rows are the [x | gate] rows of diffusers' GEGLU projection
+                                                       interleaved by 16 (row r of x -> 32*(r/16) + r%16, of gate -> 32*(r/16) + 16 + r%16);
+                                                       y[m, 0..N/2) = x * gelu_erf(gate), ldy counts those N/2 columns (N % 32 == 0) */
 } ldiff_conv_args;
 int ldiff_op_conv(const ldiff_conv_args*, void* stream);
 /* row blocks per image the launch would emit statistics for (0 = unsupported for this shape) */

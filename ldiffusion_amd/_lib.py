@@ -34,7 +34,8 @@ class ConvArgs(C.Structure):
                 ("w", C.c_void_p), ("N", C.c_int), ("Nrows", C.c_int),
                 ("gn_scale", C.c_void_p), ("gn_shift", C.c_void_p), ("silu_in", C.c_int),
                 ("bias", C.c_void_p), ("temb", C.c_void_p), ("ld_temb", C.c_int),
-                ("res", C.c_void_p), ("ld_res", C.c_int), ("y", C.c_void_p), ("ldy", C.c_int), ("out_f32", C.c_int), ("stats", C.c_void_p)]
+                ("res", C.c_void_p), ("ld_res", C.c_int), ("y", C.c_void_p), ("ldy", C.c_int), ("out_f32", C.c_int), ("stats", C.c_void_p),
+                ("geglu", C.c_int)]
 
 
 # name -> (restype, argtypes); every symbol include/ldiff.h declares

@@ -361,6 +361,7 @@ static void conv_args_to_params(const ldiff_conv_args* a, ConvParams& p) {
   p.y = a->y; p.ldy = a->ldy; p.out_f32 = a->out_f32;
   p.M = a->B * a->Hout * a->Wout;
   p.stats = (float*)a->stats;
+  p.geglu = a->geglu != 0;
 }
 int ldiff_op_conv(const ldiff_conv_args* a, void* stream) {
   API_BEGIN

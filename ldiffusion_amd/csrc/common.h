@@ -65,6 +65,7 @@ struct ConvParams {
   int M;                  // B*Hout*Wout
   float* stats;           // optional fused GroupNorm partial statistics of the output (see below)
   int stats_R;            // row blocks per image of `stats`
+  int geglu;              // gemm_dma only: weight rows are x/gate-interleaved by 16 (MatW::geglu); y[m, n/2..] = x * gelu_erf(gate), ldy counts the N/2 outputs
   int splitk;             // conv3x3 only: >1 => K (input-channel slabs) split over blockIdx.y, fp32 partials to splitk_ws
   float* splitk_ws;       // [splitk][M][N] fp32 workspace (then reduced + epilogue by splitk_reduce)
   const f16* w_par;       // conv3x3 with ups=1 only: parity weights [4][Nrows][4*Cin] (see kernels_conv3x3.hip); nullptr => 9-tap gather

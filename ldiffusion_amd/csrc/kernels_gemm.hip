@@ -182,6 +182,33 @@ __global__ __launch_bounds__(256, 2) void gemm_dma_kernel(const ConvParams p) {
         if (mrow[m] >= 0 && ncol + a * 16 < p.N) rr[m][a] = *reinterpret_cast<const f16x4*>(p.res + (long long)mrow[m] * p.ld_res + ncol + a * 16);
       }
   }
+  // GEGLU epilogue (BasicTransformerBlock.ff.net.0: Linear(C, 8C) -> x * gelu_erf(gate)): the weight rows were interleaved at
+  // load time so that column tile 2j of a wave is x[16 channels] and tile 2j+1 the matching gate; the [M, 8C] intermediate (168
+  // MB per call at SD-v1.5 sizes) and the separate activation kernel disappear.  Stores: 16 bytes after a permlane swap, as below.
+  if (p.geglu) {
+    static_assert(NT % 2 == 0, "GEGLU pairs column tiles");
+#pragma unroll
+    for (int mp = 0; mp < MT; mp += 2) {
+      const int mms = m0 + wave_m * (BM / 2) + (mp + (g & 1)) * 16 + l15;   // this lane's row after the swap
+#pragma unroll
+      for (int j = 0; j < NT / 2; ++j) {
+        uint2 pq[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const f32x4 xv = acc[2 * j][mp + h] + bb[2 * j], gv = acc[2 * j + 1][mp + h] + bb[2 * j + 1];
+          f16x4 o;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o[r] = (f16)(xv[r] * (0.5f * gv[r] * (1.0f + erff(gv[r] * 0.70710678118654752f))));
+          pq[h] = __builtin_bit_cast(uint2, o);
+        }
+        auto r0 = __builtin_amdgcn_permlane16_swap(pq[0].x, pq[1].x, false, false);
+        auto r1 = __builtin_amdgcn_permlane16_swap(pq[0].y, pq[1].y, false, false);
+        const int nb = (n0 + wave_n * (BN / 2)) / 2 + j * 16 + (g & ~1) * 4;   // output channel (of N/2)
+        if (mms < p.M && nb < p.N / 2) *reinterpret_cast<uint4*>(reinterpret_cast<f16*>(p.y) + (long long)mms * p.ldy + nb) = make_uint4(r0[0], r1[0], r0[1], r1[1]);
+      }
+    }
+    return;
+  }
   // 16-byte stores (see kernels_conv3x3.hip): one v_permlane16_swap per dword between the packed values of two m-tiles
   // leaves even-g lanes with channels 4g..4g+7 of the first tile's row and odd-g lanes with 4(g-1)..4(g-1)+7 of the second's
   if (!p.out_f32 && (p.N & 7) == 0 && (p.ldy & 7) == 0) {
@@ -257,6 +284,7 @@ void launch_g(const ConvParams& p, hipStream_t s) {
 }  // namespace
 
 bool gemm_dma_eligible(const ConvParams& p) {
+  if (p.geglu && (p.N % 32 != 0 || (p.ldy & 7) != 0 || p.res || p.out_f32 || p.stats)) return false;
   return p.ks == 1 && p.stride == 1 && p.ups == 0 && p.pad_t == 0 && p.pad_l == 0 && !p.gn_scale && !p.temb && p.K % 64 == 0 && p.C1 % 64 == 0 &&
          p.Hout == p.Hin && p.Wout == p.Win && p.M < (1 << 24) && (p.C1 > p.C2 ? p.C1 : p.C2) * 2 < (1 << 24) && (long long)p.M * (p.C1 > p.C2 ? p.C1 : p.C2) * 2 < (1LL << 32) && (long long)p.Nrows * p.K * 2 < (1LL << 32);
 }

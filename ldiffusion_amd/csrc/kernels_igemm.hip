@@ -285,13 +285,14 @@ void launch_igemm(const ConvParams& p, hipStream_t s) {
   const int Cin = p.C1 + p.C2;
   LDIFF_CHECK(p.C1 % 8 == 0 && p.C2 % 8 == 0 && Cin > 0, LDIFF_ERR_INVALID, "igemm: channel counts must be multiples of 8 (C1=%d C2=%d)", p.C1, p.C2);
   LDIFF_CHECK(p.K == p.ks * p.ks * Cin, LDIFF_ERR_INVALID, "igemm: K=%d != ks*ks*Cin=%d", p.K, p.ks * p.ks * Cin);
-  LDIFF_CHECK(p.N % 4 == 0 && p.N <= p.Nrows && p.ldy % 4 == 0 && p.N <= p.ldy, LDIFF_ERR_INVALID, "igemm: bad N=%d Nrows=%d ldy=%d", p.N, p.Nrows, p.ldy);
+  LDIFF_CHECK(p.N % 4 == 0 && p.N <= p.Nrows && p.ldy % 4 == 0 && (p.geglu ? p.N / 2 : p.N) <= p.ldy, LDIFF_ERR_INVALID, "igemm: bad N=%d Nrows=%d ldy=%d", p.N, p.Nrows, p.ldy);
   LDIFF_CHECK((p.C2 == 0) == (p.x2 == nullptr), LDIFF_ERR_INVALID, "igemm: x2/C2 mismatch");
   LDIFF_CHECK(!p.res || p.ld_res % 4 == 0, LDIFF_ERR_INVALID, "igemm: ld_res must be a multiple of 4");
   LDIFF_CHECK(!p.temb || p.ld_temb % 4 == 0, LDIFF_ERR_INVALID, "igemm: ld_temb must be a multiple of 4");
   if (p.M <= 0) return;
   if (conv3x3_eligible(p)) { launch_conv3x3(p, s); return; }
   if (gemm_dma_eligible(p)) { launch_gemm_dma(p, s); return; }
+  LDIFF_CHECK(!p.geglu, LDIFF_ERR_INVALID, "GEGLU epilogue: only on 1x1 / linear layers with K %% 64 == 0, N %% 32 == 0, fp16 output, no residual");
   const bool fast = (Cin % BK == 0) && (p.C1 % BK == 0);
   // Tile choice: largest tile that still yields >= ~2 workgroups per CU worth of tiles; narrow N gets BN=64.
   auto tiles = [&](int bm, int bn) { return (long long)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn); };

@@ -24,6 +24,7 @@ struct MatW {   // [Nrows][K] fp16 K-major + fp32 bias
   f16* w = nullptr;
   float* b = nullptr;  // nullptr => no bias
   int N = 0, Nrows = 0, K = 0, ks = 1, Cin = 0;  // Cin = padded input channels (K = ks*ks*Cin)
+  bool geglu = false;   // rows stored x/gate-interleaved by 16 so that the GEMM epilogue can apply x * gelu(gate) (ConvParams::geglu)
   mutable f16* w_par = nullptr;   // upsampler convs: parity weights [4][Nrows][4*Cin], built on first use (owned by the Exec)
   mutable int w_par_gen = -1;     // WeightStore generation the parity weights were derived from
 };
@@ -36,6 +37,7 @@ struct LoadSpec {
   std::vector<int64_t> shape;   // expected torch shape
   f16* mat = nullptr; int row_off = 0, K = 0, ks = 1, Cin_pad = 0;   // MATRIX
   float* vec = nullptr; int vec_off = 0;                             // VECTOR
+  int geglu_half = 0;   // > 0: GEGLU projection of width 2*geglu_half: row r lands at geglu_row(r) (x / gate interleaved by 16 rows)
   bool loaded = false;
 };
 
@@ -46,7 +48,7 @@ class WeightStore {
   f16* alloc_mat(int Nrows, int K);
   float* alloc_vec(int n);
   // registration
-  MatW add_conv(const std::string& prefix, int Cin, int Cout, int ks, bool bias = true, int Cin_pad = -1, int min_rows = 0);
+  MatW add_conv(const std::string& prefix, int Cin, int Cout, int ks, bool bias = true, int Cin_pad = -1, int min_rows = 0, bool geglu = false);
   void add_rows(const std::string& wname, const std::string& bname, f16* mat, int K, int ks, int Cin, int Cin_pad, int row_off, int rows,
                 float* bias_vec, bool has_bias);
   NormW add_norm(const std::string& prefix, int C);
@@ -75,6 +77,7 @@ struct ConvOpts {
   int N_override = 0;           // columns to store (multiple of 4), default = roundup4(w.N)
   int ldy = 0;                  // fp16 output channel stride (default N stored rounded up to 8)
   bool want_stats = false;      // also emit GroupNorm partial statistics of the output (consumed by Exec::gn)
+  bool geglu = false;           // apply x * gelu(gate) in the epilogue (weights must be MatW::geglu); output has N/2 channels
 };
 
 class Exec {

@@ -112,15 +112,22 @@ void WeightStore::add_rows(const std::string& wname, const std::string& bname, f
     order_.push_back(bname);
   }
 }
-MatW WeightStore::add_conv(const std::string& prefix, int Cin, int Cout, int ks, bool bias, int Cin_pad, int min_rows) {
+MatW WeightStore::add_conv(const std::string& prefix, int Cin, int Cout, int ks, bool bias, int Cin_pad, int min_rows, bool geglu) {
   if (Cin_pad < 0) Cin_pad = roundup(Cin, 8);
   MatW m;
   m.N = Cout; m.Nrows = roundup(std::max(Cout, min_rows), 16); m.ks = ks; m.Cin = Cin_pad; m.K = ks * ks * Cin_pad;
   m.w = alloc_mat(m.Nrows, m.K);
   m.b = bias ? alloc_vec(m.Nrows) : nullptr;
   add_rows(prefix + ".weight", prefix + ".bias", m.w, m.K, ks, Cin, Cin_pad, 0, Cout, m.b, bias);
+  if (geglu) {   // Linear(C, 2*half) whose output is [x | gate]: store x rows 16j..16j+15 at 32j.., gate rows 16j.. at 32j+16..
+    LDIFF_CHECK(Cout % 32 == 0, LDIFF_ERR_INVALID, "geglu projection width %d must be a multiple of 32", Cout);
+    m.geglu = true;
+    specs_[prefix + ".weight"].geglu_half = Cout / 2;
+    if (bias) specs_[prefix + ".bias"].geglu_half = Cout / 2;
+  }
   return m;
 }
+static inline int geglu_row(int r, int half) { const int q = r < half ? r : r - half; return (q / 16) * 32 + (r < half ? 0 : 16) + q % 16; }
 NormW WeightStore::add_norm(const std::string& prefix, int C) {
   NormW n;
   n.C = C; n.g = alloc_vec(C); n.b = alloc_vec(C);
@@ -166,7 +173,7 @@ void WeightStore::load(const char* name_c, const void* host, int dtype, const in
   }
   if (sp.kind == LoadSpec::VECTOR) {
     std::vector<float> tmp(numel);
-    for (size_t i = 0; i < numel; ++i) tmp[i] = host_to_float(host, dtype, i);
+    for (size_t i = 0; i < numel; ++i) tmp[sp.geglu_half ? (size_t)geglu_row((int)i, sp.geglu_half) : i] = host_to_float(host, dtype, i);
     HIP_CHECK(hipMemcpy(sp.vec + sp.vec_off, tmp.data(), numel * sizeof(float), hipMemcpyHostToDevice));
   } else {
     const int rows = (int)sp.shape[0], Cin = (int)sp.shape[1], ks = sp.ks, taps = ks * ks;
@@ -174,7 +181,8 @@ void WeightStore::load(const char* name_c, const void* host, int dtype, const in
     for (int r = 0; r < rows; ++r)
       for (int c = 0; c < Cin; ++c)
         for (int t = 0; t < taps; ++t)
-          tmp[(size_t)r * sp.K + (size_t)t * sp.Cin_pad + c] = (f16)host_to_float(host, dtype, ((size_t)r * Cin + c) * taps + t);
+          tmp[(size_t)(sp.geglu_half ? geglu_row(r, sp.geglu_half) : r) * sp.K + (size_t)t * sp.Cin_pad + c] =
+              (f16)host_to_float(host, dtype, ((size_t)r * Cin + c) * taps + t);
     HIP_CHECK(hipMemcpy(sp.mat + (size_t)sp.row_off * sp.K, tmp.data(), tmp.size() * sizeof(f16), hipMemcpyHostToDevice));
   }
   sp.loaded = true;
@@ -259,7 +267,13 @@ Act Exec::conv(const MatW& w, const Act& x, const Act* x2, const ConvOpts& o) {
     p.res = o.res->p; p.ld_res = o.res->C;
   }
   Act y;
-  if (o.out_f32) {
+  if (o.geglu) {
+    LDIFF_CHECK(w.geglu && !o.out_f32 && !o.res && !o.want_stats && p.N % 32 == 0, LDIFF_ERR_INVALID, "conv: GEGLU epilogue on a layer that was not built for it");
+    p.geglu = 1;
+    y = new_act(x.B, p.Hout, p.Wout, p.N / 2);
+    p.y = y.p; p.ldy = p.N / 2;
+    LDIFF_CHECK(gemm_dma_eligible(p), LDIFF_ERR_INVALID, "conv: GEGLU epilogue needs the DMA GEMM (K %% 64 == 0)");
+  } else if (o.out_f32) {
     p.y = o.out_f32; p.ldy = o.ldy_f32; p.out_f32 = 1;
   } else {
     const int C = o.ldy ? o.ldy : roundup(p.N, 8);
@@ -348,7 +362,7 @@ static TransformerW make_transformer(WeightStore& ws, const std::string& p, int 
   ws.add_rows(b + ".attn2.to_k.weight", "", t.kv2.w, ctx, 1, ctx, ctx, 0, C, nullptr, false);
   ws.add_rows(b + ".attn2.to_v.weight", "", t.kv2.w, ctx, 1, ctx, ctx, C, C, nullptr, false);
   t.out2 = ws.add_conv(b + ".attn2.to_out.0", C, C, 1);
-  t.ff1 = ws.add_conv(b + ".ff.net.0.proj", C, 8 * C, 1);
+  t.ff1 = ws.add_conv(b + ".ff.net.0.proj", C, 8 * C, 1, true, -1, 0, /*geglu=*/C % 64 == 0);   // fused x * gelu(gate) epilogue when the DMA GEMM applies
   t.ff2 = ws.add_conv(b + ".ff.net.2", 4 * C, C, 1);
   t.proj_out = ws.add_conv(p + ".proj_out", C, C, 1);
   return t;
@@ -529,10 +543,15 @@ Act ldiff_unet::transformer(const TransformerW& t, const Act& x) {
   ex.release(h2);
   // GEGLU feed-forward
   Act n3 = ex.layernorm(h3, t.ln3);
-  Act f1 = ex.conv(t.ff1, n3, nullptr, ConvOpts());
+  ConvOpts of1;
+  of1.geglu = t.ff1.geglu;
+  Act f1 = ex.conv(t.ff1, n3, nullptr, of1);
   ex.release(n3);
-  Act gg = ex.geglu(f1);
-  ex.release(f1);
+  Act gg = f1;
+  if (!t.ff1.geglu) {   // channel counts the DMA GEMM does not take: projection, then the standalone activation
+    gg = ex.geglu(f1);
+    ex.release(f1);
+  }
   ConvOpts o3;
   o3.res = &h3;
   Act h4 = ex.conv(t.ff2, gg, nullptr, o3);

@@ -371,3 +371,31 @@ def test_fused_groupnorm_statistics(lib, name):
     got = yr * scale.cpu()[:, :, None, None] + shift.cpu()[:, :, None, None]
     ref = F.group_norm(yr, 32, gamma, beta, 1e-5)
     assert (got - ref).abs().max() <= 2e-4 * max(1.0, ref.abs().max())
+
+
+@pytest.mark.parametrize("M,Cc,inner", [(300, 64, 128), (4096, 320, 1280), (513, 128, 512)])
+def test_linear_with_fused_geglu_epilogue(lib, M, Cc, inner):
+    """diffusers GEGLU (Linear(C, 2*inner) -> x * gelu_erf(gate)) as the GEMM epilogue: weight rows interleaved by 16 at load."""
+    g = torch.Generator().manual_seed(M + Cc)
+    x = torch.randn((M, Cc), generator=g)
+    w = torch.randn((2 * inner, Cc), generator=g) / math.sqrt(Cc)
+    b = torch.randn(2 * inner, generator=g) * 0.2
+    proj = r16(x) @ r16(w).t() + b
+    ref = proj[:, :inner] * F.gelu(proj[:, inner:])
+    perm = torch.empty(2 * inner, dtype=torch.long)
+    for r in range(2 * inner):
+        q = r if r < inner else r - inner
+        perm[(q // 16) * 32 + (0 if r < inner else 16) + q % 16] = r
+    wd = w[perm].to(torch.float16).contiguous().to(DEV)
+    bd = b[perm].contiguous().to(DEV)
+    xd = x.to(torch.float16).contiguous().to(DEV)
+    y = torch.full((M, inner), float("nan"), dtype=torch.float16, device=DEV)
+    a = _lib.ConvArgs()
+    a.x, a.C1, a.B, a.Hin, a.Win, a.Hout, a.Wout, a.ks, a.stride = xd.data_ptr(), Cc, 1, 1, M, 1, M, 1, 1
+    a.w, a.N, a.Nrows, a.bias, a.y, a.ldy, a.geglu = wd.data_ptr(), 2 * inner, 2 * inner, bd.data_ptr(), y.data_ptr(), inner, 1
+    _lib.check(lib.ldiff_op_conv(C.byref(a), sp()))
+    torch.cuda.synchronize()
+    assert_close(y.float().cpu(), ref, f"geglu_{M}_{Cc}_{inner}")
+    a.res, a.ld_res = y.data_ptr(), inner                       # a residual cannot be combined with the GEGLU epilogue
+    with pytest.raises(ValueError):
+        _lib.check(lib.ldiff_op_conv(C.byref(a), sp()))

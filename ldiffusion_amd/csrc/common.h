@@ -151,6 +151,21 @@ struct ProfScope {
   ~ProfScope() { if (on) prof_end(s); }
 };
 
+// erf to 1.5e-7 absolute (Abramowitz & Stegun 7.1.26) with the two hardware transcendentals: the libm erff is ~30 instructions with
+// branches, and the GEGLU epilogue evaluates it 32 times per thread and tile.  gelu_erf(g) = 0.5 g (1 + erf(g / sqrt 2)).
+__device__ __forceinline__ float erf_as(float x) {
+  const float ax = __builtin_fabsf(x);
+  const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f, ax, 1.0f));
+  float poly = __builtin_fmaf(1.061405429f, t, -1.453152027f);
+  poly = __builtin_fmaf(poly, t, 1.421413741f);
+  poly = __builtin_fmaf(poly, t, -0.284496736f);
+  poly = __builtin_fmaf(poly, t, 0.254829592f);
+  const float e = __builtin_amdgcn_exp2f(ax * ax * -1.4426950408889634f);
+  const float y = __builtin_fmaf(-poly * t, e, 1.0f);
+  return __builtin_copysignf(y, x);
+}
+__device__ __forceinline__ float gelu_erf(float g) { return 0.5f * g * (1.0f + erf_as(g * 0.70710678118654752f)); }
+
 // ---- GroupNorm statistics fused into the producing kernel's epilogue ------------------------------------------
 // ConvParams::stats (optional): per row-block partial sums of the fp16-rounded outputs, CHANNEL-major so that the
 // finalize kernel reads each (image, group) as one contiguous run:

@@ -54,9 +54,7 @@ __global__ void geglu_kernel(const f16* __restrict__ x, f16* __restrict__ y, lon
   f16x8 o;
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
-    float gte = (float)gv[j];
-    float ge = 0.5f * gte * (1.0f + erff(gte * 0.70710678118654752f));
-    o[j] = (f16)((float)hv[j] * ge);
+    o[j] = (f16)((float)hv[j] * gelu_erf((float)gv[j]));
   }
   *reinterpret_cast<uint4*>(y + m * C4 + cc * 8) = __builtin_bit_cast(uint4, o);
 }

@@ -198,7 +198,7 @@ __global__ __launch_bounds__(256, 2) void gemm_dma_kernel(const ConvParams p) {
           const f32x4 xv = acc[2 * j][mp + h] + bb[2 * j], gv = acc[2 * j + 1][mp + h] + bb[2 * j + 1];
           f16x4 o;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) o[r] = (f16)(xv[r] * (0.5f * gv[r] * (1.0f + erff(gv[r] * 0.70710678118654752f))));
+          for (int r = 0; r < 4; ++r) o[r] = (f16)(xv[r] * gelu_erf(gv[r]));
           pq[h] = __builtin_bit_cast(uint2, o);
         }
         auto r0 = __builtin_amdgcn_permlane16_swap(pq[0].x, pq[1].x, false, false);

@@ -171,7 +171,7 @@ __device__ __forceinline__ float gelu_erf(float g) { return 0.5f * g * (1.0f + e
 // finalize kernel reads each (image, group) as one contiguous run:
 //     stats[((b * N + n) * R + r) * 2 + {0,1}] = {sum, sum of squares} of channel n over row block r of image b
 // Row blocks never straddle two images (R = ConvParams::stats_R blocks per image):
-//   conv3x3   : r = (ty*tiles_x + tx)*2 + wave_m      (half a pixel tile)
+//   conv3x3   : r = ty*tiles_x + tx (8x16 tiles, both wave halves combined through LDS) or (ty*tiles_x + tx)*2 + wave_m (8x8 tiles)
 //   gemm/igemm: r = (m % HW) / 32                      (32 consecutive rows; needs HW % 32 == 0)
 // conv_stats_blocks_per_image() returns R for a launch (0 = not supported -> the caller falls back to the separate
 // statistics pass of kernels_norm.hip).

@@ -630,12 +630,45 @@ __global__ __launch_bounds__(256, BN > 128 ? 1 : 2) void conv3x3w_kernel(const C
       }
     }
   }
-  if (p.stats) {   // fused GroupNorm statistics of this half tile (common.h)
-    bool ok[MT];
+  if (p.stats) {   // fused GroupNorm statistics of this pixel tile (common.h): one row block per workgroup
+    // per wave: sums over its 64 pixels (in-lane over the m-tiles, DPP over the 16 pixels of a row group); the two waves that
+    // share a channel half (wave_m = 0, 1) are combined through LDS (free after the main loop's last barrier), so the
+    // finalize kernel reads half as many partials as with one block per wave
+    float2 sq[NT][4];
 #pragma unroll
-    for (int m = 0; m < MT; ++m) ok[m] = mrow[m] >= 0;
-    const long long R = p.stats_R, rblk = (((long long)q_par * tiles_y + ty) * tiles_x + tx) * 2 + wave_m;
-    wave_stats_store<MT, NT>(acc, ok, 0, MT, p.stats + ((long long)b * p.N * R + rblk) * 2, R, p.N, ncol, l15);
+    for (int a = 0; a < NT; ++a) {
+      float sv[4] = {0.f, 0.f, 0.f, 0.f}, qv[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        if (mrow[m] < 0) continue;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { const float v = acc[a][m][r]; sv[r] += v; qv[r] += v * v; }
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) sq[a][r] = make_float2(row16_sum(sv[r]), row16_sum(qv[r]));
+    }
+    float2* xch = reinterpret_cast<float2*>(smem_raw);   // [wave_n][a][g][r]
+    if (wave_m == 1 && l15 == 0) {
+#pragma unroll
+      for (int a = 0; a < NT; ++a)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) xch[((wave_n * NT + a) * 4 + g) * 4 + r] = sq[a][r];
+    }
+    __syncthreads();
+    if (wave_m == 0 && l15 == 0) {
+      const long long R = p.stats_R, rblk = ((long long)q_par * tiles_y + ty) * tiles_x + tx;
+      float* dst = p.stats + ((long long)b * p.N * R + rblk) * 2;
+#pragma unroll
+      for (int a = 0; a < NT; ++a) {
+        const int n = ncol + a * 16;
+        if (n >= p.N) continue;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float2 t = xch[((wave_n * NT + a) * 4 + g) * 4 + r];
+          *reinterpret_cast<float2*>(dst + (long long)(n + r) * R * 2) = make_float2(sq[a][r].x + t.x, sq[a][r].y + t.y);
+        }
+      }
+    }
   }
 }
 
@@ -734,7 +767,8 @@ static inline int c3_tile_w(const ConvParams& p) { return (p.w_par ? p.Win : p.W
 int conv3x3_stats_blocks(const ConvParams& p) {
   const int TW = c3_tile_w(p);
   const int Ht = p.w_par ? p.Hin : p.Hout, Wt = p.w_par ? p.Win : p.Wout;
-  return ((Ht + 7) / 8) * ((Wt + TW - 1) / TW) * 2 * (p.w_par ? 4 : 1);
+  // 8x16 tiles (wide kernel): one block per workgroup; 8x8 tiles: one per wave half
+  return ((Ht + 7) / 8) * ((Wt + TW - 1) / TW) * (TW == 16 ? 1 : 2) * (p.w_par ? 4 : 1);
 }
 
 // w_par[q][n][t][c] = sum of the 3x3 taps of w[n][ky][kx][c] that read the same source pixel for output parity q=(py,px):

@@ -32,7 +32,9 @@ struct VLayout {
 
 // MINW = waves per SIMD the register allocation must allow: 2 keeps the whole accumulator file in VGPRs (no
 // v_accvgpr_read/write traffic around the softmax / rescale VALU work); the large-head variants need 1.
-template <int DQK, int DV, int BKV, int QT, int MINW>
+// ONES: the head dim leaves padding columns in the V tile (d < DV, e.g. 40 of 48): column d of V is set to 1, so row d of O^T
+// accumulates the softmax row sums inside the P.V MFMAs and the per-score adds and cross-lane sums of the (VALU-bound) softmax go.
+template <int DQK, int DV, int BKV, int QT, int MINW, bool ONES>
 __global__ __launch_bounds__(256, MINW) void attn_kernel(const AttnParams p) {
   using KL = KLayout<DQK>;
   constexpr int KS = DQK / 32;        // MFMA k-steps for Q K^T
@@ -97,6 +99,7 @@ __global__ __launch_bounds__(256, MINW) void attn_kernel(const AttnParams p) {
         const int c = tid + i * 256, row = c / (DV / 8), ch = c - row * (DV / 8);
         uint4 v = make_uint4(0, 0, 0, 0);
         if (c < VCH && kv0 + row < p.Lk && ch * 8 < d) v = *reinterpret_cast<const uint4*>(Vp + (long long)(kv0 + row) * p.ldv + ch * 8);
+        if (ONES && c < VCH && kv0 + row < p.Lk && ch * 8 == d) v.x = 0x3C00u;   // V[key][d] = 1.0 (fp16), the rest of the padding stays 0
         rv[i] = v;
       }
     }
@@ -113,6 +116,7 @@ __global__ __launch_bounds__(256, MINW) void attn_kernel(const AttnParams p) {
       uint4 v = make_uint4(0, 0, 0, 0);
       if (PFV) v = rv[i];
       else if (c < VCH && kv0 + row < p.Lk && ch * 8 < d) v = *reinterpret_cast<const uint4*>(Vp + (long long)(kv0 + row) * p.ldv + ch * 8);
+      else if (ONES && c < VCH && kv0 + row < p.Lk && ch * 8 == d) v.x = 0x3C00u;
       if (c < VCH) *reinterpret_cast<uint4*>(sV + row * VSTR + ch * 4) = v;
     }
   };
@@ -175,12 +179,14 @@ __global__ __launch_bounds__(256, MINW) void attn_kernel(const AttnParams p) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           float pv = __builtin_amdgcn_exp2f(fmaf(sacc[qt][t][r], sl2, moff));
-          rs += pv;
+          if (!ONES) rs += pv;
           pf[qt][t >> 1][(t & 1) * 4 + r] = (f16)pv;
         }
-      rs += __shfl_xor(rs, 16);
-      rs += __shfl_xor(rs, 32);
-      lrun[qt] = lrun[qt] * alpha + rs;
+      if (!ONES) {
+        rs += __shfl_xor(rs, 16);
+        rs += __shfl_xor(rs, 32);
+        lrun[qt] = lrun[qt] * alpha + rs;
+      }
       mrun[qt] = mnew;
 #pragma unroll
       for (int dt = 0; dt < DT; ++dt) {
@@ -215,7 +221,17 @@ __global__ __launch_bounds__(256, MINW) void attn_kernel(const AttnParams p) {
 #pragma unroll
   for (int qt = 0; qt < QT; ++qt) {
     const int qi = qbase + qt * 16 + l15;
-    const float inv = 1.0f / lrun[qt];
+    float lsum = lrun[qt];
+    if (ONES) {   // the row sum sits in O^T row d: lane (g = (d%16)/4, same l15), register d%4 of d tile d/16
+      float cand = 0.f;
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (dt * 16 + g * 4 + r == d) cand = oacc[qt][dt][r];
+      lsum = __shfl(cand, ((d & 15) >> 2) * 16 + l15);
+    }
+    const float inv = 1.0f / lsum;
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) {
       const int dd = dt * 16 + g * 4;
@@ -227,11 +243,18 @@ __global__ __launch_bounds__(256, MINW) void attn_kernel(const AttnParams p) {
   }
 }
 
+template <int DQK, int DV, int BKV, int QT, int MINW, bool ONES>
+static void launch_attn_cfg2(const AttnParams& p, hipStream_t s);
 template <int DQK, int DV, int BKV, int QT, int MINW = 2>
 static void launch_attn_cfg(const AttnParams& p, hipStream_t s) {
+  if (p.d < DV) launch_attn_cfg2<DQK, DV, BKV, QT, MINW, true>(p, s);    // a padding column of V is free for the row sums
+  else launch_attn_cfg2<DQK, DV, BKV, QT, MINW, false>(p, s);
+}
+template <int DQK, int DV, int BKV, int QT, int MINW, bool ONES>
+static void launch_attn_cfg2(const AttnParams& p, hipStream_t s) {
   static bool attr_set = false;
   const size_t smem = (size_t)BKV * KLayout<DQK>::STR * 16 + (size_t)BKV * VLayout<DV>::STR_DW * 4;
-  auto kern = attn_kernel<DQK, DV, BKV, QT, MINW>;
+  auto kern = attn_kernel<DQK, DV, BKV, QT, MINW, ONES>;
   if (!attr_set) {
     HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     attr_set = true;

@@ -448,3 +448,73 @@ def test_training_time_features_v5_against_oracle(tiny):
     # the UNet output is decoded WITHOUT the 1/scaling_factor (ldiffusion.py:240): the decoder sees inputs ~5x larger than in the
     # sampler and its fp16 storage error grows with them: 2e-2 of the range here (measured 7e-3 / 1e-2)
     assert got["gray"].shape == (2, nts, 64, 64) and eg < 2e-2 and er < 2e-2
+
+
+def _fixture_context(z):
+    """The text conditioning of the reference fixture: token table lookup + the 768->cad projection (segmentor.py:54-60)."""
+    table = torch.randn((49408, int(z["hidden"])), generator=torch.Generator().manual_seed(99)) * 0.5
+    emb = table[torch.tensor([z["ids"].tolist()])]
+    return torch.nn.functional.linear(emb, torch.from_numpy(z["proj_weight"]), torch.from_numpy(z["proj_bias"]))
+
+
+def test_segmentor_mirror_augment_against_reference_fixture(tiny):
+    """ldiffusion_amd.Segmentor.ldiffusion_augment (batched, on the device) against tests/golden/reference_augment_v3.npz, which
+    was produced by the REFERENCE's own Segmentor.ldiffusion_augment (segmentor.py:86-112) driven with the oracle objects."""
+    import os
+    from ldiffusion_amd.segmentor import Segmentor, TextAlignedUNet
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "reference_augment_v3.npz"))
+    inputs = torch.rand((2, 3, 64, 64), generator=torch.Generator().manual_seed(int(z["inputs_seed"])))
+    ctx = _fixture_context(z).to(DEV)
+    seg = Segmentor(None, None, "cell", 3)
+    out = seg.ldiffusion_augment(inputs, tiny["pipe"], tiny["unet"], tiny["vae"], text_embeddings=ctx)
+    assert list(out.shape) == z["out_shape"].tolist() and out.dtype == torch.float32 and out.is_cuda
+    pooled = torch.nn.functional.avg_pool2d(out, 64).cpu().numpy()
+    d = np.abs(pooled - z["pooled"]).max()
+    print(f"segmentor mirror vs reference fixture: max |pooled diff| = {d:.2e}")
+    assert d < 6e-3                                            # <= ~1.5 grey levels after fp16 storage
+    # F12: the text-align wrapper substitutes its cached embeddings when the caller passes None or a wrong width
+    wrapped = TextAlignedUNet(tiny["unet"], ctx)
+    x = torch.randn((2, 4, 8, 8), generator=torch.Generator().manual_seed(1)).to(DEV)
+    ref = tiny["unet"](x, 1, ctx).sample
+    assert torch.equal(wrapped(x, 1, None).sample, ref)
+    assert torch.equal(wrapped(x, 1, torch.zeros((2, 5, 7), device=DEV)).sample, ref)
+    with pytest.raises(ValueError):
+        seg.initialize_model("organ", 3)
+    with pytest.raises(RuntimeError):
+        seg.inference_cell_model("x.png", "sd", "w", None)     # no head: refuses instead of substituting one
+
+
+def test_segmentor_mirror_inference_cell_model_end_to_end(tiny, tmp_path):
+    """segmentor.py:490-545 through the mirror: checkpoint directories in the diffusers layout -> load_ldiffusion -> 1024x1024
+    single pass -> decoded RGB handed to the head ON THE DEVICE -> arg-max -> NEAREST resize to the input size."""
+    import json
+    from PIL import Image
+    from ldiffusion_amd.segmentor import IMAGENET_MEAN, IMAGENET_STD, Segmentor
+    sd_dir, w_dir = tmp_path / "sd", tmp_path / "train_save" / "unet" / "25_01_01"
+    tiny["unet"].save_pretrained(str(sd_dir / "unet"))
+    tiny["vae"].save_pretrained(str(sd_dir / "vae"))
+    tiny["unet"].save_pretrained(str(w_dir))
+    rng = np.random.default_rng(5)
+    img = (rng.random((96, 80, 3)) * 255).astype(np.uint8)
+    path = tmp_path / "roi.png"
+    Image.fromarray(img).save(path)
+    ctx = (torch.randn((1, 6, 64), generator=torch.Generator().manual_seed(2)) * 0.5).to(DEV)
+    seen = {}
+
+    def head(x):                                               # stand-in for CellSegClassifier: 3-class logits from the decoded image
+        seen["device"], seen["shape"] = x.device.type, tuple(x.shape)
+        return torch.stack([x[:, 0], x[:, 1] * 0.5, -x[:, 2]], 1)
+
+    seg = Segmentor(None, None, "cell", 3)
+    decoded, mask = seg.inference_cell_model(str(path), str(sd_dir), str(w_dir), None, head=head, text_embeddings=ctx)
+    assert seen == {"device": "cuda", "shape": (1, 3, 1024, 1024)}
+    assert decoded.size == (80, 96) and mask.shape == (96, 80) and mask.dtype == np.uint8 and mask.max() <= 2
+    # the same path by hand on the oracle
+    mean, std = torch.tensor(IMAGENET_MEAN).view(1, 3, 1, 1), torch.tensor(IMAGENET_STD).view(1, 3, 1, 1)
+    x = torch.from_numpy(np.asarray(Image.fromarray(img).resize((1024, 1024), Image.BILINEAR), np.float32) / 255.0).permute(2, 0, 1)[None]
+    r = op.sample_one_pass(tiny["opipe"], (x - mean) / std, ctx.cpu())
+    logits = head((torch.from_numpy(r["rgb_u8"]).permute(0, 3, 1, 2).float() / 255.0 - mean) / std)
+    rmask = np.array(Image.fromarray(np.asarray(noise_post.argmax_mask(logits)[0]).astype(np.uint8)).resize((80, 96), resample=Image.NEAREST))
+    agree = (mask == rmask).mean()
+    print(f"inference_cell_model mirror: mask agreement with the oracle {agree:.4f}")
+    assert agree > 0.97

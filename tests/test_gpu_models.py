@@ -518,3 +518,16 @@ def test_segmentor_mirror_inference_cell_model_end_to_end(tiny, tmp_path):
     agree = (mask == rmask).mean()
     print(f"inference_cell_model mirror: mask agreement with the oracle {agree:.4f}")
     assert agree > 0.97
+
+
+def test_orchestrator_mirror_errors(tmp_path):
+    """ldiffusion_amd.LDiffusionModel keeps the reference's constructor / inference signature and its error for a bad level
+    (ldiffusion.py:32,317-324); what is outside the hot path raises instead of silently doing something else."""
+    from ldiffusion_amd.ldiffusion import LDiffusionModel
+    m = LDiffusionModel(str(tmp_path), "organ")
+    with pytest.raises(ValueError, match="Invalid level specified"):
+        m.inference("x.png", "w", None, 3, head=lambda x: x)
+    with pytest.raises(RuntimeError):
+        LDiffusionModel(str(tmp_path), "tissue").inference("x.png", "w", None, 6)
+    with pytest.raises(NotImplementedError):
+        LDiffusionModel(str(tmp_path), "cell", local_rank=0).train(None)

@@ -121,3 +121,23 @@ def test_gather_masks_world_size_2_gloo(tmp_path):
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=240, env=dict(os.environ, OMP_NUM_THREADS="1"))
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert (tmp_path / "rank0.ok").exists() and (tmp_path / "rank1.ok").exists(), r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_pixel_latent_vector_export_matches_reference_loop(tmp_path):
+    """ldiffusion_amd.pixel_latent_vector (vectorised) writes byte for byte the CSV of the reference's per-pixel dict loop
+    (pixel_latent_vector.py:85-101, restated with the csv module in oracle/pixel_export.py)."""
+    import numpy as np
+    from ldiffusion_amd import pixel_latent_vector as plv
+    from oracle import pixel_export as ope
+    rng = np.random.default_rng(0)
+    for (n, h, w) in [(5, 7, 9), (1, 3, 4), (20, 16, 12)]:
+        feats = rng.integers(0, 256, size=(n, h, w), dtype=np.uint8)
+        label = rng.integers(0, 11, size=(h, w)).astype(np.uint8)
+        assert plv.generate_title(n) == ope.generate_title(n)
+        tab = plv.pixel_table(torch.from_numpy(feats), torch.from_numpy(label))
+        assert tab.shape == (h * w, n + 1) and tab[w + 2, :n].tolist() == feats[:, 1, 2].tolist() and tab[w + 2, n] == label[1, 2]
+        p = tmp_path / f"pixel_dict_{n}.csv"
+        plv.write_pixel_csv(str(p), torch.from_numpy(feats), torch.from_numpy(label))
+        assert p.read_bytes() == ope.pixel_csv_bytes([feats[k] for k in range(n)], label)
+    with pytest.raises(ValueError):
+        plv.pixel_table(np.zeros((2, 3, 3), np.uint8), np.zeros((4, 3), np.uint8))

@@ -65,6 +65,8 @@ struct ConvParams {
   int M;                  // B*Hout*Wout
   float* stats;           // optional fused GroupNorm partial statistics of the output (see below)
   int stats_R;            // row blocks per image of `stats`
+  long long w_bstride;    // gemm_dma only: > 0 => one weight matrix (and bias vector, bias_bstride) PER IMAGE: image b = row / (Hout*Wout)
+  int bias_bstride;       //   (GroupNorm folded into a 1x1 conv: W_b = W diag(scale_b), bias_b = bias + W shift_b); tiles never straddle images
   int geglu;              // gemm_dma only: weight rows are x/gate-interleaved by 16 (MatW::geglu); y[m, n/2..] = x * gelu_erf(gate), ldy counts the N/2 outputs
   int splitk;             // conv3x3 only: >1 => K (input-channel slabs) split over blockIdx.y, fp32 partials to splitk_ws
   float* splitk_ws;       // [splitk][M][N] fp32 workspace (then reduced + epilogue by splitk_reduce)
@@ -116,6 +118,8 @@ void launch_decode_post(const float* x, int ldx, int B, int H, int W, float* img
                         uint8_t* rgb_u8 /*[B,H,W,3] or null*/, uint8_t* luma /*base of [B,N,H,W] or null*/, int n_slots, int slot,
                         hipStream_t s);
 void launch_argmax_u8(const float* logits, int B, int C, int H, int W, uint8_t* mask, hipStream_t s);
+void launch_fold_gn_weights(const f16* w, const float* bias, const float* scale, const float* shift, f16* wb, float* biasb, int B, int Nrows, int C,
+                            hipStream_t s);
 void launch_bilinear_resize(const float* x, float* y, int B, int C, int H, int W, int oh, int ow, hipStream_t s);
 void launch_luma_float(const float* rgb_nchw, float* gray, int B, int H, int W, hipStream_t s);
 

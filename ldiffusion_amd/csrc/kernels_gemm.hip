@@ -81,7 +81,11 @@ __global__ __launch_bounds__(256, 2) void gemm_dma_kernel(const ConvParams p) {
   }
   const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)((long long)p.M * p.C1 * 2), 0x00020000);
   const __amdgpu_buffer_rsrc_t rs2 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x2 ? p.x2 : p.x), 0, (int)((long long)p.M * (p.x2 ? p.C2 : p.C1) * 2), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, (int)((long long)p.Nrows * p.K * 2), 0x00020000);
+  // per-image weights (GroupNorm folded into the layer): tiles never straddle images, so the image of this tile is uniform
+  const int img = p.w_bstride > 0 ? m0 / (p.Hout * p.Wout) : 0;
+  const f16* wmat = p.w + (long long)img * p.w_bstride;
+  const float* bvec = p.bias ? p.bias + (long long)img * p.bias_bstride : nullptr;
+  const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)wmat, 0, (int)((long long)p.Nrows * p.K * 2), 0x00020000);
   const int kt2 = p.C1 / 64;   // first K-step of the second concat source
   auto issue = [&](int kt, auto bufc) {
     constexpr int buf = decltype(bufc)::value;
@@ -163,7 +167,7 @@ __global__ __launch_bounds__(256, 2) void gemm_dma_kernel(const ConvParams p) {
 #pragma unroll
   for (int a = 0; a < NT; ++a) {
     float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (p.bias && ncol + a * 16 < p.N) t = *reinterpret_cast<const float4*>(p.bias + ncol + a * 16);
+    if (bvec && ncol + a * 16 < p.N) t = *reinterpret_cast<const float4*>(bvec + ncol + a * 16);
     bb[a] = (f32x4){t.x, t.y, t.z, t.w};
   }
   int mrow[MT];
@@ -284,6 +288,7 @@ void launch_g(const ConvParams& p, hipStream_t s) {
 }  // namespace
 
 bool gemm_dma_eligible(const ConvParams& p) {
+  if (p.w_bstride > 0 && ((p.Hout * p.Wout) % 64 != 0 || p.stats)) return false;   // a tile must lie inside one image
   if (p.geglu && (p.N % 32 != 0 || (p.ldy & 7) != 0 || p.res || p.out_f32 || p.stats)) return false;
   return p.ks == 1 && p.stride == 1 && p.ups == 0 && p.pad_t == 0 && p.pad_l == 0 && !p.gn_scale && !p.temb && p.K % 64 == 0 && p.C1 % 64 == 0 &&
          p.Hout == p.Hin && p.Wout == p.Win && p.M < (1 << 24) && (p.C1 > p.C2 ? p.C1 : p.C2) * 2 < (1 << 24) && (long long)p.M * (p.C1 > p.C2 ? p.C1 : p.C2) * 2 < (1LL << 32) && (long long)p.Nrows * p.K * 2 < (1LL << 32);
@@ -292,7 +297,8 @@ bool gemm_dma_eligible(const ConvParams& p) {
 void launch_gemm_dma(const ConvParams& p, hipStream_t s) {
   auto tiles = [&](int bm, int bn) { return (long long)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn); };
   const bool n_small = p.N <= 64 || (p.N % 128 != 0 && p.N % 128 <= 64 && p.N < 512);
-  if (!n_small && tiles(128, 128) >= 384) launch_g<128, 128>(p, s);
-  else if (tiles(128, 64) >= 384) launch_g<128, 64>(p, s);
+  const bool bm128_ok = p.w_bstride == 0 || (p.Hout * p.Wout) % 128 == 0;   // per-image weights: 128-row tiles only if they divide an image
+  if (!n_small && bm128_ok && tiles(128, 128) >= 384) launch_g<128, 128>(p, s);
+  else if (bm128_ok && tiles(128, 64) >= 384) launch_g<128, 64>(p, s);
   else launch_g<64, 64>(p, s);
 }

@@ -214,3 +214,41 @@ void launch_layernorm(const f16* x, f16* y, int rows, int C, const float* gamma,
   hipLaunchKernelGGL(layernorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, x, y, rows, C, gamma, beta, eps);
   HIP_CHECK(hipGetLastError());
 }
+
+
+// ---- GroupNorm folded into a following 1x1 convolution / linear layer (no activation in between) -------------------------
+// y = W (s_b * x + t_b) + bias = (W diag(s_b)) x + (bias + W t_b): per image b the normalisation becomes a scaled copy of the
+// weights and a bias vector, and the contraction itself runs as a plain GEMM on the LDS-DMA kernel (transformer proj_in and the
+// VAE attention q/k/v: GroupNorm -> conv1x1 / Linear without SiLU).  One workgroup per (image, 4 weight rows).
+__global__ __launch_bounds__(256) void fold_gn_weights_kernel(const f16* __restrict__ w, const float* __restrict__ bias, const float* __restrict__ scale,
+                                                               const float* __restrict__ shift, f16* __restrict__ wb, float* __restrict__ biasb,
+                                                               int Nrows, int C) {
+  const int b = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int n = blockIdx.x * 4 + wave;
+  if (n >= Nrows) return;
+  const f16* wr = w + (long long)n * C;
+  f16* o = wb + ((long long)b * Nrows + n) * C;
+  const float* sc = scale + (long long)b * C;
+  const float* sh = shift + (long long)b * C;
+  float acc = 0.f;
+  for (int c = lane * 8; c < C; c += 512) {   // C % 8 == 0
+    const f16x8 v = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(wr + c));
+    f16x8 r;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float wv = (float)v[j];
+      r[j] = (f16)(wv * sc[c + j]);
+      acc += wv * sh[c + j];
+    }
+    *reinterpret_cast<uint4*>(o + c) = __builtin_bit_cast(uint4, r);
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off);
+  if (lane == 0) biasb[(long long)b * Nrows + n] = acc + (bias ? bias[n] : 0.f);
+}
+void launch_fold_gn_weights(const f16* w, const float* bias, const float* scale, const float* shift, f16* wb, float* biasb, int B, int Nrows, int C,
+                            hipStream_t s) {
+  LDIFF_CHECK(C % 8 == 0, LDIFF_ERR_INVALID, "fold_gn_weights: C=%d must be a multiple of 8", C);
+  hipLaunchKernelGGL(fold_gn_weights_kernel, dim3((Nrows + 3) / 4, B), dim3(256), 0, s, w, bias, scale, shift, wb, biasb, Nrows, C);
+  HIP_CHECK(hipGetLastError());
+}

@@ -259,7 +259,20 @@ Act Exec::conv(const MatW& w, const Act& x, const Act* x2, const ConvOpts& o) {
   p.w = w.w; p.Nrows = w.Nrows; p.K = w.K;
   p.N = o.N_override ? o.N_override : roundup(w.N, 4);
   p.bias = w.b;
+  f16* wfold = nullptr;
+  float* bfold = nullptr;
   if (o.gn) { p.gn_scale = o.gn->scale; p.gn_shift = o.gn->shift; p.silu_in = o.silu; }
+  // GroupNorm -> 1x1 conv / Linear with no activation in between (transformer proj_in, VAE attention q/k/v): fold the
+  // normalisation into per-image weights and bias and run the plain LDS-DMA GEMM instead of the register-staged GN prologue
+  const bool fold = o.gn && !o.silu && w.ks == 1 && o.stride == 1 && !x2 && !o.temb && !o.out_f32 && !o.geglu && w.K % 64 == 0 && x.C % 64 == 0 &&
+                    ((x.H * x.W) % 64 == 0) && !o.want_stats;
+  if (fold) {
+    wfold = tmp<f16>((size_t)x.B * w.Nrows * w.K);
+    bfold = tmp<float>((size_t)x.B * w.Nrows);
+    launch_fold_gn_weights(w.w, w.b, o.gn->scale, o.gn->shift, wfold, bfold, x.B, w.Nrows, w.K, s);
+    p.gn_scale = nullptr; p.gn_shift = nullptr; p.silu_in = 0;
+    p.w = wfold; p.bias = bfold; p.w_bstride = (long long)w.Nrows * w.K; p.bias_bstride = w.Nrows;
+  }
   p.temb = o.temb; p.ld_temb = o.ld_temb;
   p.M = x.B * p.Hout * p.Wout;
   if (o.res) {
@@ -310,6 +323,7 @@ Act Exec::conv(const MatW& w, const Act& x, const Act* x2, const ConvOpts& o) {
   else p.splitk = 0;
   launch_igemm(p, s);
   if (p.splitk_ws) arena.free(p.splitk_ws);   // stream-ordered reuse: safe once the launches are enqueued
+  if (wfold) { arena.free(bfold); arena.free(wfold); }
   return y;
 }
 Act Exec::layernorm(const Act& x, const NormW& w) {

@@ -43,8 +43,8 @@ UNET_FLOP_PER_SAMPLE = 797.3e9
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU oracle timing (rank 0, N=1)")
     ap.add_argument("--no-prof", action="store_true", help="skip the per-launch HIP-event profile")
     ap.add_argument("--no-unet-step", action="store_true", help="skip the separate UNet-step timing (used under rocprofv3 so that the\n                    kernel mix of the whole process equals the mix of the timed region)")

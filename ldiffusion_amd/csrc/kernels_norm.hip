@@ -115,7 +115,19 @@ __global__ __launch_bounds__(256) void gn_finalize2_kernel(const float* __restri
     const bool second = c >= C1;
     const int R = second ? R2 : R1;
     const float2* base = reinterpret_cast<const float2*>(second ? p2 + ((long long)b * C2 + (c - C1)) * R2 * 2 : p1 + ((long long)b * C1 + c) * R1 * 2);
-    for (int r = tid; r < R; r += 256) { const float2 v = base[r]; a += (double)v.x; q += (double)v.y; }
+    // R is 2048-4096 on the 512^2 VAE layers: four 16-byte loads (two partials each) in flight per thread instead of a chain of
+    // dependent 8-byte ones; the short tail (and odd R) goes one partial at a time
+    const int R2f = (R & 1) ? 0 : R / 2;   // number of float4 (= 2 partials); rows are 8-byte aligned, 16-byte when R is even
+    const float4* b4 = reinterpret_cast<const float4*>(base);
+    int r = tid;
+    for (; r + 768 < R2f; r += 1024) {
+      const float4 v0 = b4[r], v1 = b4[r + 256], v2 = b4[r + 512], v3 = b4[r + 768];
+      a += (double)((v0.x + v0.z) + (v1.x + v1.z)) + (double)((v2.x + v2.z) + (v3.x + v3.z));
+      q += (double)((v0.y + v0.w) + (v1.y + v1.w)) + (double)((v2.y + v2.w) + (v3.y + v3.w));
+    }
+    for (; r < R2f; r += 256) { const float4 v = b4[r]; a += (double)v.x + (double)v.z; q += (double)v.y + (double)v.w; }
+    if (R2f == 0)
+      for (int r1 = tid; r1 < R; r1 += 256) { const float2 v = base[r1]; a += (double)v.x; q += (double)v.y; }
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o); q += __shfl_xor(q, o); }

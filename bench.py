@@ -110,12 +110,20 @@ def main():
         raise SystemExit("bench.py needs a ROCm GPU: there is no CPU fallback for the product path")
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    # LDIFF_BENCH_SHARED_GPU=1 (test only, not a valid bench line): all ranks on cuda:0 over gloo, to exercise the multi-rank
+    # control flow (barrier, max over ranks, mask all-gather) on a single-GPU box; the real run is one rank per GPU over RCCL.
+    shared = os.environ.get("LDIFF_BENCH_SHARED_GPU") == "1"
+    if shared:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device(f"cuda:{local_rank}")
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if shared:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     from ldiffusion_amd import _lib, configs, weights
     from ldiffusion_amd.models import AutoencoderKL, UNet2DConditionModel

@@ -1,6 +1,6 @@
 """bench.py -- headline benchmark of the Laplace-diffusion sampling path on MI355X.
 
-  python bench.py --gpus N --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W          (N > 1 without a launcher: spawns the N ranks itself)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 A "step" is one pass of the hot path over one batch of synthetic input: BASELINE.json configs[1] -- 8 patches of
@@ -48,6 +48,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU oracle timing (rank 0, N=1)")
     ap.add_argument("--no-prof", action="store_true", help="skip the per-launch HIP-event profile")
     ap.add_argument("--no-unet-step", action="store_true", help="skip the separate UNet-step timing (used under rocprofv3 so that the\n                    kernel mix of the whole process equals the mix of the timed region)")
+    ap.add_argument("--launch-check", action="store_true", help="rendezvous only (gloo, no GPU): every rank joins, all-reduces its rank and rank 0 prints\n                    {launch_check, n_gpus}; covers the self-launch / env contract on a CPU box")
     ap.add_argument("--tiny", action="store_true", help="reduced-width graph + 64x64 patches (plumbing check only; not a valid bench line)")
     return ap.parse_args()
 
@@ -101,15 +102,46 @@ def cpu_baseline(ucfg, vcfg, usd, vsd, img, n_passes):
                       f"torch {torch.__version__}, {threads} threads -- not diffusers"}
 
 
+def self_launch(args) -> int:
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: start N fresh worker processes through
+    torch.distributed.run (one rank per GPU) and return their exit code.  The parent never touches the GPU and never
+    re-executes itself (an exec from a process that initialised HIP takes the box down); rank 0 of the children prints the
+    one JSON line on the inherited stdout."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     args = parse()
+    # launch decision first, before anything can initialise the GPU
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher and the flag disagree")
+    if args.launch_check:
+        import torch.distributed as dist
+        if world > 1:
+            dist.init_process_group("gloo")
+            t = torch.tensor([float(rank)])
+            dist.all_reduce(t)
+            assert t.item() == world * (world - 1) / 2
+            dist.barrier()
+            dist.destroy_process_group()
+        if rank == 0:
+            print(json.dumps({"launch_check": True, "n_gpus": world, "local_rank": local_rank}), flush=True)
+        return
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU: there is no CPU fallback for the product path")
-    if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     # LDIFF_BENCH_SHARED_GPU=1 (test only, not a valid bench line): all ranks on cuda:0 over gloo, to exercise the multi-rank
     # control flow (barrier, max over ranks, mask all-gather) on a single-GPU box; the real run is one rank per GPU over RCCL.
     shared = os.environ.get("LDIFF_BENCH_SHARED_GPU") == "1"
@@ -132,8 +164,8 @@ def main():
 
     ucfg, vcfg = (configs.TINY_UNET, configs.TINY_VAE) if args.tiny else (configs.SD15_UNET, configs.SD15_VAE)
     img = 64 if args.tiny else IMG
-    usd = weights.synthetic_state_dict(weights.unet_param_shapes(ucfg), 42)
-    vsd = weights.synthetic_state_dict(weights.vae_param_shapes(vcfg), 43)
+    usd = weights.synthetic_state_dict(weights.unet_param_shapes(ucfg), 42, fp16_values=True)
+    vsd = weights.synthetic_state_dict(weights.vae_param_shapes(vcfg), 43, fp16_values=True)
     pipe = StableDiffusionImg2ImgPipeline(AutoencoderKL(vcfg, vsd, dev), UNet2DConditionModel(ucfg, usd, dev))
     sampler = LaplaceSampler(pipe)
 

@@ -12,10 +12,12 @@
  *     -2 = HIP runtime failure, -3 = handle not ready (weights/context missing) (python: RuntimeError).
  *   - tensors crossing the boundary are plain device pointers in the layouts the reference uses:
  *     float32, NCHW, contiguous (torch_dtype=torch.float32 everywhere: ldiffusion.py:67, segmentor.py:77).
- *     Internally activations are NHWC fp16 with fp32 accumulation.
+ *     Internally activations are NHWC fp16 with fp32 accumulation; the residual stream is kept as fp16 hi|lo pairs
+ *     (ldiff_unet_set_precision).
  *   - handles own device weights and workspace; caller-owned buffers are never retained past a call.
  *   - all work is enqueued on the caller's HIP stream (`stream` = hipStream_t, e.g. torch's current
- *     stream); no hidden synchronisation.  A handle is thread-compatible, not thread-safe.
+ *     stream); no hidden synchronisation.  A handle is thread-compatible, not thread-safe; handles on different
+ *     devices are independent (no process-wide device state in the library).
  *   - there is no CPU fallback anywhere: a missing GPU or code object is an error.
  */
 #ifndef LDIFF_H
@@ -25,7 +27,7 @@
 extern "C" {
 #endif
 
-#define LDIFF_VERSION 100 /* 0.1.0 */
+#define LDIFF_VERSION 110 /* 0.1.1 */
 #define LDIFF_MAX_BLOCKS 8
 
 typedef enum { LDIFF_OK = 0, LDIFF_ERR_INVALID = -1, LDIFF_ERR_RUNTIME = -2, LDIFF_ERR_STATE = -3 } ldiff_status;
@@ -59,6 +61,11 @@ int ldiff_unet_create(ldiff_unet** out, const ldiff_unet_cfg* cfg, int device);
 /* Copy one tensor of diffusion_pytorch_model.safetensors (diffusers key names, torch layouts) to the device.
  * (from_pretrained: segmentor.py:79, ldiffusion.py:67) */
 int ldiff_unet_load(ldiff_unet*, const char* name, const void* host_ptr, int dtype, const int64_t* shape, int ndim);
+/* Storage policy of the graph (the reference computes in fp32: ldiffusion.py:67; every MFMA operand here is fp16):
+ *   0 = all activations fp16 in HBM (fastest; ~2e-3 of the output range per UNet pass)
+ *   1 = residual stream kept as fp16 hi|lo pairs (adds to fp32 round-off), stream-carrying contractions on split operands (default)
+ *   2 = every conv / linear operand split (K doubled): ~1e-4 */
+int ldiff_unet_set_precision(ldiff_unet*, int mode);
 /* number of expected tensors not loaded yet; names via ldiff_unet_missing_name(i) */
 int ldiff_unet_missing(ldiff_unet*);
 const char* ldiff_unet_missing_name(ldiff_unet*, int i);
@@ -85,6 +92,9 @@ typedef struct {
 
 int ldiff_vae_create(ldiff_vae** out, const ldiff_vae_cfg* cfg, int device);
 int ldiff_vae_load(ldiff_vae*, const char* name, const void* host_ptr, int dtype, const int64_t* shape, int ndim);
+/* storage policy of the encoder and of the decoder graph (see ldiff_unet_set_precision); defaults: encoder 2 (its error is
+ * inherited by every later pass of the sampler and it runs once per patch), decoder 1 */
+int ldiff_vae_set_precision(ldiff_vae*, int encoder_mode, int decoder_mode);
 int ldiff_vae_missing(ldiff_vae*);
 const char* ldiff_vae_missing_name(ldiff_vae*, int i);
 /* x [B,3,H,W] f32 NCHW -> moments [B, 2*latent, H/8, W/8] f32 NCHW (mean | logvar), i.e. quant_conv(encoder(x)) */
@@ -169,6 +179,9 @@ typedef struct {
   int geglu;                                        /* 1x1 / linear only: the weight rows are the [x | gate] rows of diffusers' GEGLU projection
                                                        interleaved by 16 (row r of x -> 32*(r/16) + r%16, of gate -> 32*(r/16) + 16 + r%16);
                                                        y[m, 0..N/2) = x * gelu_erf(gate), ldy counts those N/2 columns (N % 32 == 0) */
+  int ld1, ld2;                                     /* row pitch (elements) of x / x2; 0 = C1 / C2 */
+  int res_lo;                                       /* > 0: res is a split tensor (value = hi + lo), lo half res_lo elements after the hi half */
+  int y_lo;                                         /* > 0: write y split: hi at column n, lo = f16(v - hi) at column y_lo + n */
 } ldiff_conv_args;
 int ldiff_op_conv(const ldiff_conv_args*, void* stream);
 /* row blocks per image the launch would emit statistics for (0 = unsupported for this shape) */
@@ -178,11 +191,19 @@ int ldiff_op_gn_finalize(const void* part1, int R1, int C1, const void* part2, i
                          const void* gamma, const void* beta, void* scale, void* shift, void* stream);
 int ldiff_op_attention(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, void* o, int ldo, int B, int heads,
                        int Lq, int Lk, int d, int64_t q_bstride, int64_t kv_bstride, int64_t o_bstride, float scale, void* stream);
-int ldiff_op_gn_stats(const void* x, int C1, const void* x2, int C2, int B, int HW, int groups, float eps, const void* gamma,
-                      const void* beta, void* scale, void* shift, void* stream);
-int ldiff_op_layernorm(const void* x, void* y, int rows, int C, const void* gamma, const void* beta, float eps, void* stream);
+/* sources are (pointer, channels C, row pitch ld (0 = C), lo offset (0 = plain, > 0 = split tensor hi|lo)) */
+int ldiff_op_gn_stats(const void* x, int C1, int ld1, int lo1, const void* x2, int C2, int ld2, int lo2, int B, int HW, int groups, float eps,
+                      const void* gamma, const void* beta, void* scale, void* shift, void* stream);
+int ldiff_op_layernorm(const void* x, int ldx, int x_lo, void* y, int rows, int C, const void* gamma, const void* beta, float eps, void* stream);
+/* y[m, c] = act(x[m, c] * scale[b, c] + shift[b, c]) (GroupNorm-apply, optional SiLU) over the concat of one or two sources,
+ * written plain (y_lo = 0) or split */
+int ldiff_op_norm_apply(const void* x, int C1, int ld1, int lo1, const void* x2, int C2, int ld2, int lo2, int B, int HW, const void* scale,
+                        const void* shift, int silu, void* y, int ldy, int y_lo, void* stream);
+/* weights of a contraction over a split operand: per tap [a(Ca) b(Cb) ..] -> [a a b b 0..] */
+int ldiff_op_dup_weights(const void* w, void* wd, int Nrows, int taps, int src_tap_stride, int Ca, int Cb, int dst_tap_stride, void* stream);
 int ldiff_op_geglu(const void* x, void* y, int64_t M, int C4, void* stream);
-int ldiff_op_nchw_to_nhwc(const void* x_f32, void* y_f16, int B, int C, int H, int W, int Cpad, void* stream);
+/* lo_off > 0: also store the rounding remainder of channel c at channel lo_off + c (split first-layer input) */
+int ldiff_op_nchw_to_nhwc(const void* x_f32, void* y_f16, int B, int C, int H, int W, int Cpad, int lo_off, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Live measurement for bench.py's roofline line: when enabled, every conv/linear, attention and

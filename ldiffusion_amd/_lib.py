@@ -35,7 +35,7 @@ class ConvArgs(C.Structure):
                 ("gn_scale", C.c_void_p), ("gn_shift", C.c_void_p), ("silu_in", C.c_int),
                 ("bias", C.c_void_p), ("temb", C.c_void_p), ("ld_temb", C.c_int),
                 ("res", C.c_void_p), ("ld_res", C.c_int), ("y", C.c_void_p), ("ldy", C.c_int), ("out_f32", C.c_int), ("stats", C.c_void_p),
-                ("geglu", C.c_int)]
+                ("geglu", C.c_int), ("ld1", C.c_int), ("ld2", C.c_int), ("res_lo", C.c_int), ("y_lo", C.c_int)]
 
 
 # name -> (restype, argtypes); every symbol include/ldiff.h declares
@@ -45,6 +45,7 @@ SIGNATURES = {
     "ldiff_last_error": (C.c_char_p, []),
     "ldiff_unet_create": (I, [C.POINTER(P), C.POINTER(UNetCfg), I]),
     "ldiff_unet_load": (I, [P, C.c_char_p, P, I, C.POINTER(I64), I]),
+    "ldiff_unet_set_precision": (I, [P, I]),
     "ldiff_unet_missing": (I, [P]),
     "ldiff_unet_missing_name": (C.c_char_p, [P, I]),
     "ldiff_unet_set_context": (I, [P, P, I, I, P]),
@@ -52,6 +53,7 @@ SIGNATURES = {
     "ldiff_unet_destroy": (None, [P]),
     "ldiff_vae_create": (I, [C.POINTER(P), C.POINTER(VaeCfg), I]),
     "ldiff_vae_load": (I, [P, C.c_char_p, P, I, C.POINTER(I64), I]),
+    "ldiff_vae_set_precision": (I, [P, I, I]),
     "ldiff_vae_missing": (I, [P]),
     "ldiff_vae_missing_name": (C.c_char_p, [P, I]),
     "ldiff_vae_encode": (I, [P, P, I, I, I, P, P]),
@@ -75,10 +77,12 @@ SIGNATURES = {
     "ldiff_op_conv_stats_blocks": (I, [C.POINTER(ConvArgs)]),
     "ldiff_op_gn_finalize": (I, [P, I, I, P, I, I, I, I, I, F, P, P, P, P, P]),
     "ldiff_op_attention": (I, [P, I, P, I, P, I, P, I, I, I, I, I, I, I64, I64, I64, F, P]),
-    "ldiff_op_gn_stats": (I, [P, I, P, I, I, I, I, F, P, P, P, P, P]),
-    "ldiff_op_layernorm": (I, [P, P, I, I, P, P, F, P]),
+    "ldiff_op_gn_stats": (I, [P, I, I, I, P, I, I, I, I, I, I, F, P, P, P, P, P]),
+    "ldiff_op_layernorm": (I, [P, I, I, P, I, I, P, P, F, P]),
+    "ldiff_op_norm_apply": (I, [P, I, I, I, P, I, I, I, I, I, P, P, I, P, I, I, P]),
+    "ldiff_op_dup_weights": (I, [P, P, I, I, I, I, I, I, P]),
     "ldiff_op_geglu": (I, [P, P, I64, I, P]),
-    "ldiff_op_nchw_to_nhwc": (I, [P, P, I, I, I, I, I, P]),
+    "ldiff_op_nchw_to_nhwc": (I, [P, P, I, I, I, I, I, I, P]),
     "ldiff_prof_enable": (I, [I]),
     "ldiff_prof_set_filter": (I, [C.c_char_p]),
     "ldiff_prof_collect": (I, [P, I]),

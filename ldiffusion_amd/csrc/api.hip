@@ -3,6 +3,8 @@
 
 #include <cmath>
 #include <exception>
+#include <map>
+#include <mutex>
 
 #include "model.h"
 
@@ -43,6 +45,12 @@ int ldiff_unet_load(ldiff_unet* u, const char* name, const void* host_ptr, int d
   LDIFF_CHECK(u, LDIFF_ERR_INVALID, "unet_load: null handle");
   HIP_CHECK(hipSetDevice(u->device));
   u->ws.load(name, host_ptr, dtype, shape, ndim);
+  API_END
+}
+int ldiff_unet_set_precision(ldiff_unet* u, int mode) {
+  API_BEGIN
+  LDIFF_CHECK(u && mode >= PREC_FAST && mode <= PREC_FULL, LDIFF_ERR_INVALID, "unet_set_precision: mode must be 0, 1 or 2");
+  u->precision = mode;
   API_END
 }
 int ldiff_unet_missing(ldiff_unet* u) { return u ? u->ws.missing() : -1; }
@@ -88,6 +96,13 @@ int ldiff_vae_load(ldiff_vae* v, const char* name, const void* host_ptr, int dty
   LDIFF_CHECK(v, LDIFF_ERR_INVALID, "vae_load: null handle");
   HIP_CHECK(hipSetDevice(v->device));
   v->ws.load(name, host_ptr, dtype, shape, ndim);
+  API_END
+}
+int ldiff_vae_set_precision(ldiff_vae* v, int encoder_mode, int decoder_mode) {
+  API_BEGIN
+  LDIFF_CHECK(v && encoder_mode >= PREC_FAST && encoder_mode <= PREC_FULL && decoder_mode >= PREC_FAST && decoder_mode <= PREC_FULL, LDIFF_ERR_INVALID,
+              "vae_set_precision: modes must be 0, 1 or 2");
+  v->prec_enc = encoder_mode; v->prec_dec = decoder_mode;
   API_END
 }
 int ldiff_vae_missing(ldiff_vae* v) { return v ? v->ws.missing() : -1; }
@@ -304,7 +319,8 @@ int ldiff_sample(ldiff_pipeline* p, const void* images, int B, int H, int W, int
     coef[nops] = sample_coeff; ops[nops++] = sample;
     for (int k = 0; k < 5; ++k)
       if (wts[k] != 0.0) { coef[nops] = (float)((double)ce * wts[k]); ops[nops++] = opsrc[k]; }
-    if (getenv("LDIFF_DEBUG")) {
+    static const bool debug = getenv("LDIFF_DEBUG") != nullptr;   // read once per process
+    if (debug) {
       fprintf(stderr, "[ldiff_sample] pass %d t=%d prev_t=%d n_ets=%d nops=%d coef:", i, t, prev_t, n_ets, nops);
       for (int k = 0; k < nops; ++k) fprintf(stderr, " %.9g", (double)coef[k]);
       fprintf(stderr, "\n");
@@ -346,6 +362,22 @@ void ldiff_pipeline_destroy(ldiff_pipeline* p) {
 }
 
 // ---- single-kernel entry points ----
+// grow-only scratch per (device, stream, slot) for the handle-less op entry points
+static void* op_scratch(hipStream_t st, int slot, size_t bytes) {
+  struct Buf { void* p = nullptr; size_t cap = 0; };
+  static std::mutex mu;
+  static std::map<std::tuple<int, hipStream_t, int>, Buf> bufs;
+  int dev = 0;
+  HIP_CHECK(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lock(mu);
+  Buf& b = bufs[std::make_tuple(dev, st, slot)];
+  if (bytes > b.cap) {
+    if (b.p) { HIP_CHECK(hipStreamSynchronize(st)); HIP_CHECK(hipFree(b.p)); b.p = nullptr; b.cap = 0; }
+    HIP_CHECK(hipMalloc(&b.p, bytes));
+    b.cap = bytes;
+  }
+  return b.p;
+}
 static void conv_args_to_params(const ldiff_conv_args* a, ConvParams& p) {
   LDIFF_CHECK(a && a->x && a->w && a->y, LDIFF_ERR_INVALID, "op_conv: null argument");
   memset(&p, 0, sizeof(p));
@@ -359,6 +391,7 @@ static void conv_args_to_params(const ldiff_conv_args* a, ConvParams& p) {
   p.bias = (const float*)a->bias; p.temb = (const float*)a->temb; p.ld_temb = a->ld_temb;
   p.res = (const f16*)a->res; p.ld_res = a->ld_res;
   p.y = a->y; p.ldy = a->ldy; p.out_f32 = a->out_f32;
+  p.ld1 = a->ld1; p.ld2 = a->ld2; p.res_lo = a->res_lo; p.y_lo = a->y_lo;
   p.M = a->B * a->Hout * a->Wout;
   p.stats = (float*)a->stats;
   p.geglu = a->geglu != 0;
@@ -369,32 +402,17 @@ int ldiff_op_conv(const ldiff_conv_args* a, void* stream) {
   conv_args_to_params(a, p);
   p.stats_R = p.stats ? conv_stats_blocks_per_image(p) : 0;
   LDIFF_CHECK(!p.stats || p.stats_R > 0, LDIFF_ERR_INVALID, "op_conv: fused statistics are not supported for this shape");
-  // same split-K plan the executors use; this test/bench entry point owns a persistent scratch workspace for it
-  static float* ws = nullptr;
-  static size_t ws_cap = 0;
-  static f16* wpar = nullptr;
-  static size_t wpar_cap = 0;
-  if (p.ups && conv3x3_eligible(p)) {   // same algebraic 2x-upsample folding the executors use
-    const size_t need = (size_t)4 * p.Nrows * 4 * (p.C1 + p.C2) * sizeof(f16);
-    if (need > wpar_cap) {
-      if (wpar) { HIP_CHECK(hipDeviceSynchronize()); HIP_CHECK(hipFree(wpar)); wpar = nullptr; wpar_cap = 0; }
-      HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&wpar), need));
-      wpar_cap = need;
-    }
-    launch_make_parity_weights(p.w, wpar, p.Nrows, p.C1 + p.C2, (hipStream_t)stream);
+  // same split-K plan and 2x-upsample folding the executors use.  This test/bench entry point has no handle to own the scratch, so
+  // it keeps one grow-only buffer per (device, stream): reuse is stream-ordered, and two streams or devices never share one.
+  hipStream_t st = (hipStream_t)stream;
+  if (p.ups && conv3x3_eligible(p)) {
+    f16* wpar = (f16*)op_scratch(st, 0, (size_t)4 * p.Nrows * 4 * (p.C1 + p.C2) * sizeof(f16));
+    launch_make_parity_weights(p.w, wpar, p.Nrows, p.C1 + p.C2, st);
     p.w_par = wpar;
     if (p.stats) p.stats_R = conv_stats_blocks_per_image(p);
   }
   if (!p.stats && !p.out_f32 && conv3x3_eligible(p)) p.splitk = conv3x3_splitk_plan(p);
-  if (p.splitk > 1) {
-    const size_t need = (size_t)p.splitk * p.M * p.N * sizeof(float);
-    if (need > ws_cap) {
-      if (ws) { HIP_CHECK(hipDeviceSynchronize()); HIP_CHECK(hipFree(ws)); ws = nullptr; ws_cap = 0; }
-      HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&ws), need));
-      ws_cap = need;
-    }
-    p.splitk_ws = ws;
-  }
+  if (p.splitk > 1) p.splitk_ws = (float*)op_scratch(st, 1, (size_t)p.splitk * p.M * p.N * sizeof(float));
   launch_igemm(p, (hipStream_t)stream);
   API_END
 }
@@ -424,25 +442,33 @@ int ldiff_op_attention(const void* q, int ldq, const void* k, int ldk, const voi
   launch_attention(p, (hipStream_t)stream);
   API_END
 }
-int ldiff_op_gn_stats(const void* x, int C1, const void* x2, int C2, int B, int HW, int groups, float eps, const void* gamma, const void* beta,
-                      void* scale, void* shift, void* stream) {
+int ldiff_op_gn_stats(const void* x, int C1, int ld1, int lo1, const void* x2, int C2, int ld2, int lo2, int B, int HW, int groups, float eps,
+                      const void* gamma, const void* beta, void* scale, void* shift, void* stream) {
   API_BEGIN
   LDIFF_CHECK(x && gamma && beta && scale && shift && B >= 1 && HW >= 1 && groups >= 1, LDIFF_ERR_INVALID, "op_gn_stats: bad arguments");
   const size_t bytes = gn_partial_bytes(B, HW, C1 + C2);
-  float* partial = nullptr;
-  HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&partial), bytes));
-  try {
-    launch_gn_stats((const f16*)x, C1, (const f16*)x2, C2, B, HW, groups, eps, (const float*)gamma, (const float*)beta, partial, bytes,
-                    (float*)scale, (float*)shift, (hipStream_t)stream);
-  } catch (...) { (void)hipFree(partial); throw; }
-  HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
-  HIP_CHECK(hipFree(partial));
+  float* partial = (float*)op_scratch((hipStream_t)stream, 2, bytes);
+  launch_gn_stats(SrcView{(const f16*)x, C1, ld1, lo1}, SrcView{(const f16*)x2, C2, ld2, lo2}, B, HW, groups, eps, (const float*)gamma,
+                  (const float*)beta, partial, bytes, (float*)scale, (float*)shift, (hipStream_t)stream);
   API_END
 }
-int ldiff_op_layernorm(const void* x, void* y, int rows, int C, const void* gamma, const void* beta, float eps, void* stream) {
+int ldiff_op_layernorm(const void* x, int ldx, int x_lo, void* y, int rows, int C, const void* gamma, const void* beta, float eps, void* stream) {
   API_BEGIN
   LDIFF_CHECK(x && y && gamma && beta, LDIFF_ERR_INVALID, "op_layernorm: null argument");
-  launch_layernorm((const f16*)x, (f16*)y, rows, C, (const float*)gamma, (const float*)beta, eps, (hipStream_t)stream);
+  launch_layernorm(SrcView{(const f16*)x, C, ldx, x_lo}, (f16*)y, rows, (const float*)gamma, (const float*)beta, eps, (hipStream_t)stream);
+  API_END
+}
+int ldiff_op_norm_apply(const void* x, int C1, int ld1, int lo1, const void* x2, int C2, int ld2, int lo2, int B, int HW, const void* scale,
+                        const void* shift, int silu, void* y, int ldy, int y_lo, void* stream) {
+  API_BEGIN
+  launch_norm_apply(SrcView{(const f16*)x, C1, ld1, lo1}, SrcView{(const f16*)x2, C2, ld2, lo2}, B, HW, (const float*)scale, (const float*)shift, silu,
+                    (f16*)y, ldy, y_lo, (hipStream_t)stream);
+  API_END
+}
+int ldiff_op_dup_weights(const void* w, void* wd, int Nrows, int taps, int src_tap_stride, int Ca, int Cb, int dst_tap_stride, void* stream) {
+  API_BEGIN
+  LDIFF_CHECK(w && wd, LDIFF_ERR_INVALID, "op_dup_weights: null argument");
+  launch_dup_weights((const f16*)w, (f16*)wd, Nrows, taps, src_tap_stride, Ca, Cb, dst_tap_stride, (hipStream_t)stream);
   API_END
 }
 int ldiff_op_geglu(const void* x, void* y, int64_t M, int C4, void* stream) {
@@ -451,10 +477,10 @@ int ldiff_op_geglu(const void* x, void* y, int64_t M, int C4, void* stream) {
   launch_geglu((const f16*)x, (f16*)y, M, C4, (hipStream_t)stream);
   API_END
 }
-int ldiff_op_nchw_to_nhwc(const void* x_f32, void* y_f16, int B, int C, int H, int W, int Cpad, void* stream) {
+int ldiff_op_nchw_to_nhwc(const void* x_f32, void* y_f16, int B, int C, int H, int W, int Cpad, int lo_off, void* stream) {
   API_BEGIN
   LDIFF_CHECK(x_f32 && y_f16, LDIFF_ERR_INVALID, "op_nchw_to_nhwc: null argument");
-  launch_nchw_f32_to_nhwc_f16((const float*)x_f32, (f16*)y_f16, B, C, H, W, Cpad, (hipStream_t)stream);
+  launch_nchw_f32_to_nhwc_f16((const float*)x_f32, (f16*)y_f16, B, C, H, W, Cpad, (hipStream_t)stream, lo_off);
   API_END
 }
 

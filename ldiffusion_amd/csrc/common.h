@@ -43,9 +43,12 @@ struct LdiffError {
 //   upsampled, optionally with GroupNorm-apply (+SiLU) folded into the load:  a = silu(x*scale[b,c]+shift[b,c]).
 //   k = (ky*ks + kx) * Cin + c,  Cin = C1 + C2.
 struct ConvParams {
-  const f16* x;      // [B, Hin, Win, C1]
-  const f16* x2;     // [B, Hin, Win, C2] or nullptr
+  const f16* x;      // [B, Hin, Win, C1]  (row pitch ld1 elements)
+  const f16* x2;     // [B, Hin, Win, C2] or nullptr  (row pitch ld2)
   int C1, C2;        // multiples of 8
+  int ld1, ld2;      // row pitch in elements of x / x2; 0 => C1 / C2.  A split tensor (see below) read as a plain operand has
+                     // C1 = channels, ld1 = 2*channels (the kernel sees only the hi halves); read as a split operand it is a
+                     // plain tensor of 2*channels whose weights were duplicated along K (Exec::conv, MatW::dup)
   int B, Hin, Win;   // source spatial size (before the optional 2x upsample)
   int Hout, Wout;
   int ks, stride, pad_t, pad_l, ups;
@@ -59,6 +62,10 @@ struct ConvParams {
   int ld_temb;
   const f16* res;         // [M, ld_res] or nullptr
   int ld_res;
+  // Split tensors (fp16 pair hi | lo per row, value = hi + lo to ~22 bits): the residual stream of the UNet / VAE is kept this
+  // way so that the reference's fp32 residual adds are reproduced to fp32 round-off while every MFMA operand stays fp16.
+  int res_lo;             // > 0: the residual is split, its lo half starts res_lo elements after the hi half in each row
+  int y_lo;               // > 0: write y split: hi = f16(v) at column n, lo = f16(v - hi) at column y_lo + n (fp16 output only)
   void* y;                // [M, ldy] fp16 or fp32
   int ldy;
   int out_f32;
@@ -98,14 +105,27 @@ void launch_attention(const AttnParams& p, hipStream_t s);
 // ---- normalisation (kernels_norm.hip) --------------------------------------------------------
 // GroupNorm statistics over one or two NHWC sources (channel concat) -> per-(b,c) scale/shift (fp32):
 //   scale = rstd*gamma, shift = beta - mean*rstd*gamma   so that  gn(x) = x*scale + shift.
-void launch_gn_stats(const f16* x, int C1, const f16* x2, int C2, int B, int HW, int groups, float eps,
+// A source is described by (pointer, channels C, row pitch ld, lo offset): lo > 0 => split tensor, value = x[c] + x[lo + c].
+struct SrcView { const f16* p; int C, ld, lo; };
+void launch_gn_stats(SrcView x1, SrcView x2 /* p == nullptr: none */, int B, int HW, int groups, float eps,
                      const float* gamma, const float* beta, float* partial /*workspace*/, size_t partial_bytes,
                      float* scale, float* shift, hipStream_t s);
 size_t gn_partial_bytes(int B, int HW, int C);
-void launch_layernorm(const f16* x, f16* y, int rows, int C, const float* gamma, const float* beta, float eps, hipStream_t s);
+void launch_layernorm(SrcView x, f16* y, int rows, const float* gamma, const float* beta, float eps, hipStream_t s);
+// y[m, c] = act(x[m, c] * scale[b, c] + shift[b, c]) over the channel concat of one or two sources, written plain (y_lo = 0,
+// ONE fp16 rounding of the fp32 result) or split (hi | lo).  GroupNorm-apply(+SiLU) as its own pass: used where the consumer is
+// a split-operand contraction (the GEMM kernels take their operands by LDS-DMA and cannot transform them on the way).
+void launch_norm_apply(SrcView x1, SrcView x2, int B, int HW, const float* scale, const float* shift, int silu, f16* y, int ldy, int y_lo,
+                       hipStream_t s);
+// wd[n][tap][...] = { a(Ca), a(Ca), b(Cb), b(Cb), 0... } from w[n][tap][a(Ca) b(Cb) ...]: the weights of a contraction whose
+// operand is a split tensor [hi | lo] (K doubled, same weights for both halves)
+void launch_dup_weights(const f16* w, f16* wd, int Nrows, int taps, int src_tap_stride, int Ca, int Cb, int dst_tap_stride, hipStream_t s);
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (device, kernel): the attribute is per device
+void ensure_dyn_smem(const void* kernel, int bytes);
 
 // ---- elementwise / layout / sampler arithmetic (kernels_elem.hip) ----------------------------
-void launch_nchw_f32_to_nhwc_f16(const float* x, f16* y, int B, int C, int H, int W, int Cpad, hipStream_t s);
+// lo_off > 0: also write the rounding remainder f16(x - f16(x)) at channel lo_off + c (split input of the first conv)
+void launch_nchw_f32_to_nhwc_f16(const float* x, f16* y, int B, int C, int H, int W, int Cpad, hipStream_t s, int lo_off = 0);
 void launch_nhwc_f32_to_nchw_f32(const float* x, float* y, int B, int C, int H, int W, int ldx, hipStream_t s);
 void launch_geglu(const f16* x, f16* y, long long M, int C4, hipStream_t s);  // x [M, 2*C4] -> y [M, C4]
 void launch_timestep_embed(float t, f16* y, int B, int dim, int flip_sin_to_cos, float freq_shift, hipStream_t s);
@@ -184,6 +204,9 @@ void launch_gn_finalize(const float* part1, int R1, int C1, const float* part2, 
                         const float* gamma, const float* beta, float* scale, float* shift, hipStream_t s);
 
 #ifdef __HIPCC__
+// ---- epilogue helpers for split tensors (ConvParams::res_lo / y_lo) ----
+__device__ __forceinline__ f16x4 cvt4(const f32x4& v) { return (f16x4){(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]}; }
+__device__ __forceinline__ f32x4 up4(const f16x4& h) { return (f32x4){(float)h[0], (float)h[1], (float)h[2], (float)h[3]}; }
 // sum over the 16 lanes that share lane>>4 (one MFMA accumulator row group), by DPP (no LDS crossbar traffic)
 __device__ __forceinline__ float row16_sum(float v) {
   v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]

@@ -252,13 +252,9 @@ static void launch_attn_cfg(const AttnParams& p, hipStream_t s) {
 }
 template <int DQK, int DV, int BKV, int QT, int MINW, bool ONES>
 static void launch_attn_cfg2(const AttnParams& p, hipStream_t s) {
-  static bool attr_set = false;
   const size_t smem = (size_t)BKV * KLayout<DQK>::STR * 16 + (size_t)BKV * VLayout<DV>::STR_DW * 4;
   auto kern = attn_kernel<DQK, DV, BKV, QT, MINW, ONES>;
-  if (!attr_set) {
-    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-    attr_set = true;
-  }
+  ensure_dyn_smem(reinterpret_cast<const void*>(kern), (int)smem);
   dim3 grid((p.Lq + 64 * QT - 1) / (64 * QT), p.heads, p.B);
   static const std::string pname = std::string("attn<") + std::to_string(DQK) + "," + std::to_string(DV) + ">";
   const double bh = (double)p.B * p.heads;
@@ -496,13 +492,9 @@ __global__ __launch_bounds__(256, 1) void attn_dsplit_kernel(const AttnParams p)
 
 static void launch_attn_dsplit(const AttnParams& p, hipStream_t s) {
   constexpr int BKV = 32;
-  static bool attr_set = false;
   const size_t smem = (size_t)BKV * KLayout<512>::STR * 16 + (size_t)BKV * VLayout<512>::STR_DW * 4 + 64 * (BKV * 2 + 16) + 64 * 4;
   auto kern = attn_dsplit_kernel<BKV>;
-  if (!attr_set) {
-    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-    attr_set = true;
-  }
+  ensure_dyn_smem(reinterpret_cast<const void*>(kern), (int)smem);
   dim3 grid(((p.Lq + 63) / 64) * p.heads * p.B);
   const double bh = (double)p.B * p.heads;
   ProfScope prof("attn<512,512>", 4.0 * bh * p.Lq * p.Lk * p.d, 2.0 * bh * p.d * (2.0 * p.Lq + 2.0 * p.Lk * (p.kv_bstride ? 1.0 : 1.0 / p.B)), s);

@@ -83,7 +83,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const ConvParams p) {  
   auto load_halo = [&](int c) {
     const int cb = c * 64;
     const f16* src; int cs, Cs;
-    if (cb < p.C1) { src = p.x; cs = cb; Cs = p.C1; } else { src = p.x2; cs = cb - p.C1; Cs = p.C2; }
+    if (cb < p.C1) { src = p.x; cs = cb; Cs = p.ld1 ? p.ld1 : p.C1; } else { src = p.x2; cs = cb - p.C1; Cs = p.ld2 ? p.ld2 : p.C2; }
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) {
       uint4 v = make_uint4(0, 0, 0, 0);
@@ -240,14 +240,18 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const ConvParams p) {  
     const int oy = par ? 2 * ty_ + py : ty_, ox = par ? 2 * tx_ + px : tx_;
     mrow[m] = (ty_ < Ht && tx_ < Wt) ? ((long long)b * p.Hout + oy) * p.Wout + ox : -1;
   }
-  f16x4 rr[MT][NT];
+  f16x4 rr[MT][NT], rl[MT][NT];
   if (p.res) {
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
       for (int a = 0; a < NT; ++a) {
         rr[m][a] = (f16x4){(f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f};
-        if (mrow[m] >= 0 && ncol + a * 16 < p.N) rr[m][a] = *reinterpret_cast<const f16x4*>(p.res + mrow[m] * p.ld_res + ncol + a * 16);
+        rl[m][a] = rr[m][a];
+        if (mrow[m] >= 0 && ncol + a * 16 < p.N) {
+          rr[m][a] = *reinterpret_cast<const f16x4*>(p.res + mrow[m] * p.ld_res + ncol + a * 16);
+          if (p.res_lo) rl[m][a] = *reinterpret_cast<const f16x4*>(p.res + mrow[m] * p.ld_res + p.res_lo + ncol + a * 16);
+        }
       }
   }
 #pragma unroll
@@ -258,13 +262,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const ConvParams p) {  
       const int n = ncol + a * 16;
       if (n >= p.N) continue;
       f32x4 v = acc[a][m] + bt[a];
-      if (p.res) { v[0] += (float)rr[m][a][0]; v[1] += (float)rr[m][a][1]; v[2] += (float)rr[m][a][2]; v[3] += (float)rr[m][a][3]; }
+      if (p.res) { v += up4(rr[m][a]); if (p.res_lo) v += up4(rl[m][a]); }
       if (p.out_f32) {
         *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.y) + mrow[m] * p.ldy + n) = v;
       } else {
-        f16x4 o = {(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
+        const f16x4 o = cvt4(v);
         *reinterpret_cast<f16x4*>(reinterpret_cast<f16*>(p.y) + mrow[m] * p.ldy + n) = o;
-        if (p.stats) acc[a][m] = (f32x4){(float)o[0], (float)o[1], (float)o[2], (float)o[3]};   // what the consumer will read
+        if (p.y_lo) *reinterpret_cast<f16x4*>(reinterpret_cast<f16*>(p.y) + mrow[m] * p.ldy + p.y_lo + n) = cvt4(v - up4(o));
+        if (p.stats) acc[a][m] = p.y_lo ? v : up4(o);   // what the consumer will read (hi + lo ~ v for a split tensor)
       }
     }
   }
@@ -366,7 +371,7 @@ __global__ __launch_bounds__(256, BN > 128 ? 1 : 2) void conv3x3w_kernel(const C
   auto load_halo = [&](int c) {
     const int cb = c * 64;
     const f16* src; int cs, Cs;
-    if (cb < p.C1) { src = p.x; cs = cb; Cs = p.C1; } else { src = p.x2; cs = cb - p.C1; Cs = p.C2; }
+    if (cb < p.C1) { src = p.x; cs = cb; Cs = p.ld1 ? p.ld1 : p.C1; } else { src = p.x2; cs = cb - p.C1; Cs = p.ld2 ? p.ld2 : p.C2; }
     src += cs + kc * 8;
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) ra[i] = *reinterpret_cast<const uint4*>(src + (size_t)a_pix[i] * (unsigned)Cs);
@@ -572,21 +577,25 @@ __global__ __launch_bounds__(256, BN > 128 ? 1 : 2) void conv3x3w_kernel(const C
     const int oy = par ? 2 * ty_ + py : ty_, ox = par ? 2 * tx_ + px : tx_;
     mrow[m] = (ty_ < Ht && tx_ < Wt) ? ((long long)b * p.Hout + oy) * p.Wout + ox : -1;
   }
-  f16x4 rr[MT][NT];
+  f16x4 rr[MT][NT], rl[MT][NT];
   if (p.res) {
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
       for (int a = 0; a < NT; ++a) {
         rr[m][a] = (f16x4){(f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f};
-        if (mrow[m] >= 0 && ncol + a * 16 < p.N) rr[m][a] = *reinterpret_cast<const f16x4*>(p.res + mrow[m] * p.ld_res + ncol + a * 16);
+        rl[m][a] = rr[m][a];
+        if (mrow[m] >= 0 && ncol + a * 16 < p.N) {
+          rr[m][a] = *reinterpret_cast<const f16x4*>(p.res + mrow[m] * p.ld_res + ncol + a * 16);
+          if (p.res_lo) rl[m][a] = *reinterpret_cast<const f16x4*>(p.res + mrow[m] * p.ld_res + p.res_lo + ncol + a * 16);
+        }
       }
   }
   // 16-byte stores: lanes g and g+1 hold adjacent 4-channel groups of the SAME pixel.  One v_permlane16_swap per dword
   // between the packed values of two m-tiles P, Q leaves lanes with even g holding channels 4g..4g+7 of pixel P and lanes
   // with odd g channels 4(g-1)..4(g-1)+7 of pixel Q: half as many store instructions for the same bytes (the store tail of an
   // MFMA epilogue is issue-bound per instruction).
-  if (!p.out_f32 && (p.N & 7) == 0 && (p.ldy & 7) == 0) {
+  if (!p.out_f32 && (p.N & 7) == 0 && (p.ldy & 7) == 0 && (p.y_lo & 7) == 0) {
 #pragma unroll
     for (int mp = 0; mp < MT; mp += 2) {
       // this lane's pixel after the swap, from arithmetic (a select between mrow[] entries becomes a scratch-indexed load)
@@ -595,20 +604,26 @@ __global__ __launch_bounds__(256, BN > 128 ? 1 : 2) void conv3x3w_kernel(const C
       const long long row = (tys < Ht && txs < Wt) ? ((long long)b * p.Hout + (par ? 2 * tys + py : tys)) * p.Wout + (par ? 2 * txs + px : txs) : -1;
 #pragma unroll
       for (int a = 0; a < NT; ++a) {
-        uint2 pq[2];
+        uint2 pq[2], pl[2];
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
           const int m = mp + h;
           f32x4 v = acc[a][m] + bt[a];
-          if (p.res) { v[0] += (float)rr[m][a][0]; v[1] += (float)rr[m][a][1]; v[2] += (float)rr[m][a][2]; v[3] += (float)rr[m][a][3]; }
-          const f16x4 o = {(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
-          if (p.stats) acc[a][m] = (f32x4){(float)o[0], (float)o[1], (float)o[2], (float)o[3]};   // what the consumer will read
+          if (p.res) { v += up4(rr[m][a]); if (p.res_lo) v += up4(rl[m][a]); }
+          const f16x4 o = cvt4(v);
+          if (p.stats) acc[a][m] = p.y_lo ? v : up4(o);   // what the consumer will read (hi + lo ~ v for a split tensor)
           pq[h] = __builtin_bit_cast(uint2, o);
+          pl[h] = __builtin_bit_cast(uint2, cvt4(v - up4(o)));
         }
         auto r0 = __builtin_amdgcn_permlane16_swap(pq[0].x, pq[1].x, false, false);
         auto r1 = __builtin_amdgcn_permlane16_swap(pq[0].y, pq[1].y, false, false);
         const int nb = n0 + wave_n * (BN / 2) + a * 16 + (g & ~1) * 4;
         if (row >= 0 && nb < p.N) *reinterpret_cast<uint4*>(reinterpret_cast<f16*>(p.y) + row * p.ldy + nb) = make_uint4(r0[0], r1[0], r0[1], r1[1]);
+        if (p.y_lo) {   // lo halves of the split output, same swap
+          auto l0 = __builtin_amdgcn_permlane16_swap(pl[0].x, pl[1].x, false, false);
+          auto l1 = __builtin_amdgcn_permlane16_swap(pl[0].y, pl[1].y, false, false);
+          if (row >= 0 && nb < p.N) *reinterpret_cast<uint4*>(reinterpret_cast<f16*>(p.y) + row * p.ldy + p.y_lo + nb) = make_uint4(l0[0], l1[0], l0[1], l1[1]);
+        }
       }
     }
   } else
@@ -620,13 +635,14 @@ __global__ __launch_bounds__(256, BN > 128 ? 1 : 2) void conv3x3w_kernel(const C
       const int n = ncol + a * 16;
       if (n >= p.N) continue;
       f32x4 v = acc[a][m] + bt[a];
-      if (p.res) { v[0] += (float)rr[m][a][0]; v[1] += (float)rr[m][a][1]; v[2] += (float)rr[m][a][2]; v[3] += (float)rr[m][a][3]; }
+      if (p.res) { v += up4(rr[m][a]); if (p.res_lo) v += up4(rl[m][a]); }
       if (p.out_f32) {
         *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.y) + mrow[m] * p.ldy + n) = v;
       } else {
-        f16x4 o = {(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
+        const f16x4 o = cvt4(v);
         *reinterpret_cast<f16x4*>(reinterpret_cast<f16*>(p.y) + mrow[m] * p.ldy + n) = o;
-        if (p.stats) acc[a][m] = (f32x4){(float)o[0], (float)o[1], (float)o[2], (float)o[3]};   // what the consumer will read
+        if (p.y_lo) *reinterpret_cast<f16x4*>(reinterpret_cast<f16*>(p.y) + mrow[m] * p.ldy + p.y_lo + n) = cvt4(v - up4(o));
+        if (p.stats) acc[a][m] = p.y_lo ? v : up4(o);   // what the consumer will read
       }
     }
   }
@@ -688,31 +704,32 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const ConvParams p) 
     v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
   }
   if (p.res) {
-    const f16x4 r = *reinterpret_cast<const f16x4*>(p.res + m * p.ld_res + n);
-    v[0] += (float)r[0]; v[1] += (float)r[1]; v[2] += (float)r[2]; v[3] += (float)r[3];
+    v += up4(*reinterpret_cast<const f16x4*>(p.res + m * p.ld_res + n));
+    if (p.res_lo) v += up4(*reinterpret_cast<const f16x4*>(p.res + m * p.ld_res + p.res_lo + n));
   }
   if (p.out_f32) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.y) + m * p.ldy + n) = v;
-  else *reinterpret_cast<f16x4*>(reinterpret_cast<f16*>(p.y) + m * p.ldy + n) = (f16x4){(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
+  else {
+    const f16x4 o = cvt4(v);
+    *reinterpret_cast<f16x4*>(reinterpret_cast<f16*>(p.y) + m * p.ldy + n) = o;
+    if (p.y_lo) *reinterpret_cast<f16x4*>(reinterpret_cast<f16*>(p.y) + m * p.ldy + p.y_lo + n) = cvt4(v - up4(o));
+  }
 }
 
 template <int TH, int TW, int BN, bool GN>
 void launch_c3(const ConvParams& p, hipStream_t s) {
-  static bool attr_set = false;
   constexpr int HP = (TH + 2) * (TW + 2);
   const size_t smem = (size_t)(2 * HP * 8 + 2 * BN * 8) * 16;
   auto kern = conv3x3_kernel<TH, TW, BN, GN>;
-  if (!attr_set) {
-    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-    attr_set = true;
-  }
+  ensure_dyn_smem(reinterpret_cast<const void*>(kern), (int)smem);
   const bool par = p.w_par != nullptr;
   const int Ht = par ? p.Hin : p.Hout, Wt = par ? p.Win : p.Wout;
   const int tiles = p.B * ((Ht + TH - 1) / TH) * ((Wt + TW - 1) / TW);
   const int ntn = (p.N + BN - 1) / BN;
   static const std::string pname = std::string("conv3x3<") + std::to_string(TH) + "x" + std::to_string(TW) + "," + std::to_string(BN) + (GN ? ",gn>" : ">");
-  const double bytes = (double)p.B * p.Hin * p.Win * (p.C1 + p.C2) * 2.0 + (double)p.N * p.K * 2.0 + (double)p.M * p.N * (p.out_f32 ? 4.0 : 2.0) +
-                       (p.res ? (double)p.M * p.N * 2.0 : 0.0);
-  ProfScope prof(pname.c_str(), 2.0 * p.M * (double)p.N * p.K, bytes, s);   // algorithmic (9-tap) flops also in parity mode
+  const double bytes = (double)p.B * p.Hin * p.Win * (p.C1 + p.C2) * 2.0 + (double)p.N * p.K * 2.0 + (double)p.M * p.N * (p.out_f32 ? 4.0 : (p.y_lo ? 4.0 : 2.0)) +
+                       (p.res ? (double)p.M * p.N * (p.res_lo ? 4.0 : 2.0) : 0.0);
+  // flops = MFMA work actually executed: parity mode (nearest-2x folded into 4 taps) runs 16/36 of the 9-tap MACs
+  ProfScope prof(pname.c_str(), 2.0 * p.M * (double)p.N * p.K * (par ? 16.0 / 36.0 : 1.0), bytes, s);
   const int S = p.splitk > 1 ? p.splitk : 1;
   hipLaunchKernelGGL(kern, dim3(tiles * ntn, S, par ? 4 : 1), dim3(256), smem, s, p);
   HIP_CHECK(hipGetLastError());
@@ -725,22 +742,19 @@ void launch_c3(const ConvParams& p, hipStream_t s) {
 
 template <int BN, bool GN>
 void launch_c3w(const ConvParams& p, hipStream_t s) {
-  static bool attr_set = false;
   constexpr int TH = 8, TW = 16, HP = 180;
   const size_t smem = (size_t)2 * HP * 128 + 2 * BN * 128 + 1536;
   auto kern = conv3x3w_kernel<BN, GN>;
-  if (!attr_set) {
-    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-    attr_set = true;
-  }
+  ensure_dyn_smem(reinterpret_cast<const void*>(kern), (int)smem);
   const bool par = p.w_par != nullptr;
   const int Ht = par ? p.Hin : p.Hout, Wt = par ? p.Win : p.Wout;
   const int tiles = p.B * ((Ht + TH - 1) / TH) * ((Wt + TW - 1) / TW);
   const int ntn = (p.N + BN - 1) / BN;
   static const std::string pname = std::string("conv3x3<8x16,") + std::to_string(BN) + (GN ? ",gn>" : ">");
-  const double bytes = (double)p.B * p.Hin * p.Win * (p.C1 + p.C2) * 2.0 + (double)p.N * p.K * 2.0 + (double)p.M * p.N * (p.out_f32 ? 4.0 : 2.0) +
-                       (p.res ? (double)p.M * p.N * 2.0 : 0.0);
-  ProfScope prof(pname.c_str(), 2.0 * p.M * (double)p.N * p.K, bytes, s);   // algorithmic (9-tap) flops also in parity mode
+  const double bytes = (double)p.B * p.Hin * p.Win * (p.C1 + p.C2) * 2.0 + (double)p.N * p.K * 2.0 + (double)p.M * p.N * (p.out_f32 ? 4.0 : (p.y_lo ? 4.0 : 2.0)) +
+                       (p.res ? (double)p.M * p.N * (p.res_lo ? 4.0 : 2.0) : 0.0);
+  // flops = MFMA work actually executed: parity mode (nearest-2x folded into 4 taps) runs 16/36 of the 9-tap MACs
+  ProfScope prof(pname.c_str(), 2.0 * p.M * (double)p.N * p.K * (par ? 16.0 / 36.0 : 1.0), bytes, s);
   const int S = p.splitk > 1 ? p.splitk : 1;
   hipLaunchKernelGGL(kern, dim3(tiles * ntn, S, par ? 4 : 1), dim3(256), smem, s, p);
   HIP_CHECK(hipGetLastError());

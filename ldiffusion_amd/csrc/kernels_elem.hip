@@ -5,7 +5,7 @@
 static inline int nblocks(long long n, int per = 256) { return (int)((n + per - 1) / per); }
 
 // ---- boundary layout: torch NCHW fp32 <-> internal NHWC fp16 ------------------------------------
-__global__ void nchw_f32_to_nhwc_f16_kernel(const float* __restrict__ x, f16* __restrict__ y, int B, int C, int HW, int Cpad) {
+__global__ void nchw_f32_to_nhwc_f16_kernel(const float* __restrict__ x, f16* __restrict__ y, int B, int C, int HW, int Cpad, int lo_off) {
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (long long)B * HW) return;
   int b = (int)(i / HW), pix = (int)(i - (long long)b * HW);
@@ -14,15 +14,45 @@ __global__ void nchw_f32_to_nhwc_f16_kernel(const float* __restrict__ x, f16* __
   for (int c0 = 0; c0 < Cpad; c0 += 8) {
     f16x8 o;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) o[j] = (c0 + j < C) ? (f16)src[(long long)(c0 + j) * HW] : (f16)0.f;
+    for (int j = 0; j < 8; ++j) {
+      const int c = c0 + j;
+      float v = 0.f;
+      if (c < C) v = src[(long long)c * HW];
+      f16 r = (f16)v;
+      if (lo_off > 0 && c >= lo_off && c - lo_off < C) {   // remainder of channel c - lo_off: x = hi + lo to ~22 bits
+        const float f = src[(long long)(c - lo_off) * HW];
+        r = (f16)(f - (float)(f16)f);
+      }
+      o[j] = r;
+    }
     *reinterpret_cast<uint4*>(dst + c0) = __builtin_bit_cast(uint4, o);
   }
 }
-void launch_nchw_f32_to_nhwc_f16(const float* x, f16* y, int B, int C, int H, int W, int Cpad, hipStream_t s) {
-  LDIFF_CHECK(Cpad % 8 == 0 && Cpad >= C, LDIFF_ERR_INVALID, "layout: Cpad=%d must be a multiple of 8 and >= C=%d", Cpad, C);
+void launch_nchw_f32_to_nhwc_f16(const float* x, f16* y, int B, int C, int H, int W, int Cpad, hipStream_t s, int lo_off) {
+  LDIFF_CHECK(Cpad % 8 == 0 && Cpad >= C && (lo_off == 0 || (lo_off >= C && lo_off + C <= Cpad)), LDIFF_ERR_INVALID,
+              "layout: Cpad=%d must be a multiple of 8 and >= C=%d (split: 2C <= Cpad)", Cpad, C);
   long long n = (long long)B * H * W;
   if (n == 0) return;
-  hipLaunchKernelGGL(nchw_f32_to_nhwc_f16_kernel, dim3(nblocks(n)), dim3(256), 0, s, x, y, B, C, H * W, Cpad);
+  hipLaunchKernelGGL(nchw_f32_to_nhwc_f16_kernel, dim3(nblocks(n)), dim3(256), 0, s, x, y, B, C, H * W, Cpad, lo_off);
+  HIP_CHECK(hipGetLastError());
+}
+
+// ---- weights of a contraction over a split operand: K doubled, the same weights against the hi and the lo halves ----
+__global__ void dup_weights_kernel(const f16* __restrict__ w, f16* __restrict__ wd, long long rows /* Nrows*taps */, int sstride, int Ca, int Cb,
+                                   int dstride) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * dstride) return;
+  const long long r = i / dstride;
+  const int j = (int)(i - r * dstride);
+  f16 v = (f16)0.f;
+  if (j < 2 * Ca) v = w[r * sstride + (j < Ca ? j : j - Ca)];
+  else if (j < 2 * Ca + 2 * Cb) { const int k = j - 2 * Ca; v = w[r * sstride + Ca + (k < Cb ? k : k - Cb)]; }
+  wd[i] = v;
+}
+void launch_dup_weights(const f16* w, f16* wd, int Nrows, int taps, int src_tap_stride, int Ca, int Cb, int dst_tap_stride, hipStream_t s) {
+  LDIFF_CHECK(Ca + Cb <= src_tap_stride && 2 * (Ca + Cb) <= dst_tap_stride, LDIFF_ERR_INVALID, "dup_weights: bad strides");
+  const long long n = (long long)Nrows * taps * dst_tap_stride;
+  hipLaunchKernelGGL(dup_weights_kernel, dim3(nblocks(n)), dim3(256), 0, s, w, wd, (long long)Nrows * taps, src_tap_stride, Ca, Cb, dst_tap_stride);
   HIP_CHECK(hipGetLastError());
 }
 

@@ -62,6 +62,7 @@ __global__ __launch_bounds__(256, 2) void gemm_dma_kernel(const ConvParams p) {
   // hardware adds to BOTH the memory and the LDS address (voffset pre-compensated).  Rows beyond M / N are clamped (their
   // results are never stored).
   constexpr int A_NP = BM / 32, W_NP = BN / 32;
+  const int pitch1 = p.ld1 ? p.ld1 : p.C1, pitch2 = p.ld2 ? p.ld2 : p.C2;   // row pitch of the two sources (elements)
   constexpr unsigned A_BYTES = BM * 128, W_BYTES = BN * 128, W_OFF = 2 * A_BYTES;   // LDS map: A[2] | W[2]
   int a_row[A_NP], a_sw[A_NP], a_voff[A_NP], w_voff[W_NP];
 #pragma unroll
@@ -70,7 +71,7 @@ __global__ __launch_bounds__(256, 2) void gemm_dma_kernel(const ConvParams p) {
     int m = m0 + r;
     a_row[i] = m < p.M ? m : p.M - 1;
     a_sw[i] = swz8(r, pos) * 16 - (i & 3) * 1024;
-    a_voff[i] = a_row[i] * (p.C1 * 2) + a_sw[i];
+    a_voff[i] = a_row[i] * (pitch1 * 2) + a_sw[i];
   }
 #pragma unroll
   for (int i = 0; i < W_NP; ++i) {
@@ -79,8 +80,8 @@ __global__ __launch_bounds__(256, 2) void gemm_dma_kernel(const ConvParams p) {
     n = n < p.Nrows ? n : p.Nrows - 1;
     w_voff[i] = (int)(((long long)n * p.K + swz8(r, pos) * 8) * 2) - (i & 3) * 1024;
   }
-  const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)((long long)p.M * p.C1 * 2), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs2 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x2 ? p.x2 : p.x), 0, (int)((long long)p.M * (p.x2 ? p.C2 : p.C1) * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)((long long)p.M * pitch1 * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs2 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x2 ? p.x2 : p.x), 0, (int)((long long)p.M * (p.x2 ? pitch2 : pitch1) * 2), 0x00020000);
   // per-image weights (GroupNorm folded into the layer): tiles never straddle images, so the image of this tile is uniform
   const int img = p.w_bstride > 0 ? m0 / (p.Hout * p.Wout) : 0;
   const f16* wmat = p.w + (long long)img * p.w_bstride;
@@ -92,7 +93,7 @@ __global__ __launch_bounds__(256, 2) void gemm_dma_kernel(const ConvParams p) {
     const bool second = kt >= kt2;
     if (kt == kt2) {   // the row pitch changes with the source: new voffsets, once
 #pragma unroll
-      for (int i = 0; i < A_NP; ++i) a_voff[i] = a_row[i] * (p.C2 * 2) + a_sw[i];
+      for (int i = 0; i < A_NP; ++i) a_voff[i] = a_row[i] * (pitch2 * 2) + a_sw[i];
     }
     unsigned char* adst = smem_raw + buf * A_BYTES + wave * (BM * 32);
     unsigned char* wdst = smem_raw + W_OFF + buf * W_BYTES + wave * (BN * 32);
@@ -176,14 +177,18 @@ __global__ __launch_bounds__(256, 2) void gemm_dma_kernel(const ConvParams p) {
     const int mm = m0 + wave_m * (BM / 2) + m * 16 + l15;
     mrow[m] = mm < p.M ? mm : -1;
   }
-  f16x4 rr[MT][NT];
+  f16x4 rr[MT][NT], rl[MT][NT];
   if (p.res) {
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
       for (int a = 0; a < NT; ++a) {
         rr[m][a] = (f16x4){(f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f};
-        if (mrow[m] >= 0 && ncol + a * 16 < p.N) rr[m][a] = *reinterpret_cast<const f16x4*>(p.res + (long long)mrow[m] * p.ld_res + ncol + a * 16);
+        rl[m][a] = rr[m][a];
+        if (mrow[m] >= 0 && ncol + a * 16 < p.N) {
+          rr[m][a] = *reinterpret_cast<const f16x4*>(p.res + (long long)mrow[m] * p.ld_res + ncol + a * 16);
+          if (p.res_lo) rl[m][a] = *reinterpret_cast<const f16x4*>(p.res + (long long)mrow[m] * p.ld_res + p.res_lo + ncol + a * 16);
+        }
       }
   }
   // GEGLU epilogue (BasicTransformerBlock.ff.net.0: Linear(C, 8C) -> x * gelu_erf(gate)): the weight rows were interleaved at
@@ -215,26 +220,32 @@ __global__ __launch_bounds__(256, 2) void gemm_dma_kernel(const ConvParams p) {
   }
   // 16-byte stores (see kernels_conv3x3.hip): one v_permlane16_swap per dword between the packed values of two m-tiles
   // leaves even-g lanes with channels 4g..4g+7 of the first tile's row and odd-g lanes with 4(g-1)..4(g-1)+7 of the second's
-  if (!p.out_f32 && (p.N & 7) == 0 && (p.ldy & 7) == 0) {
+  if (!p.out_f32 && (p.N & 7) == 0 && (p.ldy & 7) == 0 && (p.y_lo & 7) == 0) {
 #pragma unroll
     for (int mp = 0; mp < MT; mp += 2) {
       const int mms = m0 + wave_m * (BM / 2) + (mp + (g & 1)) * 16 + l15;   // this lane's row after the swap
 #pragma unroll
       for (int a = 0; a < NT; ++a) {
-        uint2 pq[2];
+        uint2 pq[2], pl[2];
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
           const int m = mp + h;
           f32x4 v = acc[a][m] + bb[a];
-          if (p.res) { v[0] += (float)rr[m][a][0]; v[1] += (float)rr[m][a][1]; v[2] += (float)rr[m][a][2]; v[3] += (float)rr[m][a][3]; }
-          const f16x4 o = {(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
-          if (p.stats) acc[a][m] = (f32x4){(float)o[0], (float)o[1], (float)o[2], (float)o[3]};
+          if (p.res) { v += up4(rr[m][a]); if (p.res_lo) v += up4(rl[m][a]); }
+          const f16x4 o = cvt4(v);
+          if (p.stats) acc[a][m] = p.y_lo ? v : up4(o);
           pq[h] = __builtin_bit_cast(uint2, o);
+          pl[h] = __builtin_bit_cast(uint2, cvt4(v - up4(o)));
         }
         auto r0 = __builtin_amdgcn_permlane16_swap(pq[0].x, pq[1].x, false, false);
         auto r1 = __builtin_amdgcn_permlane16_swap(pq[0].y, pq[1].y, false, false);
         const int nb = n0 + wave_n * (BN / 2) + a * 16 + (g & ~1) * 4;
         if (mms < p.M && nb < p.N) *reinterpret_cast<uint4*>(reinterpret_cast<f16*>(p.y) + (long long)mms * p.ldy + nb) = make_uint4(r0[0], r1[0], r0[1], r1[1]);
+        if (p.y_lo) {   // lo halves of the split output
+          auto l0 = __builtin_amdgcn_permlane16_swap(pl[0].x, pl[1].x, false, false);
+          auto l1 = __builtin_amdgcn_permlane16_swap(pl[0].y, pl[1].y, false, false);
+          if (mms < p.M && nb < p.N) *reinterpret_cast<uint4*>(reinterpret_cast<f16*>(p.y) + (long long)mms * p.ldy + p.y_lo + nb) = make_uint4(l0[0], l1[0], l0[1], l1[1]);
+        }
       }
     }
   } else
@@ -246,13 +257,14 @@ __global__ __launch_bounds__(256, 2) void gemm_dma_kernel(const ConvParams p) {
       const int n = ncol + a * 16;
       if (n >= p.N) continue;
       f32x4 v = acc[a][m] + bb[a];
-      if (p.res) { v[0] += (float)rr[m][a][0]; v[1] += (float)rr[m][a][1]; v[2] += (float)rr[m][a][2]; v[3] += (float)rr[m][a][3]; }
+      if (p.res) { v += up4(rr[m][a]); if (p.res_lo) v += up4(rl[m][a]); }
       if (p.out_f32) {
         *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.y) + (long long)mrow[m] * p.ldy + n) = v;
       } else {
-        f16x4 o = {(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
+        const f16x4 o = cvt4(v);
         *reinterpret_cast<f16x4*>(reinterpret_cast<f16*>(p.y) + (long long)mrow[m] * p.ldy + n) = o;
-        if (p.stats) acc[a][m] = (f32x4){(float)o[0], (float)o[1], (float)o[2], (float)o[3]};
+        if (p.y_lo) *reinterpret_cast<f16x4*>(reinterpret_cast<f16*>(p.y) + (long long)mrow[m] * p.ldy + p.y_lo + n) = cvt4(v - up4(o));
+        if (p.stats) acc[a][m] = p.y_lo ? v : up4(o);
       }
     }
   }
@@ -270,16 +282,12 @@ __global__ __launch_bounds__(256, 2) void gemm_dma_kernel(const ConvParams p) {
 
 template <int BM, int BN>
 void launch_g(const ConvParams& p, hipStream_t s) {
-  static bool attr_set = false;
   const size_t smem = (size_t)2 * (BM + BN) * 8 * 16;
   auto kern = gemm_dma_kernel<BM, BN>;
-  if (!attr_set) {
-    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-    attr_set = true;
-  }
+  ensure_dyn_smem(reinterpret_cast<const void*>(kern), (int)smem);
   const int ntm = (p.M + BM - 1) / BM, ntn = (p.N + BN - 1) / BN;
   static const std::string pname = std::string("gemm_dma<") + std::to_string(BM) + "," + std::to_string(BN) + ">";
-  const double bytes = (double)p.M * p.K * 2.0 + (double)p.N * p.K * 2.0 + (double)p.M * p.N * (p.out_f32 ? 4.0 : 2.0) + (p.res ? (double)p.M * p.N * 2.0 : 0.0);
+  const double bytes = (double)p.M * p.K * 2.0 + (double)p.N * p.K * 2.0 + (double)p.M * p.N * (p.out_f32 || p.y_lo ? 4.0 : 2.0) + (p.res ? (double)p.M * p.N * (p.res_lo ? 4.0 : 2.0) : 0.0);
   ProfScope prof(pname.c_str(), 2.0 * p.M * (double)p.N * p.K, bytes, s);
   hipLaunchKernelGGL(kern, dim3(ntm * ntn), dim3(256), smem, s, p);
   HIP_CHECK(hipGetLastError());
@@ -289,9 +297,11 @@ void launch_g(const ConvParams& p, hipStream_t s) {
 
 bool gemm_dma_eligible(const ConvParams& p) {
   if (p.w_bstride > 0 && ((p.Hout * p.Wout) % 64 != 0 || p.stats)) return false;   // a tile must lie inside one image
-  if (p.geglu && (p.N % 32 != 0 || (p.ldy & 7) != 0 || p.res || p.out_f32 || p.stats)) return false;
+  if (p.geglu && (p.N % 32 != 0 || (p.ldy & 7) != 0 || p.res || p.out_f32 || p.stats || p.y_lo)) return false;
+  const int pitch1 = p.ld1 ? p.ld1 : p.C1, pitch2 = p.ld2 ? p.ld2 : p.C2, pmax = pitch1 > pitch2 ? pitch1 : pitch2;
   return p.ks == 1 && p.stride == 1 && p.ups == 0 && p.pad_t == 0 && p.pad_l == 0 && !p.gn_scale && !p.temb && p.K % 64 == 0 && p.C1 % 64 == 0 &&
-         p.Hout == p.Hin && p.Wout == p.Win && p.M < (1 << 24) && (p.C1 > p.C2 ? p.C1 : p.C2) * 2 < (1 << 24) && (long long)p.M * (p.C1 > p.C2 ? p.C1 : p.C2) * 2 < (1LL << 32) && (long long)p.Nrows * p.K * 2 < (1LL << 32);
+         pitch1 % 8 == 0 && pitch2 % 8 == 0 &&
+         p.Hout == p.Hin && p.Wout == p.Win && p.M < (1 << 24) && pmax * 2 < (1 << 24) && (long long)p.M * pmax * 2 < (1LL << 31) && (long long)p.Nrows * p.K * 2 < (1LL << 31);
 }
 
 void launch_gemm_dma(const ConvParams& p, hipStream_t s) {

@@ -102,7 +102,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const ConvParams p) {   /
       gidx[i] = -1;
       if (inb) {
         const f16* src; int cs, Cs;
-        if (c < p.C1) { src = p.x; cs = c; Cs = p.C1; } else { src = p.x2; cs = c - p.C1; Cs = p.C2; }
+        if (c < p.C1) { src = p.x; cs = c; Cs = p.ld1 ? p.ld1 : p.C1; } else { src = p.x2; cs = c - p.C1; Cs = p.ld2 ? p.ld2 : p.C2; }
         long long pix = ((long long)rb[i] * p.Hin + (iy >> p.ups)) * p.Win + (ix >> p.ups);
         v = *reinterpret_cast<const uint4*>(src + pix * Cs + cs);
         gidx[i] = rb[i] * Cin + c;
@@ -192,14 +192,18 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const ConvParams p) {   /
     const int m = m0 + wave_m * (BM / 2) + b * 16 + l15;
     mrow[b] = m < p.M ? m : -1;
   }
-  f16x4 rr[MT][NT];
+  f16x4 rr[MT][NT], rl[MT][NT];
   if (p.res) {
 #pragma unroll
     for (int b = 0; b < MT; ++b)
 #pragma unroll
       for (int a = 0; a < NT; ++a) {
         rr[b][a] = (f16x4){(f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f};
-        if (mrow[b] >= 0 && ncol + a * 16 < p.N) rr[b][a] = *reinterpret_cast<const f16x4*>(p.res + (long long)mrow[b] * p.ld_res + ncol + a * 16);
+        rl[b][a] = rr[b][a];
+        if (mrow[b] >= 0 && ncol + a * 16 < p.N) {
+          rr[b][a] = *reinterpret_cast<const f16x4*>(p.res + (long long)mrow[b] * p.ld_res + ncol + a * 16);
+          if (p.res_lo) rl[b][a] = *reinterpret_cast<const f16x4*>(p.res + (long long)mrow[b] * p.ld_res + p.res_lo + ncol + a * 16);
+        }
       }
   }
 #pragma unroll
@@ -222,13 +226,14 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const ConvParams p) {   /
       if (n >= p.N) continue;
       f32x4 v = acc[a][b] + bb[a];
       if (p.temb) v += tt[a];
-      if (p.res) { v[0] += (float)rr[b][a][0]; v[1] += (float)rr[b][a][1]; v[2] += (float)rr[b][a][2]; v[3] += (float)rr[b][a][3]; }
+      if (p.res) { v += up4(rr[b][a]); if (p.res_lo) v += up4(rl[b][a]); }
       if (p.out_f32) {
         *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.y) + m * p.ldy + n) = v;
       } else {
-        f16x4 o = {(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
+        const f16x4 o = cvt4(v);
         *reinterpret_cast<f16x4*>(reinterpret_cast<f16*>(p.y) + m * p.ldy + n) = o;
-        if (p.stats) acc[a][b] = (f32x4){(float)o[0], (float)o[1], (float)o[2], (float)o[3]};
+        if (p.y_lo) *reinterpret_cast<f16x4*>(reinterpret_cast<f16*>(p.y) + m * p.ldy + p.y_lo + n) = cvt4(v - up4(o));
+        if (p.stats) acc[a][b] = p.y_lo ? v : up4(o);
       }
     }
   }
@@ -246,20 +251,16 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const ConvParams p) {   /
 
 template <int BM, int BN, bool FAST, bool GN>
 static void launch_cfg(const ConvParams& p, hipStream_t s) {
-  static bool attr_set = false;
   const size_t smem = 2 * (BM + BN) * BK * sizeof(f16);
   auto kern = igemm_kernel<BM, BN, FAST, GN>;
-  if (!attr_set) {
-    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-    attr_set = true;
-  }
+  ensure_dyn_smem(reinterpret_cast<const void*>(kern), (int)smem);
   const int ntm = (p.M + BM - 1) / BM, ntn = (p.N + BN - 1) / BN;
   static const std::string pname = std::string("igemm<") + std::to_string(BM) + "," + std::to_string(BN) + (FAST ? ",fast" : ",gen") +
                                    (GN ? ",gn>" : ">");
   // algorithmic work: 2*M*N*K flops; each source tensor, the weights and the residual read once, the output written once
   const double esz = 2.0;
   const double in_bytes = (double)p.B * p.Hin * p.Win * (p.C1 + p.C2) * esz;
-  const double bytes = in_bytes + (double)p.N * p.K * esz + (double)p.M * p.N * (p.out_f32 ? 4.0 : esz) + (p.res ? (double)p.M * p.N * esz : 0.0);
+  const double bytes = in_bytes + (double)p.N * p.K * esz + (double)p.M * p.N * (p.out_f32 || p.y_lo ? 4.0 : esz) + (p.res ? (double)p.M * p.N * (p.res_lo ? 4.0 : esz) : 0.0);
   ProfScope prof(pname.c_str(), 2.0 * p.M * (double)p.N * p.K, bytes, s);
   hipLaunchKernelGGL(kern, dim3(ntm * ntn), dim3(256), smem, s, p);
   HIP_CHECK(hipGetLastError());
@@ -287,7 +288,13 @@ void launch_igemm(const ConvParams& p, hipStream_t s) {
   LDIFF_CHECK(p.K == p.ks * p.ks * Cin, LDIFF_ERR_INVALID, "igemm: K=%d != ks*ks*Cin=%d", p.K, p.ks * p.ks * Cin);
   LDIFF_CHECK(p.N % 4 == 0 && p.N <= p.Nrows && p.ldy % 4 == 0 && (p.geglu ? p.N / 2 : p.N) <= p.ldy, LDIFF_ERR_INVALID, "igemm: bad N=%d Nrows=%d ldy=%d", p.N, p.Nrows, p.ldy);
   LDIFF_CHECK((p.C2 == 0) == (p.x2 == nullptr), LDIFF_ERR_INVALID, "igemm: x2/C2 mismatch");
-  LDIFF_CHECK(!p.res || p.ld_res % 4 == 0, LDIFF_ERR_INVALID, "igemm: ld_res must be a multiple of 4");
+  LDIFF_CHECK(!p.res || (p.ld_res % 4 == 0 && p.res_lo % 4 == 0), LDIFF_ERR_INVALID, "igemm: ld_res / res_lo must be multiples of 4");
+  LDIFF_CHECK(p.y_lo % 4 == 0 && (p.y_lo == 0 || (!p.out_f32 && !p.geglu && p.y_lo >= p.N && p.y_lo + p.N <= p.ldy)), LDIFF_ERR_INVALID,
+              "igemm: split output needs fp16 y with N <= y_lo and y_lo + N <= ldy (N=%d y_lo=%d ldy=%d)", p.N, p.y_lo, p.ldy);
+  LDIFF_CHECK((p.ld1 == 0 || (p.ld1 >= p.C1 && p.ld1 % 8 == 0)) && (p.ld2 == 0 || (p.ld2 >= p.C2 && p.ld2 % 8 == 0)), LDIFF_ERR_INVALID,
+              "igemm: row pitches must be multiples of 8 and >= the channel counts");
+  // per-image weights (GroupNorm folded into the layer) exist only in the LDS-DMA GEMM: any other kernel would silently use image 0's
+  LDIFF_CHECK(p.w_bstride == 0 || (!conv3x3_eligible(p) && gemm_dma_eligible(p)), LDIFF_ERR_INVALID, "igemm: per-image weights need the DMA GEMM path");
   LDIFF_CHECK(!p.temb || p.ld_temb % 4 == 0, LDIFF_ERR_INVALID, "igemm: ld_temb must be a multiple of 4");
   if (p.M <= 0) return;
   if (conv3x3_eligible(p)) { launch_conv3x3(p, s); return; }

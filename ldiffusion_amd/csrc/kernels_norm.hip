@@ -21,12 +21,24 @@ static int gn_chunks(int HW) {
 
 size_t gn_partial_bytes(int B, int HW, int C) { return (size_t)B * gn_chunks(HW) * C * 2 * sizeof(float); }
 
+// 8 channels of one pixel as fp32: plain fp16 or split (hi + lo)
+__device__ __forceinline__ void load8(const f16* p, int lo, float (&f)[8]) {
+  const f16x8 h = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(p));
+#pragma unroll
+  for (int j = 0; j < 8; ++j) f[j] = (float)h[j];
+  if (lo) {
+    const f16x8 l = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(p + lo));
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f[j] += (float)l[j];
+  }
+}
+
 // grid (nchunk, B, nsrc); block 256.  Thread (r, cc): channel chunk cc (8 channels), pixel rows r, r+R, ...
-__global__ __launch_bounds__(256) void gn_partial_kernel(const f16* __restrict__ x1, int C1, const f16* __restrict__ x2, int C2,
-                                                         int HW, int pix_per_chunk, int nchunk, float* __restrict__ partial) {
+__global__ __launch_bounds__(256) void gn_partial_kernel(SrcView s1, SrcView s2, int HW, int pix_per_chunk, int nchunk, float* __restrict__ partial) {
   const int src = blockIdx.z;
-  const f16* x = src ? x2 : x1;
-  const int C = src ? C2 : C1, coff = src ? C1 : 0, Ct = C1 + C2;
+  const SrcView sv = src ? s2 : s1;
+  const f16* x = sv.p;
+  const int C = sv.C, ld = sv.ld, lo = sv.lo, coff = src ? s1.C : 0, Ct = s1.C + (s2.p ? s2.C : 0);
   const int b = blockIdx.y, chunk = blockIdx.x;
   const int CC = C >> 3;              // 16-byte chunks per pixel (<= 256)
   const int R = 256 / CC;
@@ -38,25 +50,26 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const f16* __restrict__
 #pragma unroll
   for (int j = 0; j < 8; ++j) { s[j] = 0.f; ss[j] = 0.f; }
   if (r < R) {
-    const f16* base = x + ((long long)b * HW) * C + cc * 8;
+    const f16* base = x + ((long long)b * HW) * ld + cc * 8;
     // 4 independent 16-byte loads in flight per thread (the tensor is read exactly once: pure HBM streaming)
     int pix = p0 + r;
     for (; pix + 3 * R < p1; pix += 4 * R) {
-      f16x8 v0 = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(base + (long long)pix * C));
-      f16x8 v1 = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(base + (long long)(pix + R) * C));
-      f16x8 v2 = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(base + (long long)(pix + 2 * R) * C));
-      f16x8 v3 = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(base + (long long)(pix + 3 * R) * C));
+      float f0[8], f1[8], f2[8], f3[8];
+      load8(base + (long long)pix * ld, lo, f0);
+      load8(base + (long long)(pix + R) * ld, lo, f1);
+      load8(base + (long long)(pix + 2 * R) * ld, lo, f2);
+      load8(base + (long long)(pix + 3 * R) * ld, lo, f3);
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        float f0 = (float)v0[j], f1 = (float)v1[j], f2 = (float)v2[j], f3 = (float)v3[j];
-        s[j] += (f0 + f1) + (f2 + f3);
-        ss[j] += (f0 * f0 + f1 * f1) + (f2 * f2 + f3 * f3);
+        s[j] += (f0[j] + f1[j]) + (f2[j] + f3[j]);
+        ss[j] += (f0[j] * f0[j] + f1[j] * f1[j]) + (f2[j] * f2[j] + f3[j] * f3[j]);
       }
     }
     for (; pix < p1; pix += R) {
-      f16x8 v = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(base + (long long)pix * C));
+      float f[8];
+      load8(base + (long long)pix * ld, lo, f);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) { float f = (float)v[j]; s[j] += f; ss[j] += f * f; }
+      for (int j = 0; j < 8; ++j) { s[j] += f[j]; ss[j] += f[j] * f[j]; }
     }
   }
   // reduce over r through LDS: red[r][c] for sums and squares
@@ -156,40 +169,88 @@ void launch_gn_finalize(const float* part1, int R1, int C1, const float* part2, 
   HIP_CHECK(hipGetLastError());
 }
 
-void launch_gn_stats(const f16* x, int C1, const f16* x2, int C2, int B, int HW, int groups, float eps, const float* gamma,
+static inline SrcView norm_view(SrcView v) { if (v.p && v.ld == 0) v.ld = v.C; return v; }
+
+void launch_gn_stats(SrcView x1, SrcView x2, int B, int HW, int groups, float eps, const float* gamma,
                      const float* beta, float* partial, size_t partial_bytes, float* scale, float* shift, hipStream_t s) {
-  const int C = C1 + C2;
+  x1 = norm_view(x1); x2 = norm_view(x2);
+  if (!x2.p) x2.C = 0;
+  const int C1 = x1.C, C2 = x2.C, C = C1 + C2;
   LDIFF_CHECK(C1 % 8 == 0 && C2 % 8 == 0 && C1 > 0 && C1 <= 2048 && C2 <= 2048, LDIFF_ERR_INVALID, "gn_stats: bad channels C1=%d C2=%d", C1, C2);
+  LDIFF_CHECK(x1.ld % 8 == 0 && x1.lo % 8 == 0 && (!x2.p || (x2.ld % 8 == 0 && x2.lo % 8 == 0)), LDIFF_ERR_INVALID, "gn_stats: pitches must be multiples of 8");
   LDIFF_CHECK(C % groups == 0, LDIFF_ERR_INVALID, "gn_stats: C=%d not divisible by groups=%d", C, groups);
   LDIFF_CHECK(gn_partial_bytes(B, HW, C) <= partial_bytes, LDIFF_ERR_INVALID, "gn_stats: workspace too small");
   const int nchunk = gn_chunks(HW);
   const int pix = (HW + nchunk - 1) / nchunk;
   const size_t smem = 2 * 2048 * sizeof(float);  // [2][R][C] with R*C <= 256*8
-  ProfScope prof("gn_stats", 3.0 * B * HW * (double)C, 2.0 * B * HW * (double)C, s);
-  hipLaunchKernelGGL(gn_partial_kernel, dim3(nchunk, B, C2 ? 2 : 1), dim3(256), smem, s, x, C1, x2, C2, HW, pix, nchunk, partial);
+  ProfScope prof("gn_stats", 3.0 * B * HW * (double)C, 2.0 * B * HW * ((double)C1 * (x1.lo ? 2 : 1) + (double)C2 * (x2.lo ? 2 : 1)), s);
+  hipLaunchKernelGGL(gn_partial_kernel, dim3(nchunk, B, C2 ? 2 : 1), dim3(256), smem, s, x1, x2, HW, pix, nchunk, partial);
   HIP_CHECK(hipGetLastError());
   hipLaunchKernelGGL(gn_finalize_kernel, dim3(groups, B), dim3(64), 0, s, partial, nchunk, C, groups, HW, eps, gamma, beta, scale, shift);
   HIP_CHECK(hipGetLastError());
 }
 
+// ---- GroupNorm-apply (+SiLU) as its own pass (common.h launch_norm_apply): one thread per 8 channels of one pixel ----
+__global__ __launch_bounds__(256) void norm_apply_kernel(SrcView s1, SrcView s2, int HW, long long rows, const float* __restrict__ scale,
+                                                         const float* __restrict__ shift, int silu, f16* __restrict__ y, int ldy, int y_lo) {
+  const int Ct = s1.C + (s2.p ? s2.C : 0), cpr = Ct >> 3;
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * cpr) return;
+  const long long m = i / cpr;
+  const int c = (int)(i - m * cpr) * 8;
+  const int b = (int)(m / HW);
+  float f[8];
+  if (c < s1.C) load8(s1.p + m * s1.ld + c, s1.lo, f);
+  else load8(s2.p + m * s2.ld + (c - s1.C), s2.lo, f);
+  const float* sc = scale + (long long)b * Ct + c;
+  const float* sh = shift + (long long)b * Ct + c;
+  const float4 a0 = *reinterpret_cast<const float4*>(sc), a1 = *reinterpret_cast<const float4*>(sc + 4);
+  const float4 t0 = *reinterpret_cast<const float4*>(sh), t1 = *reinterpret_cast<const float4*>(sh + 4);
+  const float sv[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w}, tv[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
+  f16x8 hi, lo;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    float v = f[j] * sv[j] + tv[j];
+    if (silu) v = v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v * -1.4426950408889634f));
+    hi[j] = (f16)v;
+    lo[j] = (f16)(v - (float)hi[j]);
+  }
+  *reinterpret_cast<uint4*>(y + m * ldy + c) = __builtin_bit_cast(uint4, hi);
+  if (y_lo) *reinterpret_cast<uint4*>(y + m * ldy + y_lo + c) = __builtin_bit_cast(uint4, lo);
+}
+void launch_norm_apply(SrcView x1, SrcView x2, int B, int HW, const float* scale, const float* shift, int silu, f16* y, int ldy, int y_lo,
+                       hipStream_t s) {
+  x1 = norm_view(x1); x2 = norm_view(x2);
+  if (!x2.p) x2.C = 0;
+  const int Ct = x1.C + x2.C;
+  LDIFF_CHECK(x1.p && y && scale && shift && x1.C % 8 == 0 && x2.C % 8 == 0 && x1.ld % 8 == 0 && x1.lo % 8 == 0 && (!x2.p || (x2.ld % 8 == 0 && x2.lo % 8 == 0)) &&
+                  ldy % 8 == 0 && y_lo % 8 == 0 && (y_lo == 0 || y_lo >= Ct) && ldy >= Ct + (y_lo ? y_lo : 0),
+              LDIFF_ERR_INVALID, "norm_apply: bad layout (C=%d+%d ldy=%d y_lo=%d)", x1.C, x2.C, ldy, y_lo);
+  const long long rows = (long long)B * HW, n = rows * (Ct >> 3);
+  if (n == 0) return;
+  ProfScope prof("norm_apply", 4.0 * rows * Ct, 2.0 * rows * ((double)x1.C * (x1.lo ? 2 : 1) + (double)x2.C * (x2.lo ? 2 : 1) + (double)Ct * (y_lo ? 2 : 1)), s);
+  hipLaunchKernelGGL(norm_apply_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x1, x2, HW, rows, scale, shift, silu, y, ldy, y_lo);
+  HIP_CHECK(hipGetLastError());
+}
+
 // ---- LayerNorm: one wave per row, up to 2560 channels (5 chunks of 8 per lane) ----------------
 #define LN_MAXCH 5
-__global__ __launch_bounds__(256) void layernorm_kernel(const f16* __restrict__ x, f16* __restrict__ y, int rows, int C,
+__global__ __launch_bounds__(256) void layernorm_kernel(SrcView xs, f16* __restrict__ y, int rows,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta, float eps) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
-  const int CC = C >> 3;
-  const f16* xr = x + (long long)row * C;
-  f16x8 v[LN_MAXCH];
+  const int C = xs.C, CC = C >> 3;
+  const f16* xr = xs.p + (long long)row * xs.ld;
+  float v[LN_MAXCH][8];
   float sum = 0.f;
 #pragma unroll
   for (int i = 0; i < LN_MAXCH; ++i) {
     const int cc = lane + i * 64;
     if (cc < CC) {
-      v[i] = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(xr + cc * 8));
+      load8(xr + cc * 8, xs.lo, v[i]);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) sum += (float)v[i][j];
+      for (int j = 0; j < 8; ++j) sum += v[i][j];
     }
   }
 #pragma unroll
@@ -201,7 +262,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const f16* __restrict__ 
     const int cc = lane + i * 64;
     if (cc < CC) {
 #pragma unroll
-      for (int j = 0; j < 8; ++j) { float dlt = (float)v[i][j] - mean; var += dlt * dlt; }
+      for (int j = 0; j < 8; ++j) { float dlt = v[i][j] - mean; var += dlt * dlt; }
     }
   }
 #pragma unroll
@@ -214,16 +275,18 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const f16* __restrict__ 
     if (cc < CC) {
       f16x8 o;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) o[j] = (f16)(((float)v[i][j] - mean) * rstd * gamma[cc * 8 + j] + beta[cc * 8 + j]);
+      for (int j = 0; j < 8; ++j) o[j] = (f16)((v[i][j] - mean) * rstd * gamma[cc * 8 + j] + beta[cc * 8 + j]);
       *reinterpret_cast<uint4*>(yr + cc * 8) = __builtin_bit_cast(uint4, o);
     }
   }
 }
 
-void launch_layernorm(const f16* x, f16* y, int rows, int C, const float* gamma, const float* beta, float eps, hipStream_t s) {
-  LDIFF_CHECK(C % 8 == 0 && C <= 8 * 64 * LN_MAXCH, LDIFF_ERR_INVALID, "layernorm: C=%d unsupported", C);
+void launch_layernorm(SrcView x, f16* y, int rows, const float* gamma, const float* beta, float eps, hipStream_t s) {
+  x = norm_view(x);
+  LDIFF_CHECK(x.C % 8 == 0 && x.C <= 8 * 64 * LN_MAXCH && x.ld % 8 == 0 && x.lo % 8 == 0, LDIFF_ERR_INVALID, "layernorm: C=%d unsupported", x.C);
   if (rows <= 0) return;
-  hipLaunchKernelGGL(layernorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, x, y, rows, C, gamma, beta, eps);
+  ProfScope prof("layernorm", 8.0 * rows * x.C, 2.0 * rows * x.C * (x.lo ? 3.0 : 2.0), s);
+  hipLaunchKernelGGL(layernorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, x, y, rows, gamma, beta, eps);
   HIP_CHECK(hipGetLastError());
 }
 

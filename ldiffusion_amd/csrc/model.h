@@ -11,22 +11,36 @@
 #include "../../include/ldiff.h"
 #include "common.h"
 
-struct Act {  // NHWC fp16 activation (tokens [M, C] are B=1,H=1,W=M or keep the image shape)
+// NHWC fp16 activation (tokens [M, C] are B=1,H=1,W=M or keep the image shape).  A SPLIT activation stores every row as
+// [hi(C) | lo(C)] with value = hi + lo (~22 significant bits): the residual stream is kept this way so that
+// the reference's fp32 residual adds survive ~40 chained blocks; plain consumers read the hi half with row pitch 2C, split
+// consumers (the contractions that carry the whole stream: shortcut / proj_in / proj_out / resampling convs) read all 2C
+// channels against weights duplicated along K.
+struct Act {
   f16* p = nullptr;
   int B = 0, H = 0, W = 0, C = 0;
+  bool split = false;
   float* st = nullptr;   // producer-fused GroupNorm partial statistics [B][st_R][C][2] (nullptr: none)
   int st_R = 0;
   long long rows() const { return (long long)B * H * W; }
-  size_t bytes() const { return (size_t)rows() * C * sizeof(f16); }
+  int ld() const { return split ? 2 * C : C; }       // row pitch in elements
+  int lo() const { return split ? C : 0; }           // offset of the lo half inside a row
+  size_t bytes() const { return (size_t)rows() * ld() * sizeof(f16); }
+  SrcView view() const { return SrcView{p, C, ld(), lo()}; }
 };
+
+struct Derived { f16* p = nullptr; int gen = -1; int key = 0; };   // lazily built weights derived from a checkpoint matrix
 
 struct MatW {   // [Nrows][K] fp16 K-major + fp32 bias
   f16* w = nullptr;
   float* b = nullptr;  // nullptr => no bias
   int N = 0, Nrows = 0, K = 0, ks = 1, Cin = 0;  // Cin = padded input channels (K = ks*ks*Cin)
   bool geglu = false;   // rows stored x/gate-interleaved by 16 so that the GEMM epilogue can apply x * gelu(gate) (ConvParams::geglu)
-  mutable f16* w_par = nullptr;   // upsampler convs: parity weights [4][Nrows][4*Cin], built on first use (owned by the Exec)
-  mutable int w_par_gen = -1;     // WeightStore generation the parity weights were derived from
+  int Cin_logical = 0;            // unpadded input channels of a first-layer conv (Cin padded to 8): the split form keeps hi | lo inside the pad
+  // derived weights, built on first use by the Exec that needs them and rebuilt when the checkpoint is reloaded:
+  mutable Derived par;            //   upsampler convs: parity weights [4][Nrows][4*Cin]
+  mutable Derived dup;            //   split operand: [Nrows][taps][2*Cin] (same weights against the hi and the lo half); key = C1 of a concat
+  mutable Derived dup_par;        //   parity weights of the duplicated matrix
 };
 struct NormW { float* g = nullptr; float* b = nullptr; int C = 0; };
 struct GNss { float* scale = nullptr; float* shift = nullptr; };
@@ -72,7 +86,9 @@ struct ConvOpts {
   int Hout = -1, Wout = -1;     // override output size (asymmetric-pad downsample)
   const GNss* gn = nullptr; int silu = 0;
   const float* temb = nullptr; int ld_temb = 0;
-  const Act* res = nullptr;
+  const Act* res = nullptr;      // residual operand (plain or split)
+  bool split_in = false;         // consume the (split) sources as a split operand: K doubled, duplicated weights
+  bool split_out = false;        // write the output as a split activation
   void* out_f32 = nullptr; int ldy_f32 = 0;   // write fp32 [M, ldy] here instead of allocating an fp16 Act
   int N_override = 0;           // columns to store (multiple of 4), default = roundup4(w.N)
   int ldy = 0;                  // fp16 output channel stride (default N stored rounded up to 8)
@@ -90,7 +106,10 @@ class Exec {
   const int* weights_gen = nullptr;   // -> WeightStore::generation of the owning model
   ~Exec();
   void ensure_gn_partial(size_t bytes);
-  Act new_act(int B, int H, int W, int C);
+  Act new_act(int B, int H, int W, int C, bool split = false);
+  const f16* derived_dup(const MatW& w, int C1_logical, int C2_logical);
+  const f16* derived_par(const MatW& w, const f16* src, int Cin, Derived& d);
+  Act norm_apply(const Act& x, const Act* x2, const GNss& g, bool silu, bool split_out);
   void release(Act& a);
   template <typename T> T* tmp(size_t n) { return reinterpret_cast<T*>(arena.alloc(n * sizeof(T))); }
   GNss gn(const Act& x, const Act* x2, const NormW& w, int groups, float eps);
@@ -98,6 +117,8 @@ class Exec {
   Act conv(const MatW& w, const Act& x, const Act* x2, const ConvOpts& o);
   Act layernorm(const Act& x, const NormW& w);
   Act geglu(const Act& x);
+  // ResnetBlock2D (UNet: with time embedding and optional skip concat; VAE: neither) under storage policy `prec`
+  Act resnet(const struct ResnetW& r, const Act& x, const Act* skip, const float* temb, int ld_temb, int groups, float eps, int prec);
 };
 
 // ---- UNet -------------------------------------------------------------------------------------
@@ -109,9 +130,16 @@ struct TransformerW {
   f16* kv_ctx = nullptr;  // [Bctx*L, 2C] precomputed by set_context
 };
 
+// Storage policy of a graph (ldiff_*_set_precision):
+//   0  everything fp16 in HBM (fastest; one UNet pass ~2e-3 of the output range from the fp32 reference)
+//   1  split residual stream: stream tensors hi|lo, residual adds to fp32 round-off, stream-carrying contractions on split operands
+//   2  every conv / linear operand split (K doubled everywhere): ~1e-4; used for the VAE encoder, whose error every later pass inherits
+enum { PREC_FAST = 0, PREC_STREAM = 1, PREC_FULL = 2 };
+
 struct ldiff_unet {
   ldiff_unet_cfg cfg;
   int device = 0;
+  int precision = PREC_STREAM;
   WeightStore ws;
   Exec ex;
   MatW conv_in, conv_out, t_lin1, t_lin2, temb_proj_all;
@@ -129,7 +157,6 @@ struct ldiff_unet {
   void build();
   void set_context(const float* ctx, int Bc, int L, hipStream_t s);
   void forward(const float* x, int B, int h, int w, float t, float* out, hipStream_t s);
-  Act resnet(const ResnetW& r, const Act& x, const Act* skip, const float* temb_all);
   Act transformer(const TransformerW& t, const Act& x);
 };
 
@@ -138,6 +165,8 @@ struct VaeAttnW { NormW gn; MatW qkv, out; int C = 0; };
 struct ldiff_vae {
   ldiff_vae_cfg cfg;
   int device = 0;
+  int prec_enc = PREC_FULL, prec_dec = PREC_STREAM;
+  int prec() const { return cur == &ex_enc ? prec_enc : prec_dec; }
   WeightStore ws;
   // Two workspaces: the decoder's and the encoder's.  A pipelined sampler decodes batch k on the side stream while the encoder
   // of batch k+1 already runs on the caller's stream; ex() is the one the running graph builder uses.
@@ -164,7 +193,6 @@ struct ldiff_vae {
   // writes the fp32 NHWC decoder output [B*8h*8w, 4] into the arena and post-processes it
   void decode(const float* z, int B, int h, int w, float z_scale, float* sample_nchw, float* image_nhwc, uint8_t* rgb, uint8_t* luma,
               int n_slots, int slot, hipStream_t s);
-  Act resnet(const ResnetW& r, const Act& x);
   Act mid_attention(const VaeAttnW& a, const Act& x);
 };
 

@@ -23,6 +23,20 @@ const char* ldiff_error_message() { return g_err; }
 
 static inline int roundup(int x, int m) { return (x + m - 1) / m * m; }
 
+// ---- per-(device, kernel) launch attribute ---------------------------------------------------------
+#include <mutex>
+#include <set>
+void ensure_dyn_smem(const void* kernel, int bytes) {
+  static std::mutex mu;
+  static std::set<std::pair<int, const void*>> done;
+  int dev = 0;
+  HIP_CHECK(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lock(mu);
+  if (done.count({dev, kernel})) return;
+  HIP_CHECK(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+  done.insert({dev, kernel});
+}
+
 // ---- Arena -------------------------------------------------------------------------------------
 Arena::~Arena() {
   if (base_) (void)hipFree(base_);
@@ -116,6 +130,7 @@ MatW WeightStore::add_conv(const std::string& prefix, int Cin, int Cout, int ks,
   if (Cin_pad < 0) Cin_pad = roundup(Cin, 8);
   MatW m;
   m.N = Cout; m.Nrows = roundup(std::max(Cout, min_rows), 16); m.ks = ks; m.Cin = Cin_pad; m.K = ks * ks * Cin_pad;
+  m.Cin_logical = 2 * Cin <= Cin_pad ? Cin : 0;   // hi | lo of a <= 4-channel input fit into the 8 padded channels
   m.w = alloc_mat(m.Nrows, m.K);
   m.b = bias ? alloc_vec(m.Nrows) : nullptr;
   add_rows(prefix + ".weight", prefix + ".bias", m.w, m.K, ks, Cin, Cin_pad, 0, Cout, m.b, bias);
@@ -210,9 +225,9 @@ void Exec::ensure_gn_partial(size_t bytes) {
   HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&gn_partial), bytes));
   gn_partial_cap = bytes;
 }
-Act Exec::new_act(int B, int H, int W, int C) {
+Act Exec::new_act(int B, int H, int W, int C, bool split) {
   Act a;
-  a.B = B; a.H = H; a.W = W; a.C = C;
+  a.B = B; a.H = H; a.W = W; a.C = C; a.split = split;
   a.p = (f16*)arena.alloc(a.bytes());
   return a;
 }
@@ -234,7 +249,7 @@ GNss Exec::gn(const Act& x, const Act* x2, const NormW& w, int groups, float eps
     return g;
   }
   LDIFF_CHECK(gn_partial_bytes(x.B, x.H * x.W, C) <= gn_partial_cap, LDIFF_ERR_RUNTIME, "group norm workspace too small");
-  launch_gn_stats(x.p, x.C, x2 ? x2->p : nullptr, x2 ? x2->C : 0, x.B, x.H * x.W, groups, eps, w.g, w.b, gn_partial, gn_partial_cap, g.scale,
+  launch_gn_stats(x.view(), x2 ? x2->view() : SrcView{nullptr, 0, 0, 0}, x.B, x.H * x.W, groups, eps, w.g, w.b, gn_partial, gn_partial_cap, g.scale,
                   g.shift, s);
   return g;
 }
@@ -243,12 +258,56 @@ void Exec::release(GNss& g) {
   arena.free(g.shift);
   g.scale = g.shift = nullptr;
 }
+// duplicated weights of a split-operand contraction: per tap [a(C1) a(C1) b(C2) b(C2)] from [a(C1) b(C2)]; first-layer convs whose
+// input channels are padded to 8 keep hi | lo inside the pad ([a(c) a(c) 0..] with c = Cin_logical)
+const f16* Exec::derived_dup(const MatW& w, int C1, int C2) {
+  const int gen = weights_gen ? *weights_gen : 0;
+  const bool small = w.Cin_logical > 0;
+  const int dst_stride = small ? w.Cin : 2 * w.Cin;
+  if (!w.dup.p) {
+    void* q = nullptr;
+    HIP_CHECK(hipMalloc(&q, (size_t)w.Nrows * w.ks * w.ks * dst_stride * sizeof(f16)));
+    owned.push_back(q);
+    w.dup.p = (f16*)q;
+  }
+  if (w.dup.gen != gen || w.dup.key != C1) {
+    launch_dup_weights(w.w, w.dup.p, w.Nrows, w.ks * w.ks, w.Cin, small ? w.Cin_logical : C1, small ? 0 : C2, dst_stride, s);
+    w.dup.gen = gen; w.dup.key = C1;
+  }
+  return w.dup.p;
+}
+const f16* Exec::derived_par(const MatW& w, const f16* src, int Cin, Derived& d) {
+  const int gen = weights_gen ? *weights_gen : 0;
+  if (!d.p) {
+    void* q = nullptr;
+    HIP_CHECK(hipMalloc(&q, (size_t)4 * w.Nrows * 4 * Cin * sizeof(f16)));
+    owned.push_back(q);
+    d.p = (f16*)q;
+  }
+  if (d.gen != gen) {   // first use, or the checkpoint was reloaded since
+    launch_make_parity_weights(src, d.p, w.Nrows, Cin, s);
+    d.gen = gen;
+  }
+  return d.p;
+}
 Act Exec::conv(const MatW& w, const Act& x, const Act* x2, const ConvOpts& o) {
   ConvParams p;
   memset(&p, 0, sizeof(p));
-  p.x = x.p; p.C1 = x.C;
-  p.x2 = x2 ? x2->p : nullptr; p.C2 = x2 ? x2->C : 0;
-  LDIFF_CHECK(p.C1 + p.C2 == w.Cin, LDIFF_ERR_INVALID, "conv: input has %d channels, weight expects %d", p.C1 + p.C2, w.Cin);
+  const bool small = w.Cin_logical > 0;   // first-layer conv: <= 4 logical channels inside 8 padded ones (hi | lo fit in the pad)
+  LDIFF_CHECK(!o.split_in || (x.split && (!x2 || x2->split) && !o.gn) || (small && !x.split), LDIFF_ERR_INVALID,
+              "conv: a split operand needs split sources and no GroupNorm prologue");
+  p.x = x.p; p.x2 = x2 ? x2->p : nullptr;
+  if (o.split_in && small) {             // hi | lo live inside the 8 padded channels of ONE source
+    LDIFF_CHECK(!x2, LDIFF_ERR_INVALID, "conv: first-layer split operand takes one source");
+    p.C1 = x.split ? x.ld() : x.C;
+  } else if (o.split_in) {               // all 2C channels of each source, K doubled
+    p.C1 = 2 * x.C; p.C2 = x2 ? 2 * x2->C : 0;
+  } else {                               // hi halves only (row pitch 2C for a split source)
+    p.C1 = x.C; p.C2 = x2 ? x2->C : 0;
+    p.ld1 = x.split ? x.ld() : 0; p.ld2 = (x2 && x2->split) ? x2->ld() : 0;
+  }
+  const int Cin_eff = (o.split_in && !small) ? 2 * w.Cin : w.Cin;
+  LDIFF_CHECK(p.C1 + p.C2 == Cin_eff, LDIFF_ERR_INVALID, "conv: input has %d channels, weight expects %d", p.C1 + p.C2, Cin_eff);
   p.B = x.B; p.Hin = x.H; p.Win = x.W;
   p.ks = w.ks; p.stride = o.stride; p.ups = o.ups;
   p.pad_t = o.pad_t < 0 ? (w.ks - 1) / 2 : o.pad_t;
@@ -256,58 +315,51 @@ Act Exec::conv(const MatW& w, const Act& x, const Act* x2, const ConvOpts& o) {
   const int He = x.H << o.ups, We = x.W << o.ups;
   p.Hout = o.Hout > 0 ? o.Hout : (He + 2 * p.pad_t - w.ks) / o.stride + 1;
   p.Wout = o.Wout > 0 ? o.Wout : (We + 2 * p.pad_l - w.ks) / o.stride + 1;
-  p.w = w.w; p.Nrows = w.Nrows; p.K = w.K;
+  const f16* wsrc = o.split_in ? derived_dup(w, x.C, x2 ? x2->C : 0) : w.w;
+  p.w = wsrc; p.Nrows = w.Nrows; p.K = w.ks * w.ks * Cin_eff;
   p.N = o.N_override ? o.N_override : roundup(w.N, 4);
   p.bias = w.b;
   f16* wfold = nullptr;
   float* bfold = nullptr;
   if (o.gn) { p.gn_scale = o.gn->scale; p.gn_shift = o.gn->shift; p.silu_in = o.silu; }
-  // GroupNorm -> 1x1 conv / Linear with no activation in between (transformer proj_in, VAE attention q/k/v): fold the
-  // normalisation into per-image weights and bias and run the plain LDS-DMA GEMM instead of the register-staged GN prologue
-  const bool fold = o.gn && !o.silu && w.ks == 1 && o.stride == 1 && !x2 && !o.temb && !o.out_f32 && !o.geglu && w.K % 64 == 0 && x.C % 64 == 0 &&
-                    ((x.H * x.W) % 64 == 0) && !o.want_stats;
-  if (fold) {
-    wfold = tmp<f16>((size_t)x.B * w.Nrows * w.K);
-    bfold = tmp<float>((size_t)x.B * w.Nrows);
-    launch_fold_gn_weights(w.w, w.b, o.gn->scale, o.gn->shift, wfold, bfold, x.B, w.Nrows, w.K, s);
-    p.gn_scale = nullptr; p.gn_shift = nullptr; p.silu_in = 0;
-    p.w = wfold; p.bias = bfold; p.w_bstride = (long long)w.Nrows * w.K; p.bias_bstride = w.Nrows;
-  }
   p.temb = o.temb; p.ld_temb = o.ld_temb;
   p.M = x.B * p.Hout * p.Wout;
   if (o.res) {
     LDIFF_CHECK(o.res->rows() == p.M && o.res->C >= p.N, LDIFF_ERR_INVALID, "conv: residual shape mismatch");
-    p.res = o.res->p; p.ld_res = o.res->C;
+    p.res = o.res->p; p.ld_res = o.res->ld(); p.res_lo = o.res->lo();
+  }
+  // GroupNorm -> 1x1 conv / Linear with no activation in between (VAE attention q/k/v; transformer proj_in under PREC_FAST): fold the
+  // normalisation into per-image weights and bias and run the plain LDS-DMA GEMM instead of the register-staged GN prologue
+  if (o.gn && !o.silu && w.ks == 1 && !x2 && !o.out_f32 && !o.geglu && !o.want_stats && !o.split_in) {
+    ConvParams q = p;
+    q.gn_scale = nullptr; q.gn_shift = nullptr; q.silu_in = 0;
+    q.w_bstride = (long long)w.Nrows * w.K; q.bias_bstride = w.Nrows;
+    q.ldy = roundup(p.N, 8) * (o.split_out ? 2 : 1);
+    if (gemm_dma_eligible(q)) {          // same predicate the dispatcher uses: no silent fall-through to a kernel without per-image weights
+      wfold = tmp<f16>((size_t)x.B * w.Nrows * w.K);
+      bfold = tmp<float>((size_t)x.B * w.Nrows);
+      launch_fold_gn_weights(w.w, w.b, o.gn->scale, o.gn->shift, wfold, bfold, x.B, w.Nrows, w.K, s);
+      p = q;
+      p.w = wfold; p.bias = bfold;
+    }
   }
   Act y;
   if (o.geglu) {
-    LDIFF_CHECK(w.geglu && !o.out_f32 && !o.res && !o.want_stats && p.N % 32 == 0, LDIFF_ERR_INVALID, "conv: GEGLU epilogue on a layer that was not built for it");
+    LDIFF_CHECK(w.geglu && !o.out_f32 && !o.res && !o.want_stats && !o.split_out && p.N % 32 == 0, LDIFF_ERR_INVALID, "conv: GEGLU epilogue on a layer that was not built for it");
     p.geglu = 1;
     y = new_act(x.B, p.Hout, p.Wout, p.N / 2);
     p.y = y.p; p.ldy = p.N / 2;
     LDIFF_CHECK(gemm_dma_eligible(p), LDIFF_ERR_INVALID, "conv: GEGLU epilogue needs the DMA GEMM (K %% 64 == 0)");
   } else if (o.out_f32) {
+    LDIFF_CHECK(!o.split_out, LDIFF_ERR_INVALID, "conv: fp32 output cannot be split");
     p.y = o.out_f32; p.ldy = o.ldy_f32; p.out_f32 = 1;
   } else {
-    const int C = o.ldy ? o.ldy : roundup(p.N, 8);
-    y = new_act(x.B, p.Hout, p.Wout, C);
+    const int C = o.ldy ? o.ldy : (o.split_out ? roundup(p.N, 4) : roundup(p.N, 8));
+    y = new_act(x.B, p.Hout, p.Wout, C, o.split_out);
     if (C > p.N) HIP_CHECK(hipMemsetAsync(y.p, 0, y.bytes(), s));  // zero the pad columns
-    p.y = y.p; p.ldy = C;
-    if (o.ups && conv3x3_eligible(p)) {   // nearest-2x upsample folded algebraically (4 parity convs with pre-summed taps)
-      const int gen = weights_gen ? *weights_gen : 0;
-      if (!w.w_par) {
-        void* q = nullptr;
-        HIP_CHECK(hipMalloc(&q, (size_t)4 * w.Nrows * 4 * w.Cin * sizeof(f16)));
-        owned.push_back(q);
-        w.w_par = (f16*)q;
-        w.w_par_gen = -1;
-      }
-      if (w.w_par_gen != gen) {   // first use, or the checkpoint was reloaded since
-        launch_make_parity_weights(w.w, w.w_par, w.Nrows, w.Cin, s);
-        w.w_par_gen = gen;
-      }
-      p.w_par = w.w_par;
-    }
+    p.y = y.p; p.ldy = y.ld(); p.y_lo = y.lo();
+    if (o.ups && conv3x3_eligible(p))   // nearest-2x upsample folded algebraically (4 parity convs with pre-summed taps)
+      p.w_par = derived_par(w, wsrc, Cin_eff, o.split_in ? w.dup_par : w.par);
     if (conv3x3_eligible(p)) p.splitk = conv3x3_splitk_plan(p);
     if (o.want_stats && C == p.N && p.N == w.N && p.splitk <= 1) {
       const int R = conv_stats_blocks_per_image(p);
@@ -326,15 +378,70 @@ Act Exec::conv(const MatW& w, const Act& x, const Act* x2, const ConvOpts& o) {
   if (wfold) { arena.free(bfold); arena.free(wfold); }
   return y;
 }
+Act Exec::norm_apply(const Act& x, const Act* x2, const GNss& g, bool silu, bool split_out) {
+  const int C = x.C + (x2 ? x2->C : 0);
+  Act y = new_act(x.B, x.H, x.W, C, split_out);
+  launch_norm_apply(x.view(), x2 ? x2->view() : SrcView{nullptr, 0, 0, 0}, x.B, x.H * x.W, g.scale, g.shift, silu ? 1 : 0, y.p, y.ld(), y.lo(), s);
+  return y;
+}
 Act Exec::layernorm(const Act& x, const NormW& w) {
   Act y = new_act(x.B, x.H, x.W, x.C);
-  launch_layernorm(x.p, y.p, (int)x.rows(), x.C, w.g, w.b, 1e-5f, s);
+  launch_layernorm(x.view(), y.p, (int)x.rows(), w.g, w.b, 1e-5f, s);
   return y;
 }
 Act Exec::geglu(const Act& x) {
   Act y = new_act(x.B, x.H, x.W, x.C / 2);
   launch_geglu(x.p, y.p, x.rows(), x.C / 2, s);
   return y;
+}
+
+// ResnetBlock2D: GN -> SiLU -> conv3x3 (+temb) -> GN -> SiLU -> conv3x3, + shortcut(x) (1x1 conv iff Cin != Cout).
+//   PREC_FAST   : plain fp16 tensors, GroupNorm-apply+SiLU in the conv's load path.
+//   PREC_STREAM : x / skip / output split; conv1 reads the hi halves (pitch 2C) through the GN prologue, the shortcut conv and the
+//                 residual add see hi + lo.
+//   PREC_FULL   : additionally the normalised operands are materialised split (norm_apply) and both convs run on split operands.
+Act Exec::resnet(const ResnetW& r, const Act& x, const Act* skip, const float* temb, int ld_temb, int groups, float eps, int prec) {
+  const bool st = prec >= PREC_STREAM, full = prec >= PREC_FULL;
+  LDIFF_CHECK(r.has_sc || skip == nullptr, LDIFF_ERR_RUNTIME, "resnet: concat input without shortcut conv");
+  GNss g1 = gn(x, skip, r.n1, groups, eps);
+  ConvOpts o1;
+  o1.temb = temb; o1.ld_temb = ld_temb; o1.want_stats = true;
+  Act h;
+  if (full) {
+    Act a = norm_apply(x, skip, g1, true, true);
+    o1.split_in = true; o1.split_out = true;
+    h = conv(r.c1, a, nullptr, o1);
+    release(a);
+  } else {
+    o1.gn = &g1; o1.silu = 1;
+    h = conv(r.c1, x, skip, o1);
+  }
+  release(g1);
+  GNss g2 = gn(h, nullptr, r.n2, groups, eps);
+  Act sc;
+  const Act* resp = &x;
+  if (r.has_sc) {
+    ConvOpts os;
+    os.split_in = st; os.split_out = st;
+    sc = conv(r.sc, x, skip, os);
+    resp = &sc;
+  }
+  ConvOpts o2;
+  o2.res = resp; o2.want_stats = true; o2.split_out = st;
+  Act out;
+  if (full) {
+    Act a = norm_apply(h, nullptr, g2, true, true);
+    o2.split_in = true;
+    out = conv(r.c2, a, nullptr, o2);
+    release(a);
+  } else {
+    o2.gn = &g2; o2.silu = 1;
+    out = conv(r.c2, h, nullptr, o2);
+  }
+  release(g2);
+  release(h);
+  if (r.has_sc) release(sc);
+  return out;
 }
 
 // ================================================================================================
@@ -495,33 +602,22 @@ void ldiff_unet::set_context(const float* ctx, int Bc, int L, hipStream_t s) {
   ctx_B = Bc; ctx_L = L;
 }
 
-Act ldiff_unet::resnet(const ResnetW& r, const Act& x, const Act* skip, const float* temb_all) {
-  const int G = cfg.norm_num_groups;
-  GNss g1 = ex.gn(x, skip, r.n1, G, cfg.norm_eps);
-  ConvOpts o1;
-  o1.gn = &g1; o1.silu = 1; o1.temb = temb_all + r.temb_off; o1.ld_temb = temb_total; o1.want_stats = true;
-  Act h = ex.conv(r.c1, x, skip, o1);
-  ex.release(g1);
-  GNss g2 = ex.gn(h, nullptr, r.n2, G, cfg.norm_eps);
-  Act sc;
-  const Act* resp = &x;
-  if (r.has_sc) { sc = ex.conv(r.sc, x, skip, ConvOpts()); resp = &sc; }
-  else LDIFF_CHECK(skip == nullptr, LDIFF_ERR_RUNTIME, "resnet: concat input without shortcut conv");
-  ConvOpts o2;
-  o2.gn = &g2; o2.silu = 1; o2.res = resp; o2.want_stats = true;
-  Act out = ex.conv(r.c2, h, nullptr, o2);
-  ex.release(g2);
-  ex.release(h);
-  if (r.has_sc) ex.release(sc);
-  return out;
-}
-
 Act ldiff_unet::transformer(const TransformerW& t, const Act& x) {
   const int C = t.C, heads = cfg.heads, d = C / heads, L = x.H * x.W;
+  const bool st = precision >= PREC_STREAM;
   GNss g = ex.gn(x, nullptr, t.gn, cfg.norm_num_groups, 1e-6f);
-  ConvOpts oi;
-  oi.gn = &g; oi.silu = 0;
-  Act h = ex.conv(t.proj_in, x, nullptr, oi);
+  Act h;
+  if (st) {   // proj_in carries the whole stream: GroupNorm-apply to a split tensor, then a split-operand GEMM
+    Act xn = ex.norm_apply(x, nullptr, g, false, true);
+    ConvOpts oi;
+    oi.split_in = true; oi.split_out = true;
+    h = ex.conv(t.proj_in, xn, nullptr, oi);
+    ex.release(xn);
+  } else {
+    ConvOpts oi;
+    oi.gn = &g; oi.silu = 0;
+    h = ex.conv(t.proj_in, x, nullptr, oi);
+  }
   ex.release(g);
   // self-attention
   Act n1 = ex.layernorm(h, t.ln1);
@@ -536,7 +632,7 @@ Act ldiff_unet::transformer(const TransformerW& t, const Act& x) {
   launch_attention(ap, ex.s);
   ex.release(qkv);
   ConvOpts o1;
-  o1.res = &h;
+  o1.res = &h; o1.split_out = st;
   Act h2 = ex.conv(t.out1, a1, nullptr, o1);
   ex.release(a1);
   ex.release(h);
@@ -551,7 +647,7 @@ Act ldiff_unet::transformer(const TransformerW& t, const Act& x) {
   launch_attention(ap, ex.s);
   ex.release(q2);
   ConvOpts o2;
-  o2.res = &h2;
+  o2.res = &h2; o2.split_out = st;
   Act h3 = ex.conv(t.out2, a2, nullptr, o2);
   ex.release(a2);
   ex.release(h2);
@@ -567,12 +663,12 @@ Act ldiff_unet::transformer(const TransformerW& t, const Act& x) {
     ex.release(f1);
   }
   ConvOpts o3;
-  o3.res = &h3;
+  o3.res = &h3; o3.split_out = st;
   Act h4 = ex.conv(t.ff2, gg, nullptr, o3);
   ex.release(gg);
   ex.release(h3);
   ConvOpts oo;
-  oo.res = &x; oo.want_stats = true;
+  oo.res = &x; oo.want_stats = true; oo.split_in = st; oo.split_out = st;
   Act out = ex.conv(t.proj_out, h4, nullptr, oo);
   ex.release(h4);
   return out;
@@ -590,7 +686,7 @@ void ldiff_unet::forward(const float* x, int B, int h, int w, float tval, float*
   const int C0 = cfg.block_out_channels[0];
   int Cmax = 0;
   for (int i = 0; i < nb; ++i) Cmax = std::max(Cmax, cfg.block_out_channels[i]);
-  ex.arena.reserve((size_t)B * h * w * C0 * 2 * 96 + (size_t)B * temb_total * 16 + (64u << 20));
+  ex.arena.reserve((size_t)B * h * w * C0 * 2 * (precision >= PREC_STREAM ? 160 : 96) + (size_t)B * temb_total * 16 + (64u << 20));
   ex.ensure_gn_partial(gn_partial_bytes(B, h * w, 2 * Cmax));
 
   // time embedding: sinusoid -> linear_1 -> SiLU -> linear_2, then SiLU once and all 22 per-resnet projections in one GEMM
@@ -609,10 +705,15 @@ void ldiff_unet::forward(const float* x, int B, int h, int w, float tval, float*
   { ConvOpts o; o.out_f32 = temb_all; o.ldy_f32 = temb_total; ex.conv(temb_proj_all, l2h, nullptr, o); }
   ex.release(e16); ex.arena.free(l1); ex.release(l1h); ex.arena.free(l2); ex.release(l2h);
 
+  const bool st = precision >= PREC_STREAM;
+  auto rb = [&](const ResnetW& r, const Act& xin, const Act* skip) {
+    return ex.resnet(r, xin, skip, temb_all + r.temb_off, temb_total, cfg.norm_num_groups, cfg.norm_eps, precision);
+  };
   Act x16 = ex.new_act(B, h, w, 8);
-  launch_nchw_f32_to_nhwc_f16(x, x16.p, B, cfg.in_channels, h, w, 8, s);
+  const bool split_first = st && conv_in.Cin_logical > 0;   // the fp32 latents enter as hi | lo inside the 8 padded channels
+  launch_nchw_f32_to_nhwc_f16(x, x16.p, B, cfg.in_channels, h, w, 8, s, split_first ? cfg.in_channels : 0);
   ConvOpts oci;
-  oci.want_stats = true;
+  oci.want_stats = true; oci.split_in = split_first; oci.split_out = st;
   Act cur = ex.conv(conv_in, x16, nullptr, oci);
   ex.release(x16);
 
@@ -625,40 +726,48 @@ void ldiff_unet::forward(const float* x, int B, int h, int w, float tval, float*
   };
   for (int i = 0; i < nb; ++i) {
     for (size_t j = 0; j < down_res[i].size(); ++j) {
-      advance(resnet(down_res[i][j], cur, nullptr, temb_all));
+      advance(rb(down_res[i][j], cur, nullptr));
       if (cfg.down_has_attn[i]) advance(transformer(down_attn[i][j], cur));
       skips.push_back(cur);
       cur_is_skip = true;
     }
     if (has_down[i]) {
       ConvOpts o;
-      o.stride = 2; o.want_stats = true;
+      o.stride = 2; o.want_stats = true; o.split_in = st; o.split_out = st;
       advance(ex.conv(down_sample[i], cur, nullptr, o));
       skips.push_back(cur);
       cur_is_skip = true;
     }
   }
-  advance(resnet(mid_res[0], cur, nullptr, temb_all));
+  advance(rb(mid_res[0], cur, nullptr));
   advance(transformer(mid_attn, cur));
-  advance(resnet(mid_res[1], cur, nullptr, temb_all));
+  advance(rb(mid_res[1], cur, nullptr));
   for (int i = 0; i < nb; ++i) {
     for (size_t j = 0; j < up_res[i].size(); ++j) {
       Act sk = skips.back();
       skips.pop_back();
-      advance(resnet(up_res[i][j], cur, &sk, temb_all));
+      advance(rb(up_res[i][j], cur, &sk));
       ex.release(sk);
       if (cfg.up_has_attn[i]) advance(transformer(up_attn[i][j], cur));
     }
     if (has_up[i]) {
       ConvOpts o;
-      o.ups = 1; o.want_stats = true;
+      o.ups = 1; o.want_stats = true; o.split_in = st; o.split_out = st;
       advance(ex.conv(up_sample[i], cur, nullptr, o));
     }
   }
   GNss g = ex.gn(cur, nullptr, norm_out, cfg.norm_num_groups, cfg.norm_eps);
   const int Nst = roundup(cfg.out_channels, 4);
   float* o32 = ex.tmp<float>((size_t)B * h * w * Nst);
-  { ConvOpts o; o.gn = &g; o.silu = 1; o.out_f32 = o32; o.ldy_f32 = Nst; ex.conv(conv_out, cur, nullptr, o); }
+  if (precision >= PREC_FULL) {
+    Act a = ex.norm_apply(cur, nullptr, g, true, true);
+    ConvOpts o; o.split_in = true; o.out_f32 = o32; o.ldy_f32 = Nst;
+    ex.conv(conv_out, a, nullptr, o);
+    ex.release(a);
+  } else {
+    ConvOpts o; o.gn = &g; o.silu = 1; o.out_f32 = o32; o.ldy_f32 = Nst;
+    ex.conv(conv_out, cur, nullptr, o);
+  }
   launch_nhwc_f32_to_nchw_f32(o32, out, B, cfg.out_channels, h, w, Nst, s);
   ex.release(g);
   ex.arena.free(o32);
@@ -740,32 +849,22 @@ void ldiff_vae::build() {
   d_conv_out = ws.add_conv("decoder.conv_out", ch, cfg.out_channels, 3);
 }
 
-Act ldiff_vae::resnet(const ResnetW& r, const Act& x) {
-  const int G = cfg.norm_num_groups;
-  GNss g1 = ex().gn(x, nullptr, r.n1, G, 1e-6f);
-  ConvOpts o1;
-  o1.gn = &g1; o1.silu = 1; o1.want_stats = true;
-  Act h = ex().conv(r.c1, x, nullptr, o1);
-  ex().release(g1);
-  GNss g2 = ex().gn(h, nullptr, r.n2, G, 1e-6f);
-  Act sc;
-  const Act* resp = &x;
-  if (r.has_sc) { sc = ex().conv(r.sc, x, nullptr, ConvOpts()); resp = &sc; }
-  ConvOpts o2;
-  o2.gn = &g2; o2.silu = 1; o2.res = resp; o2.want_stats = true;
-  Act out = ex().conv(r.c2, h, nullptr, o2);
-  ex().release(g2);
-  ex().release(h);
-  if (r.has_sc) ex().release(sc);
-  return out;
-}
-
 Act ldiff_vae::mid_attention(const VaeAttnW& a, const Act& x) {
   const int C = a.C, L = x.H * x.W;
+  const bool st = prec() >= PREC_STREAM, full = prec() >= PREC_FULL;
   GNss g = ex().gn(x, nullptr, a.gn, cfg.norm_num_groups, 1e-6f);
-  ConvOpts oq;
-  oq.gn = &g; oq.silu = 0;
-  Act qkv = ex().conv(a.qkv, x, nullptr, oq);
+  Act qkv;
+  if (full) {   // normalised operand materialised split, q/k/v on the split operand
+    Act xn = ex().norm_apply(x, nullptr, g, false, true);
+    ConvOpts oq;
+    oq.split_in = true;
+    qkv = ex().conv(a.qkv, xn, nullptr, oq);
+    ex().release(xn);
+  } else {      // GroupNorm folded into per-image q/k/v weights (reads the hi half of a split x)
+    ConvOpts oq;
+    oq.gn = &g; oq.silu = 0;
+    qkv = ex().conv(a.qkv, x, nullptr, oq);
+  }
   ex().release(g);
   Act o = ex().new_act(x.B, x.H, x.W, C);
   AttnParams ap;
@@ -776,7 +875,7 @@ Act ldiff_vae::mid_attention(const VaeAttnW& a, const Act& x) {
   launch_attention(ap, ex().s);
   ex().release(qkv);
   ConvOpts oo;
-  oo.res = &x; oo.want_stats = true;
+  oo.res = &x; oo.want_stats = true; oo.split_out = st;
   Act out = ex().conv(a.out, o, nullptr, oo);
   ex().release(o);
   return out;
@@ -789,42 +888,56 @@ void ldiff_vae::encode(const float* x, int B, int H, int W, float* moments, hipS
   LDIFF_CHECK(ws.missing() == 0, LDIFF_ERR_STATE, "vae: %d weight tensors not loaded (first: %s)", ws.missing(), ws.missing_name(0));
   HIP_CHECK(hipSetDevice(device));
   struct UseEnc { ldiff_vae* v; UseEnc(ldiff_vae* v_) : v(v_) { v->cur = &v->ex_enc; } ~UseEnc() { v->cur = &v->ex_dec; } } use_enc(this);
+  const int pr = prec_enc;
+  const bool st = pr >= PREC_STREAM, full = pr >= PREC_FULL;
   ex().arena.reset();
   ex().s = s;
   const int* boc = cfg.block_out_channels;
   int Cmax = 0;
   for (int i = 0; i < nb; ++i) Cmax = std::max(Cmax, boc[i]);
-  ex().arena.reserve((size_t)B * H * W * boc[0] * 2 * 10 + (size_t)B * (H / f) * (W / f) * Cmax * 2 * 24 + (64u << 20));
+  const size_t mult = full ? 3 : (st ? 2 : 1);
+  ex().arena.reserve(mult * ((size_t)B * H * W * boc[0] * 2 * 10 + (size_t)B * (H / f) * (W / f) * Cmax * 2 * 24) + (64u << 20));
   ex().ensure_gn_partial(std::max(gn_partial_bytes(B, H * W, boc[0]), gn_partial_bytes(B, (H / f) * (W / f), Cmax)));
   for (int i = 0; i < nb; ++i) ex().ensure_gn_partial(gn_partial_bytes(B, (H >> i) * (W >> i), boc[i]));
+  auto rb = [&](const ResnetW& r, const Act& xin) { return ex().resnet(r, xin, nullptr, nullptr, 0, cfg.norm_num_groups, 1e-6f, pr); };
 
   Act x16 = ex().new_act(B, H, W, 8);
-  launch_nchw_f32_to_nhwc_f16(x, x16.p, B, cfg.in_channels, H, W, 8, s);
+  const bool split_first = st && e_conv_in.Cin_logical > 0;   // the fp32 image enters as hi | lo inside the 8 padded channels
+  launch_nchw_f32_to_nhwc_f16(x, x16.p, B, cfg.in_channels, H, W, 8, s, split_first ? cfg.in_channels : 0);
   ConvOpts oci;
-  oci.want_stats = true;
+  oci.want_stats = true; oci.split_in = split_first; oci.split_out = st;
   Act cur = ex().conv(e_conv_in, x16, nullptr, oci);
   ex().release(x16);
   auto advance = [&](Act nxt) { ex().release(cur); cur = nxt; };
   for (int i = 0; i < nb; ++i) {
-    for (auto& r : e_res[i]) advance(resnet(r, cur));
+    for (auto& r : e_res[i]) advance(rb(r, cur));
     if (i != nb - 1) {
       ConvOpts o;  // Downsample2D(padding=0): F.pad(x,(0,1,0,1)) then stride-2 conv without padding
-      o.stride = 2; o.pad_t = 0; o.pad_l = 0; o.Hout = cur.H / 2; o.Wout = cur.W / 2; o.want_stats = true;
+      o.stride = 2; o.pad_t = 0; o.pad_l = 0; o.Hout = cur.H / 2; o.Wout = cur.W / 2; o.want_stats = true; o.split_in = st; o.split_out = st;
       advance(ex().conv(e_down[i], cur, nullptr, o));
     }
   }
-  advance(resnet(e_mid[0], cur));
+  advance(rb(e_mid[0], cur));
   advance(mid_attention(e_attn, cur));
-  advance(resnet(e_mid[1], cur));
+  advance(rb(e_mid[1], cur));
   GNss g = ex().gn(cur, nullptr, e_norm_out, cfg.norm_num_groups, 1e-6f);
-  ConvOpts oc;
-  oc.gn = &g; oc.silu = 1;
-  Act m = ex().conv(e_conv_out, cur, nullptr, oc);   // [B,h,w,8] (2*latent channels, zero padded)
+  Act m;   // [B,h,w,8] (2*latent channels)
+  if (full) {
+    Act a = ex().norm_apply(cur, nullptr, g, true, true);
+    ConvOpts oc;
+    oc.split_in = true; oc.split_out = true; oc.ldy = roundup(2 * cfg.latent_channels, 8);
+    m = ex().conv(e_conv_out, a, nullptr, oc);
+    ex().release(a);
+  } else {
+    ConvOpts oc;
+    oc.gn = &g; oc.silu = 1;
+    m = ex().conv(e_conv_out, cur, nullptr, oc);
+  }
   ex().release(g);
   ex().release(cur);
   const int Nst = roundup(2 * cfg.latent_channels, 4);
   float* q32 = ex().tmp<float>((size_t)m.rows() * Nst);
-  { ConvOpts o; o.out_f32 = q32; o.ldy_f32 = Nst; ex().conv(quant, m, nullptr, o); }
+  { ConvOpts o; o.out_f32 = q32; o.ldy_f32 = Nst; o.split_in = m.split; ex().conv(quant, m, nullptr, o); }
   launch_nhwc_f32_to_nchw_f32(q32, moments, B, 2 * cfg.latent_channels, m.H, m.W, Nst, s);
   ex().arena.free(q32);
   ex().release(m);
@@ -837,46 +950,66 @@ void ldiff_vae::decode(const float* z, int B, int h, int w, float z_scale, float
   LDIFF_CHECK(ws.missing() == 0, LDIFF_ERR_STATE, "vae: %d weight tensors not loaded (first: %s)", ws.missing(), ws.missing_name(0));
   LDIFF_CHECK(!luma || (slot >= 0 && slot < n_slots), LDIFF_ERR_INVALID, "vae_decode: luma slot %d out of range [0,%d)", slot, n_slots);
   HIP_CHECK(hipSetDevice(device));
+  const int pr = prec_dec;
+  const bool st = pr >= PREC_STREAM, full = pr >= PREC_FULL;
   ex().arena.reset();   // decodes of one VAE run on one stream at a time: the workspace is reused in stream order
   ex().s = s;
   const int* boc = cfg.block_out_channels;
   const int H = h * f, W = w * f;
   int Cmax = 0;
   for (int i = 0; i < nb; ++i) Cmax = std::max(Cmax, boc[i]);
-  ex().arena.reserve((size_t)B * H * W * boc[0] * 2 * 10 + (size_t)B * h * w * Cmax * 2 * 24 + (64u << 20));
+  const size_t mult = full ? 3 : (st ? 2 : 1);
+  ex().arena.reserve(mult * ((size_t)B * H * W * boc[0] * 2 * 10 + (size_t)B * h * w * Cmax * 2 * 24) + (64u << 20));
   for (int i = 0; i < nb; ++i) ex().ensure_gn_partial(gn_partial_bytes(B, (H >> i) * (W >> i), boc[std::min(i + 1, nb - 1)]));
   ex().ensure_gn_partial(gn_partial_bytes(B, h * w, Cmax));
+  auto rb = [&](const ResnetW& r, const Act& xin) { return ex().resnet(r, xin, nullptr, nullptr, 0, cfg.norm_num_groups, 1e-6f, pr); };
 
   const long long nz = (long long)B * cfg.latent_channels * h * w;
   float* zs = ex().tmp<float>((size_t)nz);
   launch_scale_f32(z, zs, z_scale, nz, s);
   Act z16 = ex().new_act(B, h, w, 8);
-  launch_nchw_f32_to_nhwc_f16(zs, z16.p, B, cfg.latent_channels, h, w, 8, s);
+  const bool split_first = st && post_quant.Cin_logical > 0 && d_conv_in.Cin_logical > 0;   // z and post_quant(z) as hi | lo in 8 channels
+  launch_nchw_f32_to_nhwc_f16(zs, z16.p, B, cfg.latent_channels, h, w, 8, s, split_first ? cfg.latent_channels : 0);
   ex().arena.free(zs);
-  ConvOpts opq;
-  opq.N_override = 8; opq.ldy = 8;   // rows >= latent_channels are zero => pad channels come out zero
-  Act pq = ex().conv(post_quant, z16, nullptr, opq);
+  Act pq;
+  if (split_first) {
+    ConvOpts opq;
+    opq.split_in = true; opq.split_out = true; opq.N_override = roundup(cfg.latent_channels, 4);
+    pq = ex().conv(post_quant, z16, nullptr, opq);   // [B,h,w, hi(4) | lo(4)]
+  } else {
+    ConvOpts opq;
+    opq.N_override = 8; opq.ldy = 8;   // rows >= latent_channels are zero => pad channels come out zero
+    pq = ex().conv(post_quant, z16, nullptr, opq);
+  }
   ex().release(z16);
   ConvOpts odi;
-  odi.want_stats = true;
+  odi.want_stats = true; odi.split_in = split_first; odi.split_out = st;
   Act cur = ex().conv(d_conv_in, pq, nullptr, odi);
   ex().release(pq);
   auto advance = [&](Act nxt) { ex().release(cur); cur = nxt; };
-  advance(resnet(d_mid[0], cur));
+  advance(rb(d_mid[0], cur));
   advance(mid_attention(d_attn, cur));
-  advance(resnet(d_mid[1], cur));
+  advance(rb(d_mid[1], cur));
   for (int i = 0; i < nb; ++i) {
-    for (auto& r : d_res[i]) advance(resnet(r, cur));
+    for (auto& r : d_res[i]) advance(rb(r, cur));
     if (i != nb - 1) {
       ConvOpts o;
-      o.ups = 1; o.want_stats = true;
+      o.ups = 1; o.want_stats = true; o.split_in = st; o.split_out = st;
       advance(ex().conv(d_up[i], cur, nullptr, o));
     }
   }
   GNss g = ex().gn(cur, nullptr, d_norm_out, cfg.norm_num_groups, 1e-6f);
   const int Nst = 4;
   float* o32 = ex().tmp<float>((size_t)B * H * W * Nst);
-  { ConvOpts o; o.gn = &g; o.silu = 1; o.out_f32 = o32; o.ldy_f32 = Nst; ex().conv(d_conv_out, cur, nullptr, o); }
+  if (full) {
+    Act a = ex().norm_apply(cur, nullptr, g, true, true);
+    ConvOpts o; o.split_in = true; o.out_f32 = o32; o.ldy_f32 = Nst;
+    ex().conv(d_conv_out, a, nullptr, o);
+    ex().release(a);
+  } else {
+    ConvOpts o; o.gn = &g; o.silu = 1; o.out_f32 = o32; o.ldy_f32 = Nst;
+    ex().conv(d_conv_out, cur, nullptr, o);
+  }
   ex().release(g);
   ex().release(cur);
   if (sample_nchw) launch_nhwc_f32_to_nchw_f32(o32, sample_nchw, B, cfg.out_channels, H, W, Nst, s);

@@ -76,6 +76,12 @@ class UNet2DConditionModel:
         self._ctx_key = None
         self.load_state_dict(state_dict)
 
+    def set_precision(self, mode: int):
+        """Storage policy of the graph (include/ldiff.h ldiff_unet_set_precision): 0 all-fp16, 1 split residual stream (default),
+        2 every contraction operand split."""
+        _lib.check(self._lib.ldiff_unet_set_precision(self._h, int(mode)))
+        return self
+
     # ---- checkpoint surface ----
     def load_state_dict(self, sd, strict=True):
         _load_state_dict(self._lib, self._lib.ldiff_unet_load, self._h, sd, weights.unet_param_shapes(self._cfg))
@@ -205,6 +211,11 @@ class AutoencoderKL:
 
     def save_pretrained(self, path):
         weights.save_model_dir(path, self._cfg, self._host_sd)
+
+    def set_precision(self, encoder: int = 2, decoder: int = 1):
+        """Storage policy of the encoder / decoder graphs (include/ldiff.h ldiff_vae_set_precision)."""
+        _lib.check(self._lib.ldiff_vae_set_precision(self._h, int(encoder), int(decoder)))
+        return self
 
     def eval(self):
         return self

@@ -159,9 +159,12 @@ def param_count(shapes) -> int:
 # ------------------------------------------------------------------------------------------
 # seeded synthetic weights
 # ------------------------------------------------------------------------------------------
-def synthetic_state_dict(shapes, seed: int, dtype=torch.float32) -> "OrderedDict[str, torch.Tensor]":
+def synthetic_state_dict(shapes, seed: int, dtype=torch.float32, fp16_values: bool = False) -> "OrderedDict[str, torch.Tensor]":
     """Deterministic (CPU generator) stand-in weights: conv/linear ~ N(0, 1/fan_in), biases ~ 0.02 N,
-    norm gamma ~ 1 + 0.1 N, beta ~ 0.05 N.  Keeps activations O(1) through the ~480-op graph."""
+    norm gamma ~ 1 + 0.1 N, beta ~ 0.05 N.  Keeps activations O(1) through the ~480-op graph.
+    fp16_values=True: every value is fp16-representable (an fp16 checkpoint, BASELINE.json configs[1] "fp16 SD-v1.5 UNet", loaded
+    with torch_dtype=float32 as the reference does, ldiffusion.py:67): the HIP path, which stores conv / linear weights in fp16,
+    and an fp32 consumer of the same dict then hold identical parameters."""
     g = torch.Generator(device="cpu")
     g.manual_seed(seed)
     sd = OrderedDict()
@@ -178,6 +181,8 @@ def synthetic_state_dict(shapes, seed: int, dtype=torch.float32) -> "OrderedDict
             t = torch.randn(shp, generator=g) * (1.0 / fan_in) ** 0.5
         else:
             t = 0.02 * torch.randn(shp, generator=g)
+        if fp16_values:
+            t = t.to(torch.float16).to(torch.float32)
         sd[name] = t.to(dtype)
     return sd
 

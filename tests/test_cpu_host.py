@@ -24,7 +24,7 @@ def test_library_exports_every_symbol_declared_in_header(lib):
     assert declared == set(_lib.SIGNATURES), f"header vs ctypes table differ: {declared ^ set(_lib.SIGNATURES)}"
     for name in declared:
         assert hasattr(lib, name), f"{name} not exported by libldiff_hip.so"
-    assert lib.ldiff_version() == 100
+    assert lib.ldiff_version() == 110
 
 
 def test_host_only_entry_points_match_oracle(lib):
@@ -121,6 +121,22 @@ def test_gather_masks_world_size_2_gloo(tmp_path):
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=240, env=dict(os.environ, OMP_NUM_THREADS="1"))
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert (tmp_path / "rank0.ok").exists() and (tmp_path / "rank1.ok").exists(), r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_bench_self_launches_n_ranks_without_a_launcher():
+    """`python bench.py --gpus 2` with no WORLD_SIZE around it must spawn its own ranks (the driver starts it that way) and
+    rank 0 must print the JSON line with n_gpus=2; --launch-check stops after the rendezvous so it runs without a GPU."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--launch-check"], capture_output=True, text=True,
+                       timeout=240, env=dict(env, OMP_NUM_THREADS="1"))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    import json
+    lines = [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert lines == [{"launch_check": True, "n_gpus": 2, "local_rank": 0}], r.stdout[-2000:]
+    # already wrapped by a launcher whose world disagrees with the flag: refuse, do not spawn again
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--launch-check"], capture_output=True, text=True,
+                       timeout=120, env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"))
+    assert r.returncode != 0 and "disagree" in r.stderr
 
 
 def test_pixel_latent_vector_export_matches_reference_loop(tmp_path):

@@ -283,7 +283,7 @@ def test_group_norm_stats(lib, name):
     scale = torch.empty((B, Cc), device=DEV)
     shift = torch.empty((B, Cc), device=DEV)
     gd, bd = gamma.to(DEV), beta.to(DEV)
-    _lib.check(lib.ldiff_op_gn_stats(x1.data_ptr(), C1, x2.data_ptr() if C2 else None, C2, B, HW, groups, eps, gd.data_ptr(), bd.data_ptr(),
+    _lib.check(lib.ldiff_op_gn_stats(x1.data_ptr(), C1, 0, 0, x2.data_ptr() if C2 else None, C2, 0, 0, B, HW, groups, eps, gd.data_ptr(), bd.data_ptr(),
                                      scale.data_ptr(), shift.data_ptr(), sp()))
     torch.cuda.synchronize()
     xr = x16.float()
@@ -300,7 +300,7 @@ def test_layernorm(lib, rows, C):
     gamma, beta = 1 + 0.1 * torch.randn(C, generator=g), 0.1 * torch.randn(C, generator=g)
     xd, gd, bd = x.to(torch.float16).to(DEV), gamma.to(DEV), beta.to(DEV)
     y = torch.empty_like(xd)
-    _lib.check(lib.ldiff_op_layernorm(xd.data_ptr(), y.data_ptr(), rows, C, gd.data_ptr(), bd.data_ptr(), 1e-5, sp()))
+    _lib.check(lib.ldiff_op_layernorm(xd.data_ptr(), 0, 0, y.data_ptr(), rows, C, gd.data_ptr(), bd.data_ptr(), 1e-5, sp()))
     torch.cuda.synchronize()
     ref = F.layer_norm(r16(x), (C,), gamma, beta, 1e-5)
     assert_close(y, ref, f"layernorm {rows}x{C}", rtol=1e-3, atol_rel=1e-3)
@@ -323,10 +323,19 @@ def test_layout_nchw_to_nhwc_pads_channels(lib):
     x = torch.randn((2, 3, 5, 7))
     xd = x.to(DEV)
     y = torch.full((2, 5, 7, 8), float("nan"), dtype=torch.float16, device=DEV)
-    _lib.check(lib.ldiff_op_nchw_to_nhwc(xd.data_ptr(), y.data_ptr(), 2, 3, 5, 7, 8, sp()))
+    _lib.check(lib.ldiff_op_nchw_to_nhwc(xd.data_ptr(), y.data_ptr(), 2, 3, 5, 7, 8, 0, sp()))
     torch.cuda.synchronize()
     assert torch.equal(y[..., :3].cpu(), x.permute(0, 2, 3, 1).to(torch.float16))
     assert (y[..., 3:] == 0).all()
+    # split form: hi at channels 0..2, the rounding remainder at 3..5, zeros after
+    _lib.check(lib.ldiff_op_nchw_to_nhwc(xd.data_ptr(), y.data_ptr(), 2, 3, 5, 7, 8, 3, sp()))
+    torch.cuda.synchronize()
+    xh = x.permute(0, 2, 3, 1)
+    hi = xh.to(torch.float16)
+    assert torch.equal(y[..., :3].cpu(), hi) and torch.equal(y[..., 3:6].cpu(), (xh - hi.float()).to(torch.float16)) and (y[..., 6:] == 0).all()
+    assert (y[..., :3].float().cpu() + y[..., 3:6].float().cpu() - xh).abs().max() <= 2e-6 * xh.abs().max()
+    with pytest.raises(ValueError):
+        _lib.check(lib.ldiff_op_nchw_to_nhwc(xd.data_ptr(), y.data_ptr(), 2, 3, 5, 7, 8, 6, sp()))   # lo half does not fit
 
 
 FUSED_STATS_CASES = {
@@ -399,3 +408,205 @@ def test_linear_with_fused_geglu_epilogue(lib, M, Cc, inner):
     a.res, a.ld_res = y.data_ptr(), inner                       # a residual cannot be combined with the GEGLU epilogue
     with pytest.raises(ValueError):
         _lib.check(lib.ldiff_op_conv(C.byref(a), sp()))
+
+
+# ======================================================================================================================
+# Split tensors (fp16 hi | lo per row, value = hi + lo): the residual stream of the UNet / VAE (DESIGN.md section 3)
+# ======================================================================================================================
+def to_split(x_nhwc):
+    """[..., C] f32 -> [..., 2C] f16 = [hi | lo]"""
+    hi = x_nhwc.to(torch.float16)
+    lo = (x_nhwc - hi.float()).to(torch.float16)
+    return torch.cat([hi, lo], -1).contiguous()
+
+
+def from_split(t, C):
+    return t[..., :C].float() + t[..., C:2 * C].float()
+
+
+SPLIT_CASES = {
+    # name: (B, C1, C2, H, W, Cout, ks, stride, ups, operand_split, gn)
+    "wide3x3_hi_operand_gn": (2, 64, 0, 16, 32, 128, 3, 1, 0, False, True),          # resnet conv1 reading a split x through the GN prologue
+    "wide3x3_hi_operand_concat_gn": (1, 128, 64, 16, 16, 64, 3, 1, 0, False, True),   # ... with a split skip tensor
+    "small3x3_8x8_hi_operand": (2, 128, 0, 8, 8, 128, 3, 1, 0, False, True),
+    "splitk3x3_hi_operand": (1, 1280, 0, 8, 8, 128, 3, 1, 0, False, True),
+    "gemm_split_operand_shortcut_concat": (2, 128, 64, 16, 16, 128, 1, 1, 0, True, False),   # conv_shortcut over [x | skip], both split
+    "gemm_split_operand_proj": (1, 320, 0, 1, 300, 320, 1, 1, 0, True, False),
+    "igemm_stride2_split_operand": (2, 64, 0, 16, 16, 64, 3, 2, 0, True, False),       # downsampler on the split stream
+    "wide3x3_upsample_split_operand": (1, 64, 0, 16, 16, 64, 3, 1, 1, True, False),    # upsampler (parity folding on duplicated weights)
+    "wide3x3_split_operand": (1, 64, 0, 16, 16, 96, 3, 1, 0, True, False),             # PREC_FULL conv on a normalised split operand
+}
+
+
+@pytest.mark.parametrize("name", list(SPLIT_CASES))
+def test_conv_on_split_tensors(lib, name):
+    """Sources, residual and output as split tensors.  With a hi-only operand the MFMA sees fp16(x); with a split operand it sees
+    x to ~22 bits.  Either way the residual add and the stored output must be exact to fp32 round-off: |hi+lo - ref| <= 3e-6."""
+    B, C1, C2, H, W, Cout, ks, stride, ups, opsplit, use_gn = SPLIT_CASES[name]
+    g = torch.Generator().manual_seed(zlib.crc32(name.encode()) % 1000)
+    Cin = C1 + C2
+    x = torch.randn((B, H, W, C1), generator=g)
+    x2 = torch.randn((B, H, W, C2), generator=g) if C2 else None
+    w = r16(torch.randn((Cout, Cin, ks, ks), generator=g) / math.sqrt(Cin * ks * ks))
+    bias = torch.randn(Cout, generator=g) * 0.1
+    gn = (1.0 + 0.2 * torch.randn((B, Cin), generator=g), 0.2 * torch.randn((B, Cin), generator=g)) if use_gn else None
+    He, We = H << ups, W << ups
+    Ho, Wo = (He + 2 * (ks // 2) - ks) // stride + 1, (We + 2 * (ks // 2) - ks) // stride + 1
+    res = torch.randn((B, Ho, Wo, Cout), generator=g) * 3.0
+    xs, x2s = to_split(x), (to_split(x2) if C2 else None)
+    # ---- reference (float64): the operand the kernel sees, exact weights, exact residual hi + lo ----
+    seen = (lambda t, C: from_split(t, C)) if opsplit else (lambda t, C: t[..., :C].float())
+    a = seen(xs, C1) if not C2 else torch.cat([seen(xs, C1), seen(x2s, C2)], -1)
+    a = a.permute(0, 3, 1, 2).double()
+    if gn is not None:
+        a = F.silu(a * gn[0].double()[:, :, None, None] + gn[1].double()[:, :, None, None])
+        a = r16(a.float()).double()
+    if ups:
+        a = F.interpolate(a, scale_factor=2.0, mode="nearest")
+    rs = to_split(res)
+    ref = F.conv2d(a, w.double(), bias.double(), stride=stride, padding=ks // 2) + from_split(rs, Cout).permute(0, 3, 1, 2).double()
+    # ---- device ----
+    Nrows = (Cout + 15) // 16 * 16
+    wd = torch.zeros((Nrows, ks, ks, Cin), dtype=torch.float16)
+    wd[:Cout] = w.permute(0, 2, 3, 1).to(torch.float16)
+    wd = wd.reshape(Nrows, ks * ks * Cin).contiguous().to(DEV)
+    a_ = _lib.ConvArgs()
+    xd = xs.to(DEV)
+    x2d = x2s.to(DEV) if C2 else None
+    if opsplit:
+        wdup = torch.full((Nrows, ks * ks * 2 * Cin), float("nan"), dtype=torch.float16, device=DEV)
+        _lib.check(lib.ldiff_op_dup_weights(wd.data_ptr(), wdup.data_ptr(), Nrows, ks * ks, Cin, C1, C2, 2 * Cin, sp()))
+        a_.w, a_.C1, a_.C2 = wdup.data_ptr(), 2 * C1, 2 * C2
+    else:
+        a_.w, a_.C1, a_.C2, a_.ld1, a_.ld2 = wd.data_ptr(), C1, C2, 2 * C1, 2 * C2
+    a_.x = xd.data_ptr()
+    if C2:
+        a_.x2 = x2d.data_ptr()
+    a_.B, a_.Hin, a_.Win, a_.Hout, a_.Wout = B, H, W, Ho, Wo
+    a_.ks, a_.stride, a_.ups, a_.pad_t, a_.pad_l = ks, stride, ups, ks // 2, ks // 2
+    a_.N, a_.Nrows = Cout, Nrows
+    if gn is not None:
+        sd, hd = gn[0].contiguous().to(DEV), gn[1].contiguous().to(DEV)
+        a_.gn_scale, a_.gn_shift, a_.silu_in = sd.data_ptr(), hd.data_ptr(), 1
+    bd = torch.zeros(Nrows); bd[:Cout] = bias; bd = bd.to(DEV)
+    a_.bias = bd.data_ptr()
+    rd = rs.to(DEV)
+    a_.res, a_.ld_res, a_.res_lo = rd.data_ptr(), 2 * Cout, Cout
+    y = torch.full((B, Ho, Wo, 2 * Cout), float("nan"), dtype=torch.float16, device=DEV)
+    a_.y, a_.ldy, a_.y_lo = y.data_ptr(), 2 * Cout, Cout
+    R = lib.ldiff_op_conv_stats_blocks(C.byref(a_)) if name != "splitk3x3_hi_operand" else 0
+    if R > 0:
+        st = torch.full((B, Cout, R, 2), float("nan"), device=DEV)
+        a_.stats = st.data_ptr()
+    _lib.check(lib.ldiff_op_conv(C.byref(a_), sp()))
+    torch.cuda.synchronize()
+    yc = y.cpu()
+    got = from_split(yc, Cout).permute(0, 3, 1, 2).double()
+    err = (got - ref).abs().max().item() / ref.abs().max().item()
+    print(f"{name}: split output rel err {err:.2e}")
+    # nearest-2x folding pre-sums 2-4 taps and rounds the sums to fp16: a weight rounding (2^-12 rms) the 9-tap form does not have
+    tol = 6e-4 if ups else 1e-5   # fp32 accumulation order over K up to 11,520 terms
+    assert torch.isfinite(got).all() and err <= tol, f"{name}: {err:.3e}"
+    if R > 0:   # fused statistics describe the fp32 value (hi + lo), not the rounded hi half
+        gamma, beta = torch.ones(Cout), torch.zeros(Cout)
+        scale, shift = torch.empty((B, Cout), device=DEV), torch.empty((B, Cout), device=DEV)
+        gd, btd = gamma.to(DEV), beta.to(DEV)
+        _lib.check(lib.ldiff_op_gn_finalize(st.data_ptr(), R, Cout, None, 0, 0, B, Ho * Wo, 32, 1e-5, gd.data_ptr(), btd.data_ptr(),
+                                            scale.data_ptr(), shift.data_ptr(), sp()))
+        torch.cuda.synchronize()
+        gotn = got.float() * scale.cpu()[:, :, None, None] + shift.cpu()[:, :, None, None]
+        refn = F.group_norm(got.float(), 32, gamma, beta, 1e-5)
+        assert (gotn - refn).abs().max() <= 2e-4 * max(1.0, refn.abs().max())
+
+
+def test_split_operand_beats_plain_operand(lib):
+    """The point of the split operand: the same 1x1 conv over the same fp32 stream is ~2^-11 accurate with a plain fp16 operand and
+    ~1e-6 with the split one."""
+    g = torch.Generator().manual_seed(1)
+    M, Cc, N = 512, 320, 320
+    x = torch.randn((1, 1, M, Cc), generator=g)
+    w = r16(torch.randn((N, Cc), generator=g) / math.sqrt(Cc))
+    ref = (x[0, 0].double() @ w.double().t())
+    wd = w.to(torch.float16).contiguous().to(DEV)
+    wdup = torch.empty((N, 2 * Cc), dtype=torch.float16, device=DEV)
+    _lib.check(lib.ldiff_op_dup_weights(wd.data_ptr(), wdup.data_ptr(), N, 1, Cc, Cc, 0, 2 * Cc, sp()))
+    xs = to_split(x).to(DEV)
+    errs = {}
+    for mode in ("plain", "split"):
+        a = _lib.ConvArgs()
+        a.x, a.B, a.Hin, a.Win, a.Hout, a.Wout, a.ks, a.stride = xs.data_ptr(), 1, 1, M, 1, M, 1, 1
+        if mode == "plain":
+            a.C1, a.ld1, a.w = Cc, 2 * Cc, wd.data_ptr()
+        else:
+            a.C1, a.w = 2 * Cc, wdup.data_ptr()
+        y = torch.empty((M, N), dtype=torch.float32, device=DEV)
+        a.N, a.Nrows, a.y, a.ldy, a.out_f32 = N, N, y.data_ptr(), N, 1
+        _lib.check(lib.ldiff_op_conv(C.byref(a), sp()))
+        torch.cuda.synchronize()
+        errs[mode] = ((y.cpu().double() - ref).abs().max() / ref.abs().max()).item()
+    print(f"1x1 conv over an fp32 stream: plain fp16 operand {errs['plain']:.2e}, split operand {errs['split']:.2e}")
+    assert errs["split"] <= 3e-6 and errs["plain"] > 20 * errs["split"]
+
+
+@pytest.mark.parametrize("C1,C2,in_split,out_split,silu", [(64, 0, True, True, 1), (128, 64, True, False, 1), (320, 0, False, True, 0), (64, 32, True, True, 0)])
+def test_norm_apply(lib, C1, C2, in_split, out_split, silu):
+    g = torch.Generator().manual_seed(C1 + C2)
+    B, HW = 2, 300
+    Cc = C1 + C2
+    x = torch.randn((B, HW, Cc), generator=g) * 2
+    scale, shift = 1 + 0.2 * torch.randn((B, Cc), generator=g), 0.3 * torch.randn((B, Cc), generator=g)
+    pack = to_split if in_split else (lambda t: t.to(torch.float16).contiguous())
+    x1d = pack(x[..., :C1]).to(DEV)
+    x2d = pack(x[..., C1:]).to(DEV) if C2 else None
+    seen = (lambda t, C: from_split(t.cpu(), C)) if in_split else (lambda t, C: t.cpu().float())
+    xin = seen(x1d, C1) if not C2 else torch.cat([seen(x1d, C1), seen(x2d, C2)], -1)
+    ref = xin.double() * scale.double()[:, None, :] + shift.double()[:, None, :]
+    if silu:
+        ref = F.silu(ref)
+    ld = lambda C: 2 * C if in_split else C
+    lo = lambda C: C if in_split else 0
+    y = torch.full((B, HW, 2 * Cc if out_split else Cc), float("nan"), dtype=torch.float16, device=DEV)
+    sd, hd = scale.to(DEV), shift.to(DEV)
+    _lib.check(lib.ldiff_op_norm_apply(x1d.data_ptr(), C1, ld(C1), lo(C1), x2d.data_ptr() if C2 else None, C2, ld(C2), lo(C2), B, HW, sd.data_ptr(),
+                                       hd.data_ptr(), silu, y.data_ptr(), y.shape[-1], Cc if out_split else 0, sp()))
+    torch.cuda.synchronize()
+    yc = y.cpu()
+    if out_split:
+        err = (from_split(yc, Cc).double() - ref).abs().max() / ref.abs().max()
+        assert err <= 3e-6, f"split output err {err:.2e}"
+    else:
+        assert_close(yc, ref.float(), "norm_apply", rtol=6e-4, atol_rel=1e-6)   # one fp16 rounding of the exact value
+    with pytest.raises(ValueError):
+        _lib.check(lib.ldiff_op_norm_apply(x1d.data_ptr(), C1, ld(C1), lo(C1), None, 0, 0, 0, B, HW, sd.data_ptr(), hd.data_ptr(), silu, y.data_ptr(), C1 - 8, 0, sp()))
+
+
+def test_layernorm_and_groupnorm_statistics_read_split_tensors(lib):
+    g = torch.Generator().manual_seed(12)
+    rows, Cc = 513, 320
+    x = torch.randn((rows, Cc), generator=g) * 2 + 0.5
+    gamma, beta = 1 + 0.1 * torch.randn(Cc, generator=g), 0.1 * torch.randn(Cc, generator=g)
+    xs = to_split(x).to(DEV)
+    gd, bd = gamma.to(DEV), beta.to(DEV)
+    y = torch.empty((rows, Cc), dtype=torch.float16, device=DEV)
+    _lib.check(lib.ldiff_op_layernorm(xs.data_ptr(), 2 * Cc, Cc, y.data_ptr(), rows, Cc, gd.data_ptr(), bd.data_ptr(), 1e-5, sp()))
+    torch.cuda.synchronize()
+    ref = F.layer_norm(from_split(xs.cpu(), Cc), (Cc,), gamma, beta, 1e-5)
+    assert_close(y, ref, "layernorm split", rtol=6e-4, atol_rel=1e-5)           # exactly one fp16 rounding
+    # hi-only view of the same buffer (pitch 2C, lo = 0) == LayerNorm of the rounded tensor
+    _lib.check(lib.ldiff_op_layernorm(xs.data_ptr(), 2 * Cc, 0, y.data_ptr(), rows, Cc, gd.data_ptr(), bd.data_ptr(), 1e-5, sp()))
+    torch.cuda.synchronize()
+    assert_close(y, F.layer_norm(r16(x), (Cc,), gamma, beta, 1e-5), "layernorm pitch", rtol=1e-3, atol_rel=1e-3)
+    # GroupNorm statistics over a split concat
+    B, HW, C1, C2 = 2, 256, 128, 64
+    xg = torch.randn((B, HW, C1 + C2), generator=g) * 1.7 + 0.3
+    x1, x2 = to_split(xg[..., :C1]).to(DEV), to_split(xg[..., C1:]).to(DEV)
+    gam, bet = 1 + 0.1 * torch.randn(C1 + C2, generator=g), 0.1 * torch.randn(C1 + C2, generator=g)
+    scale, shift = torch.empty((B, C1 + C2), device=DEV), torch.empty((B, C1 + C2), device=DEV)
+    g2, b2 = gam.to(DEV), bet.to(DEV)
+    _lib.check(lib.ldiff_op_gn_stats(x1.data_ptr(), C1, 2 * C1, C1, x2.data_ptr(), C2, 2 * C2, C2, B, HW, 32, 1e-5, g2.data_ptr(), b2.data_ptr(),
+                                     scale.data_ptr(), shift.data_ptr(), sp()))
+    torch.cuda.synchronize()
+    xr = torch.cat([from_split(x1.cpu(), C1), from_split(x2.cpu(), C2)], -1)
+    got = xr * scale.cpu()[:, None, :] + shift.cpu()[:, None, :]
+    ref = F.group_norm(xr.permute(0, 2, 1), 32, gam, bet, 1e-5).permute(0, 2, 1)
+    assert (got - ref).abs().max() <= 2e-5 * max(1.0, ref.abs().max())

@@ -1,10 +1,13 @@
 """-m gpu: UNet / VAE / scheduler / sampler through the python shims (which bind the C ABI) against the CPU oracle.
 
-Tolerances.  BASELINE.json's north star asks for latents within 1e-3 of the (fp32) CPU path with an fp16 UNet.
-Storage is fp16 (rel. 2^-11 = 4.9e-4 per rounding) through ~480 chained ops, so what is asserted here is:
-  * one UNet pass / VAE encode / VAE decode: max|err| <= 1e-2 * max|ref|  (measured values are printed and recorded
-    in BASELINE.md; they are ~1e-3 of the output range),
-  * uint8 images: at most 1 grey level apart on >= 99% of pixels (a 1e-3 float error moves a rounding boundary),
+Tolerances.  BASELINE.json's north star: latents within 1e-3 of the (fp32) CPU path with an fp16 UNet, identical arg-max masks.
+All errors are max|got - ref| / max|ref| (relative to the range of the compared tensor).  Checkpoints are fp16-valued (configs[1]:
+"fp16 SD-v1.5 UNet") and both sides load the same values; every MFMA operand is fp16, the residual stream is kept as fp16 hi|lo
+pairs.  Asserted:
+  * sampler latents after every pass, VAE encode mean: <= 1e-3 (measured 0.7e-4 .. 4.7e-4 at SD-v1.5 width, <= 3.6e-4 tiny),
+  * one UNet pass (eps): <= 1e-3 at SD-v1.5 width (measured 7.4e-4), <= 1.2e-3 at 1/5 width (measured 6.0e-4 .. 9.1e-4: a
+    64-channel graph averages less rounding noise per output than a 320-channel one),
+  * VAE decode (image range, not a latent): <= 3e-3 (measured 1.4e-3 .. 1.7e-3); uint8 images / luma: at most 1 grey level apart,
   * integer kernels given identical inputs (luma, uint8 rounding, argmax): bit exact.
 """
 import numpy as np
@@ -30,8 +33,8 @@ def rel_err(got, ref):
 @pytest.fixture(scope="module")
 def tiny():
     ucfg, vcfg = configs.TINY_UNET, configs.TINY_VAE
-    usd = weights.synthetic_state_dict(weights.unet_param_shapes(ucfg), 42)
-    vsd = weights.synthetic_state_dict(weights.vae_param_shapes(vcfg), 43)
+    usd = weights.synthetic_state_dict(weights.unet_param_shapes(ucfg), 42, fp16_values=True)
+    vsd = weights.synthetic_state_dict(weights.vae_param_shapes(vcfg), 43, fp16_values=True)
     unet, vae = UNet2DConditionModel(ucfg, usd, DEV), AutoencoderKL(vcfg, vsd, DEV)
     pipe = StableDiffusionImg2ImgPipeline(vae, unet)
     opipe = op.OraclePipeline(op.OracleUNet(usd, ucfg), op.OracleVAE(vsd, vcfg))
@@ -47,7 +50,7 @@ def test_unet_forward_tiny(tiny, B, h, w, L, t):
     ref = tiny["opipe"].unet(x, t, ctx)
     e = rel_err(out.sample, ref.sample)
     print(f"unet tiny B={B} {h}x{w} L={L} t={t}: rel err {e:.3e}")
-    assert out[0] is out.sample and e < 1e-2
+    assert out[0] is out.sample and e <= 1.2e-3
 
 
 def test_unet_per_sample_context_and_errors(tiny):
@@ -56,7 +59,7 @@ def test_unet_per_sample_context_and_errors(tiny):
     ctx = torch.randn((2, 5, 64), generator=g)
     out = tiny["unet"](x.to(DEV), 251, ctx.to(DEV)).sample
     ref = tiny["opipe"].unet(x, 251, ctx).sample
-    assert rel_err(out, ref) < 1e-2
+    assert rel_err(out, ref) <= 1.2e-3
     with pytest.raises(ValueError):
         tiny["unet"](x.to(DEV), 1, torch.randn((3, 5, 64), device=DEV))       # context batch mismatch
     with pytest.raises(ValueError):
@@ -80,7 +83,7 @@ def test_vae_encode_decode_tiny(tiny, B, H, W):
     odec = tiny["opipe"].vae.decode(z).sample
     e_dec = rel_err(dec, odec)
     print(f"vae tiny {B}x{H}x{W}: mean {e_mean:.3e} logvar {e_logvar:.3e} decode {e_dec:.3e}")
-    assert e_mean < 1e-2 and e_logvar < 1e-2 and e_dec < 1e-2
+    assert e_mean <= 3e-4 and e_logvar <= 3e-4 and e_dec <= 3e-3
     assert dist.sample().shape == dist.mean.shape
 
 
@@ -90,7 +93,7 @@ def test_decode_latents_uint8_and_luma(tiny):
     img = tiny["pipe"].decode_latents(z.to(DEV))
     oimg = tiny["opipe"].decode_latents(z)
     assert img.shape == oimg.shape == (2, 64, 64, 3) and img.dtype == np.float32
-    assert np.abs(img - oimg).max() < 1e-2
+    assert np.abs(img - oimg).max() <= 3e-3
     # fused uint8 + luma slots vs the oracle's integer pipeline applied to the *device* float image: bit exact
     luma = torch.zeros((2, 3, 64, 64), dtype=torch.uint8, device=DEV)
     _, image, rgb = tiny["vae"]._decode(z.to(DEV), 1 / 0.18215, want_image=True, want_rgb=True, luma=luma, slot=1)
@@ -142,7 +145,7 @@ def test_fused_sampler_matches_oracle_tiny(tiny, N):
     rd = np.abs(out["rgb"].cpu().numpy().astype(int) - ref["rgb_u8"][:, -1].astype(int))
     print(f"sampler N={N}: latents rel err {e:.3e}; luma max diff {fd.max()} (>1: {(fd > 1).mean():.4f}); rgb max diff {rd.max()}")
     assert out["features"].shape == (2, N, 64, 64)
-    assert e < 2e-2 and (fd > 1).mean() < 0.01 and (rd > 1).mean() < 0.01
+    assert e <= 1e-3 and fd.max() <= 1 and rd.max() <= 1
     # luma of the last pass must be the integer luma of the last-pass rgb, bit exact
     assert np.array_equal(out["features"][:, -1].cpu().numpy(), noise_post.luma_u8(out["rgb"].cpu().numpy()))
 
@@ -247,7 +250,7 @@ def test_vae_accepts_deprecated_attention_names(tiny):
 def test_sd15_width_unet_and_vae_against_oracle():
     """Full SD-v1.5 widths (859.5 M / 83.7 M params, synthetic weights), B=1, 256x256 patch (32x32 latents)."""
     ucfg, vcfg = configs.SD15_UNET, configs.SD15_VAE
-    usd = weights.synthetic_state_dict(weights.unet_param_shapes(ucfg), 42)
+    usd = weights.synthetic_state_dict(weights.unet_param_shapes(ucfg), 42, fp16_values=True)
     g = torch.Generator().manual_seed(2)
     x = torch.randn((1, 4, 32, 32), generator=g)
     ctx = torch.randn((1, 6, 768), generator=g) * 0.5
@@ -256,7 +259,7 @@ def test_sd15_width_unet_and_vae_against_oracle():
     ref = op.OracleUNet(usd, ucfg)(x, 501, ctx).sample
     e_u = rel_err(out, ref)
     del unet, usd
-    vsd = weights.synthetic_state_dict(weights.vae_param_shapes(vcfg), 43)
+    vsd = weights.synthetic_state_dict(weights.vae_param_shapes(vcfg), 43, fp16_values=True)
     vae = AutoencoderKL(vcfg, vsd, DEV)
     img = torch.rand((1, 3, 256, 256), generator=g)
     ovae = op.OracleVAE(vsd, vcfg)
@@ -264,7 +267,88 @@ def test_sd15_width_unet_and_vae_against_oracle():
     z = torch.randn((1, 4, 32, 32), generator=g)
     e_d = rel_err(vae.decode(z.to(DEV)).sample, ovae.decode(z).sample)
     print(f"SD15 widths: unet rel err {e_u:.3e}, vae encode {e_e:.3e}, vae decode {e_d:.3e}")
-    assert e_u < 1e-2 and e_e < 1e-2 and e_d < 1e-2
+    assert e_u <= 1e-3 and e_e <= 3e-4 and e_d <= 3e-3
+
+
+@pytest.mark.timeout(2400)
+def test_config1_sd15_width_512_five_passes_against_oracle():
+    """BASELINE.json configs[1] at its real size: SD-v1.5-width UNet + VAE (fp16 checkpoint values), 512x512 patches, the 5-pass
+    PLMS sampler, against the fp32 CPU oracle (~20-60 s per patch on the box's cores).
+    North-star tolerance: latents within 1e-3 of the reference, as max|diff| / max|ref| over the final latents (the latent
+    range; values reach ~10-20 after five passes), asserted for every pass; identical arg-max masks of a 6-class probe over the
+    per-pixel latent vectors are reported (uint8 luma features can flip a rounding boundary under ANY float error)."""
+    ucfg, vcfg = configs.SD15_UNET, configs.SD15_VAE
+    usd = weights.synthetic_state_dict(weights.unet_param_shapes(ucfg), 42, fp16_values=True)
+    vsd = weights.synthetic_state_dict(weights.vae_param_shapes(vcfg), 43, fp16_values=True)
+    g = torch.Generator().manual_seed(1234)
+    B, N = 2, 5
+    x = torch.rand((B, 3, 512, 512), generator=g)
+    ctx = torch.randn((1, 6, 768), generator=g) * 0.5
+    pipe = StableDiffusionImg2ImgPipeline(AutoencoderKL(vcfg, vsd, DEV), UNet2DConditionModel(ucfg, usd, DEV))
+    out = LaplaceSampler(pipe).sample(x.to(DEV), ctx.to(DEV), N)
+    torch.cuda.synchronize()
+    # the same loop step by step on the shims, to get the per-pass latents
+    lat_dev = []
+    latents = pipe.vae.encode(x.to(DEV)).latent_dist.mean
+    z0_dev = latents.clone()
+    pipe.scheduler.set_timesteps(N - 1, device=DEV)
+    for t in pipe.scheduler.timesteps:
+        latents = pipe.scheduler.step(pipe.unet(latents, t, ctx.to(DEV))[0], t, latents).prev_sample
+        lat_dev.append(latents.clone())
+    assert (out["latents"] - lat_dev[-1]).abs().max() <= 1e-5 * lat_dev[-1].abs().max()
+    torch.set_num_threads(max(1, min(32, len(__import__("os").sched_getaffinity(0)))))
+    opipe = op.OraclePipeline(op.OracleUNet(usd, ucfg), op.OracleVAE(vsd, vcfg))
+    z0_ref = opipe.vae.encode(x).latent_dist.mean
+    ref = op.sample_v6(opipe, x, ctx, N)
+    e_enc = rel_err(z0_dev, z0_ref)
+    errs = [rel_err(a, b) for a, b in zip(lat_dev, ref["latents"])]
+    fd = np.abs(out["features"].cpu().numpy().astype(int) - ref["features"].astype(int))
+    W, bias = _probe_head(6, N, 5)
+    lg = torch.einsum("cn,bnhw->bchw", W.to(DEV), out["features"].float()) + bias.to(DEV)[None, :, None, None]
+    mask = argmax_mask(lg).cpu().numpy()
+    rlg = torch.einsum("cn,bnhw->bchw", W, torch.from_numpy(ref["features"]).float()) + bias[None, :, None, None]
+    rmask = np.asarray(noise_post.argmax_mask(rlg))
+    agree = (mask == rmask).mean()
+    print(f"configs[1] SD15 width 512^2 x {N} passes, B={B}: encode rel err {e_enc:.3e}; latents per pass {[f'{e:.2e}' for e in errs]}; "
+          f"luma max diff {fd.max()} (!=0: {(fd > 0).mean():.4f}, >1: {(fd > 1).mean():.6f}); mask agreement {agree:.5f}")
+    assert e_enc <= 1e-3 and max(errs) <= 1e-3, "north-star tolerance: latents within 1e-3 of the reference (relative to the latent range)"
+    assert fd.max() <= 1 and agree >= 0.9999
+    # the decoder's storage policy does not touch the latents; what it buys in the uint8 features, for the record
+    for dmode in (0, 2):
+        pipe.vae.set_precision(2, dmode)
+        f2 = LaplaceSampler(pipe).sample(x.to(DEV), ctx.to(DEV), N)["features"]
+        d2 = np.abs(f2.cpu().numpy().astype(int) - ref["features"].astype(int))
+        m2 = argmax_mask(torch.einsum("cn,bnhw->bchw", W.to(DEV), f2.float()) + bias.to(DEV)[None, :, None, None]).cpu().numpy()
+        print(f"  decoder precision {dmode}: luma max diff {d2.max()} (!=0: {(d2 > 0).mean():.4f}); mask agreement {(m2 == rmask).mean():.5f}")
+
+
+def test_precision_modes_tiny(tiny):
+    """ldiff_*_set_precision: 0 = all-fp16 storage (round-1 behaviour), 1 = split residual stream, 2 = every operand split.
+    The error against the fp32 oracle must fall with the mode; the default (UNet 1, encoder 2, decoder 1) meets 1e-3."""
+    g = torch.Generator().manual_seed(40)
+    x = torch.randn((2, 4, 32, 32), generator=g)
+    ctx = torch.randn((1, 6, 64), generator=g) * 0.5
+    img = torch.rand((2, 3, 128, 128), generator=g)
+    z = torch.randn((2, 4, 16, 16), generator=g) * 0.5
+    ref_u = tiny["opipe"].unet(x, 501, ctx).sample
+    ref_e = tiny["opipe"].vae.encode(img).latent_dist.mean
+    ref_d = tiny["opipe"].vae.decode(z).sample
+    eu, ee, ed = [], [], []
+    try:
+        for mode in (0, 1, 2):
+            tiny["unet"].set_precision(mode)
+            tiny["vae"].set_precision(mode, mode)
+            eu.append(rel_err(tiny["unet"](x.to(DEV), 501, ctx.to(DEV)).sample, ref_u))
+            ee.append(rel_err(tiny["vae"].encode(img.to(DEV)).latent_dist.mean, ref_e))
+            ed.append(rel_err(tiny["vae"].decode(z.to(DEV)).sample, ref_d))
+    finally:
+        tiny["unet"].set_precision(1)
+        tiny["vae"].set_precision(2, 1)
+    print(f"precision modes 0/1/2: unet {[f'{e:.2e}' for e in eu]}  vae encode {[f'{e:.2e}' for e in ee]}  vae decode {[f'{e:.2e}' for e in ed]}")
+    assert eu[1] < eu[0] and eu[2] < eu[1] and ee[2] < ee[0] and ed[2] < ed[0]
+    assert eu[1] <= 1e-3 and ee[2] <= 3e-4 and eu[2] <= 5e-4
+    with pytest.raises(ValueError):
+        tiny["unet"].set_precision(3)
 
 
 def _probe_head(num_classes, n_feat, seed):
@@ -308,7 +392,7 @@ def test_config4_tiled_roi_20_passes_6_classes(tiny, step):
     print(f"config4 step={step}: {tiles.shape[0]} tiles x {N} passes; latents rel err {e:.3e}; luma max diff {fd.max()} (>1: {(fd > 1).mean():.4f}); "
           f"mask agreement {agree:.4f}")
     assert mask.shape == (128, 128) and mask.max() < C
-    assert e < 3e-2 and (fd > 2).mean() < 0.01 and agree > 0.97
+    assert e <= 1e-3 and fd.max() <= 1 and agree > 0.995   # 20 passes of uint8 features: a luma off by one can move an arg-max
     if step == 1.0:   # non-overlapping: the merged mask is the tile masks side by side
         tm = argmax_mask(logits)
         assert torch.equal(tiling.merge_tile_masks(tm, origins, (128, 128)).cpu(), torch.from_numpy(mask))
@@ -344,7 +428,7 @@ def test_one_pass_1024_roi_against_oracle(tiny):
     rd = np.abs(out["rgb"].cpu().numpy().astype(int) - ref["rgb_u8"].astype(int))
     print(f"1024^2 one pass: latents rel err {e:.3e}; rgb max diff {rd.max()} (>1: {(rd > 1).mean():.5f})")
     assert out["rgb"].shape == (1, 1024, 1024, 3) or out["rgb"].shape[1:3] == (1024, 1024)
-    assert e < 2e-2 and (rd > 1).mean() < 0.01
+    assert e <= 1e-3 and rd.max() <= 1
 
 
 def test_decode_side_stream_changes_nothing(tiny):
@@ -413,7 +497,7 @@ def test_sampler_non_square_padded_prompt_per_sample_context(tiny):
     e = rel_err(out["latents"], ref["latents"][-1])
     fd = np.abs(out["features"].cpu().numpy().astype(int) - ref["features"].astype(int))
     print(f"sampler 64x192, L=77, per-sample ctx: latents rel err {e:.3e}; luma max diff {fd.max()} (>1: {(fd > 1).mean():.4f})")
-    assert out["features"].shape == (3, 4, 64, 192) and e < 2e-2 and (fd > 1).mean() < 0.01
+    assert out["features"].shape == (3, 4, 64, 192) and e <= 1e-3 and fd.max() <= 1
 
 
 def test_bilinear_resize_matches_torch():
@@ -445,9 +529,9 @@ def test_training_time_features_v5_against_oracle(tiny):
     ref = op.laplace_features_v5(tiny["opipe"], x, ctx, n_sched, u_list, out_hw=64)
     eg, er = rel_err(got["gray"], ref["gray"]), rel_err(got["rgb"], ref["rgb"])
     print(f"V5 features: {nts} planes, gray rel err {eg:.3e}, last rgb rel err {er:.3e}")
-    # the UNet output is decoded WITHOUT the 1/scaling_factor (ldiffusion.py:240): the decoder sees inputs ~5x larger than in the
-    # sampler and its fp16 storage error grows with them: 2e-2 of the range here (measured 7e-3 / 1e-2)
-    assert got["gray"].shape == (2, nts, 64, 64) and eg < 2e-2 and er < 2e-2
+    # the decoded image of the raw UNet output (no 1/scaling_factor, ldiffusion.py:240) through the decoder: image-range error
+    # (measured 2.5e-3 / 3.1e-3 of the range)
+    assert got["gray"].shape == (2, nts, 64, 64) and eg <= 5e-3 and er <= 5e-3
 
 
 def _fixture_context(z):
@@ -471,7 +555,7 @@ def test_segmentor_mirror_augment_against_reference_fixture(tiny):
     pooled = torch.nn.functional.avg_pool2d(out, 64).cpu().numpy()
     d = np.abs(pooled - z["pooled"]).max()
     print(f"segmentor mirror vs reference fixture: max |pooled diff| = {d:.2e}")
-    assert d < 6e-3                                            # <= ~1.5 grey levels after fp16 storage
+    assert d < 4e-3                                            # mean of a 64x64 block of uint8/255 pixels, each <= 1 grey level off
     # F12: the text-align wrapper substitutes its cached embeddings when the caller passes None or a wrong width
     wrapped = TextAlignedUNet(tiny["unet"], ctx)
     x = torch.randn((2, 4, 8, 8), generator=torch.Generator().manual_seed(1)).to(DEV)
@@ -517,7 +601,7 @@ def test_segmentor_mirror_inference_cell_model_end_to_end(tiny, tmp_path):
     rmask = np.array(Image.fromarray(np.asarray(noise_post.argmax_mask(logits)[0]).astype(np.uint8)).resize((80, 96), resample=Image.NEAREST))
     agree = (mask == rmask).mean()
     print(f"inference_cell_model mirror: mask agreement with the oracle {agree:.4f}")
-    assert agree > 0.97
+    assert agree > 0.995
 
 
 def test_orchestrator_mirror_errors(tmp_path):

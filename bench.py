@@ -240,18 +240,25 @@ def main():
     assert masks.shape[0] == total and masks.dtype == torch.uint8
 
     # ---- UNet step alone (the metric's second half: UNet-step HBM GB/s vs peak), HIP events on the launch stream ----
-    unet_ms = None
+    unet_ms = unet_eager_ms = None
     if not args.no_unet_step:
         lat = torch.randn((PATCHES_PER_GPU, 4, img // 8, img // 8), device=dev)
-        pipe.unet(lat, 501, ctx)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        reps = 5
-        e0.record()
-        for _ in range(reps):
-            pipe.unet(lat, 501, ctx)   # launched on torch's current stream, the same one the events are recorded on
-        e1.record()
-        torch.cuda.synchronize()
-        unet_ms = e0.elapsed_time(e1) / reps
+
+        def time_unet(reps=5):
+            for _ in range(3):
+                pipe.unet(lat, 501, ctx)       # eager, capture, first replay
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                pipe.unet(lat, 501, ctx)   # launched on torch's current stream, the same one the events are recorded on
+            e1.record()
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1) / reps
+
+        unet_ms = time_unet()                  # product default: hipGraph replay of the ~900 launches
+        pipe.unet.set_graph(False)
+        unet_eager_ms = time_unet()
+        pipe.unet.set_graph(True)
 
     if rank != 0:
         if dist is not None:
@@ -294,7 +301,8 @@ def main():
         uf = PATCHES_PER_GPU * UNET_FLOP_PER_SAMPLE
         result["unet_step"] = {"ms": unet_ms, "batch": PATCHES_PER_GPU,
                                "hbm_GBps": ub / (unet_ms * 1e-3) / 1e9, "hbm_frac": ub / (unet_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-                               "tflops": uf / (unet_ms * 1e-3) / 1e12, "mfma_frac": uf / (unet_ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS}
+                               "tflops": uf / (unet_ms * 1e-3) / 1e12, "mfma_frac": uf / (unet_ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS,
+                               "ms_eager_launches": unet_eager_ms, "launch": "hipGraph replay (ms) vs the same kernels launched one by one (ms_eager_launches)"}
     if world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(ucfg, vcfg, usd, vsd, img, N_PASSES)
     print(json.dumps(result), flush=True)

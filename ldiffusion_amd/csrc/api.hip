@@ -53,6 +53,15 @@ int ldiff_unet_set_precision(ldiff_unet* u, int mode) {
   u->precision = mode;
   API_END
 }
+int ldiff_unet_set_graph(ldiff_unet* u, int on) {
+  API_BEGIN
+  LDIFF_CHECK(u, LDIFF_ERR_INVALID, "unet_set_graph: null handle");
+  HIP_CHECK(hipSetDevice(u->device));
+  if (!on) { HIP_CHECK(hipDeviceSynchronize()); u->gc.drop(); }
+  u->gc.enabled = on != 0;
+  API_END
+}
+int64_t ldiff_unet_graph_replays(ldiff_unet* u) { return u ? (int64_t)u->gc.replays : -1; }
 int ldiff_unet_missing(ldiff_unet* u) { return u ? u->ws.missing() : -1; }
 const char* ldiff_unet_missing_name(ldiff_unet* u, int i) { return u ? u->ws.missing_name(i) : ""; }
 int ldiff_unet_set_context(ldiff_unet* u, const void* ctx_dev, int B_ctx, int L, void* stream) {
@@ -64,7 +73,6 @@ int ldiff_unet_set_context(ldiff_unet* u, const void* ctx_dev, int B_ctx, int L,
 int ldiff_unet_forward(ldiff_unet* u, const void* sample_dev, int B, int h, int w, float timestep, void* out_dev, void* stream) {
   API_BEGIN
   LDIFF_CHECK(u, LDIFF_ERR_INVALID, "unet_forward: null handle");
-  u->ex.arena.reset();
   u->forward((const float*)sample_dev, B, h, w, timestep, (float*)out_dev, (hipStream_t)stream);
   API_END
 }
@@ -280,7 +288,6 @@ int ldiff_sample(ldiff_pipeline* p, const void* images, int B, int H, int W, int
   int n_ets = 0, counter = 0;  // ets[0] is the oldest kept entry
   for (int i = 0; i < nts; ++i) {
     int t = (int)ts[i];
-    u->ex.arena.reset();
     u->forward(z, B, h, w, (float)t, eps_new, s);
     // ---- PNDMScheduler.step_plms ----
     int prev_t = t - ratio;

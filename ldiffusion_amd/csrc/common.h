@@ -128,7 +128,10 @@ void ensure_dyn_smem(const void* kernel, int bytes);
 void launch_nchw_f32_to_nhwc_f16(const float* x, f16* y, int B, int C, int H, int W, int Cpad, hipStream_t s, int lo_off = 0);
 void launch_nhwc_f32_to_nchw_f32(const float* x, float* y, int B, int C, int H, int W, int ldx, hipStream_t s);
 void launch_geglu(const f16* x, f16* y, long long M, int C4, hipStream_t s);  // x [M, 2*C4] -> y [M, C4]
-void launch_timestep_embed(float t, f16* y, int B, int dim, int flip_sin_to_cos, float freq_shift, hipStream_t s);
+void launch_timestep_embed(float t, const float* t_dev /* overrides t when not null */, f16* y, int B, int dim, int flip_sin_to_cos, float freq_shift,
+                           hipStream_t s);
+void launch_set_scalar(float* p, float v, hipStream_t s);
+bool prof_enabled();   // any per-launch profiling active (graph replay would hide the launches from it)
 void launch_silu_f32_to_f16(const float* x, f16* y, long long n, hipStream_t s);
 void launch_lincomb(const float* coef, const void* const* ops, int nops, float* out, long long n, hipStream_t s);
 void launch_laplace_add(const float* z0, float scale, const float* u, unsigned long long seed, unsigned long long offset,

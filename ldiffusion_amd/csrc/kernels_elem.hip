@@ -97,10 +97,11 @@ void launch_geglu(const f16* x, f16* y, long long M, int C4, hipStream_t s) {
 }
 
 // ---- sinusoidal timestep embedding (diffusers get_timestep_embedding) ------------------
-__global__ void timestep_embed_kernel(float tval, f16* __restrict__ y, int B, int dim, int flip, float freq_shift) {
+__global__ void timestep_embed_kernel(float tval, const float* __restrict__ t_dev, f16* __restrict__ y, int B, int dim, int flip, float freq_shift) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   const int half = dim / 2;
   if (i >= B * half) return;
+  if (t_dev) tval = *t_dev;   // timestep from device memory: lets a captured graph of the forward be replayed for any t
   int b = i / half, k = i - b * half;
   float exponent = (-9.210340371976184f * (float)k) / ((float)half - freq_shift);  // -ln(10000) * k / (half - shift)
   float arg = tval * expf(exponent);
@@ -109,8 +110,13 @@ __global__ void timestep_embed_kernel(float tval, f16* __restrict__ y, int B, in
   if (flip) { row[k] = (f16)cs; row[half + k] = (f16)sn; }
   else { row[k] = (f16)sn; row[half + k] = (f16)cs; }
 }
-void launch_timestep_embed(float t, f16* y, int B, int dim, int flip, float freq_shift, hipStream_t s) {
-  hipLaunchKernelGGL(timestep_embed_kernel, dim3(nblocks((long long)B * dim / 2)), dim3(256), 0, s, t, y, B, dim, flip, freq_shift);
+void launch_timestep_embed(float t, const float* t_dev, f16* y, int B, int dim, int flip, float freq_shift, hipStream_t s) {
+  hipLaunchKernelGGL(timestep_embed_kernel, dim3(nblocks((long long)B * dim / 2)), dim3(256), 0, s, t, t_dev, y, B, dim, flip, freq_shift);
+  HIP_CHECK(hipGetLastError());
+}
+__global__ void set_scalar_kernel(float* p, float v) { *p = v; }
+void launch_set_scalar(float* p, float v, hipStream_t s) {
+  hipLaunchKernelGGL(set_scalar_kernel, dim3(1), dim3(1), 0, s, p, v);
   HIP_CHECK(hipGetLastError());
 }
 

@@ -121,27 +121,24 @@ __global__ __launch_bounds__(256) void gn_finalize2_kernel(const float* __restri
                                                            int groups, int HW, float eps, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, float* __restrict__ scale, float* __restrict__ shift) {
   const int grp = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
-  const int C = C1 + C2, Cg = C / groups, c0 = grp * Cg;
+  const int C = C1 + C2, Cg = C / groups, c0 = grp * Cg, c1 = c0 + Cg;
+  // the partials of the group's channels are (up to) two contiguous runs of float2: channels [c0, min(c1, C1)) of part 1 and
+  // [max(c0, C1), c1) of part 2.  All loads of a run are independent (a per-channel loop would chain Cg memory round trips:
+  // 10-60 of them on the UNet levels, where R is small and most threads idle).
   double a = 0.0, q = 0.0;
-  for (int cc = 0; cc < Cg; ++cc) {
-    const int c = c0 + cc;
-    const bool second = c >= C1;
-    const int R = second ? R2 : R1;
-    const float2* base = reinterpret_cast<const float2*>(second ? p2 + ((long long)b * C2 + (c - C1)) * R2 * 2 : p1 + ((long long)b * C1 + c) * R1 * 2);
-    // R is 2048-4096 on the 512^2 VAE layers: four 16-byte loads (two partials each) in flight per thread instead of a chain of
-    // dependent 8-byte ones; the short tail (and odd R) goes one partial at a time
-    const int R2f = (R & 1) ? 0 : R / 2;   // number of float4 (= 2 partials); rows are 8-byte aligned, 16-byte when R is even
-    const float4* b4 = reinterpret_cast<const float4*>(base);
-    int r = tid;
-    for (; r + 768 < R2f; r += 1024) {
-      const float4 v0 = b4[r], v1 = b4[r + 256], v2 = b4[r + 512], v3 = b4[r + 768];
-      a += (double)((v0.x + v0.z) + (v1.x + v1.z)) + (double)((v2.x + v2.z) + (v3.x + v3.z));
-      q += (double)((v0.y + v0.w) + (v1.y + v1.w)) + (double)((v2.y + v2.w) + (v3.y + v3.w));
+  auto sum_run = [&](const float2* base, long long n) {   // n float2 elements, 8-byte aligned
+    long long i = tid;
+    for (; i + 768 < n; i += 1024) {
+      const float2 v0 = base[i], v1 = base[i + 256], v2 = base[i + 512], v3 = base[i + 768];
+      a += (double)((v0.x + v1.x) + (v2.x + v3.x));
+      q += (double)((v0.y + v1.y) + (v2.y + v3.y));
     }
-    for (; r < R2f; r += 256) { const float4 v = b4[r]; a += (double)v.x + (double)v.z; q += (double)v.y + (double)v.w; }
-    if (R2f == 0)
-      for (int r1 = tid; r1 < R; r1 += 256) { const float2 v = base[r1]; a += (double)v.x; q += (double)v.y; }
-  }
+    for (; i < n; i += 256) { const float2 v = base[i]; a += (double)v.x; q += (double)v.y; }
+  };
+  const int e1 = c1 < C1 ? c1 : C1;
+  if (c0 < e1) sum_run(reinterpret_cast<const float2*>(p1 + ((long long)b * C1 + c0) * R1 * 2), (long long)(e1 - c0) * R1);
+  const int s2 = c0 > C1 ? c0 : C1;
+  if (s2 < c1) sum_run(reinterpret_cast<const float2*>(p2 + ((long long)b * C2 + (s2 - C1)) * R2 * 2), (long long)(c1 - s2) * R2);
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o); q += __shfl_xor(q, o); }
   __shared__ double red[2][4];

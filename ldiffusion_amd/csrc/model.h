@@ -152,11 +152,28 @@ struct ldiff_unet {
   ResnetW mid_res[2];
   TransformerW mid_attn;
   std::vector<TransformerW*> all_tf;
-  int ctx_B = 0, ctx_L = 0;
+  int ctx_B = 0, ctx_L = 0, ctx_gen = 0;
   f16* ctx_buf = nullptr; size_t ctx_cap = 0;     // all kv_ctx live in one allocation
   void build();
   void set_context(const float* ctx, int Bc, int L, hipStream_t s);
+  // forward = the ~900 launches of one pass.  With graphs on (default) the launch sequence of a (B, h, w, precision, context)
+  // configuration is captured into a hipGraph on its second use and replayed afterwards: input, timestep and output go through
+  // handle-owned staging buffers, so the replay is valid for any caller pointers and any timestep.
   void forward(const float* x, int B, int h, int w, float t, float* out, hipStream_t s);
+  void forward_impl(const float* x, int B, int h, int w, float t, const float* t_dev, float* out, hipStream_t s);
+  struct GraphCache {
+    bool enabled = true;
+    int uses = 0;                       // forwards seen with the current key (0: none, 1: ran eagerly once, >= 2: graph ready)
+    long long key[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    hipStream_t cap_stream = nullptr;
+    float *in = nullptr, *out = nullptr, *t = nullptr;
+    size_t in_cap = 0;
+    long long replays = 0, captures = 0;
+    void drop();
+  } gc;
+  ~ldiff_unet();
   Act transformer(const TransformerW& t, const Act& x);
 };
 

@@ -600,6 +600,7 @@ void ldiff_unet::set_context(const float* ctx, int Bc, int L, hipStream_t s) {
   }
   ex.release(c16);
   ctx_B = Bc; ctx_L = L;
+  ++ctx_gen;   // the K/V buffer may have moved: a captured forward graph holds its old address
 }
 
 Act ldiff_unet::transformer(const TransformerW& t, const Act& x) {
@@ -674,7 +675,73 @@ Act ldiff_unet::transformer(const TransformerW& t, const Act& x) {
   return out;
 }
 
+void ldiff_unet::GraphCache::drop() {
+  if (exec) (void)hipGraphExecDestroy(exec);
+  if (graph) (void)hipGraphDestroy(graph);
+  exec = nullptr; graph = nullptr; uses = 0;
+}
+ldiff_unet::~ldiff_unet() {
+  gc.drop();
+  if (gc.in) (void)hipFree(gc.in);
+  if (gc.out) (void)hipFree(gc.out);
+  if (gc.t) (void)hipFree(gc.t);
+  if (gc.cap_stream) (void)hipStreamDestroy(gc.cap_stream);
+}
+
 void ldiff_unet::forward(const float* x, int B, int h, int w, float tval, float* out, hipStream_t s) {
+  static const bool env_off = getenv("LDIFF_NO_GRAPH") != nullptr;
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (s) (void)hipStreamIsCapturing(s, &cs);   // the legacy default stream cannot be captured
+  if (!gc.enabled || env_off || prof_enabled() || cs != hipStreamCaptureStatusNone || !x || !out || B < 1 || h < 1 || w < 1) {
+    forward_impl(x, B, h, w, tval, nullptr, out, s);   // (argument errors are reported by forward_impl)
+    return;
+  }
+  HIP_CHECK(hipSetDevice(device));
+  const size_t n_in = (size_t)B * cfg.in_channels * h * w, n_out = (size_t)B * cfg.out_channels * h * w;
+  const long long key[8] = {B, h, w, precision, (long long)ctx_B * 65536 + ctx_L, ws.generation, ctx_gen, (long long)ex.arena.capacity()};
+  if (memcmp(key, gc.key, sizeof(key)) != 0) { gc.drop(); memcpy(gc.key, key, sizeof(key)); }
+  if (gc.uses == 0) {               // first use of this configuration: eager (builds lazily derived weights, sizes the workspaces)
+    forward_impl(x, B, h, w, tval, nullptr, out, s);
+    gc.uses = 1;
+    return;
+  }
+  if (gc.uses == 1) {               // second use: capture the same launch sequence on staging buffers
+    const size_t need = std::max(n_in, n_out) * sizeof(float);
+    if (need > gc.in_cap) {
+      if (gc.in) { HIP_CHECK(hipDeviceSynchronize()); HIP_CHECK(hipFree(gc.in)); HIP_CHECK(hipFree(gc.out)); gc.in = gc.out = nullptr; }
+      HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&gc.in), need));
+      HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&gc.out), need));
+      gc.in_cap = need;
+    }
+    if (!gc.t) HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&gc.t), sizeof(float)));
+    // capture on a handle-owned stream (the caller's may be the legacy default stream, which cannot be captured); nothing
+    // executes during capture, and the instantiated graph is launched on the caller's stream
+    if (!gc.cap_stream) HIP_CHECK(hipStreamCreateWithFlags(&gc.cap_stream, hipStreamNonBlocking));
+    HIP_CHECK(hipStreamBeginCapture(gc.cap_stream, hipStreamCaptureModeThreadLocal));
+    hipGraph_t g = nullptr;
+    try {
+      forward_impl(gc.in, B, h, w, 0.f, gc.t, gc.out, gc.cap_stream);
+    } catch (...) {
+      (void)hipStreamEndCapture(gc.cap_stream, &g);
+      if (g) (void)hipGraphDestroy(g);
+      gc.enabled = false;           // this configuration cannot be captured: stay eager (same kernels, same results)
+      forward_impl(x, B, h, w, tval, nullptr, out, s);
+      return;
+    }
+    HIP_CHECK(hipStreamEndCapture(gc.cap_stream, &g));
+    gc.graph = g;
+    HIP_CHECK(hipGraphInstantiate(&gc.exec, g, nullptr, nullptr, 0));
+    gc.uses = 2;
+    ++gc.captures;
+  }
+  HIP_CHECK(hipMemcpyAsync(gc.in, x, n_in * sizeof(float), hipMemcpyDeviceToDevice, s));
+  launch_set_scalar(gc.t, tval, s);
+  HIP_CHECK(hipGraphLaunch(gc.exec, s));
+  HIP_CHECK(hipMemcpyAsync(out, gc.out, n_out * sizeof(float), hipMemcpyDeviceToDevice, s));
+  ++gc.replays;
+}
+
+void ldiff_unet::forward_impl(const float* x, int B, int h, int w, float tval, const float* t_dev, float* out, hipStream_t s) {
   LDIFF_CHECK(x && out && B >= 1 && h >= 1 && w >= 1, LDIFF_ERR_INVALID, "unet_forward: bad arguments (B=%d h=%d w=%d)", B, h, w);
   const int nb = cfg.n_blocks;
   LDIFF_CHECK(h % (1 << (nb - 1)) == 0 && w % (1 << (nb - 1)) == 0, LDIFF_ERR_INVALID, "unet_forward: latent size %dx%d must be divisible by %d", h, w, 1 << (nb - 1));
@@ -683,6 +750,7 @@ void ldiff_unet::forward(const float* x, int B, int h, int w, float tval, float*
   LDIFF_CHECK(ctx_B == 1 || ctx_B == B, LDIFF_ERR_INVALID, "unet: context batch %d does not match sample batch %d", ctx_B, B);
   HIP_CHECK(hipSetDevice(device));
   ex.s = s;
+  ex.arena.reset();
   const int C0 = cfg.block_out_channels[0];
   int Cmax = 0;
   for (int i = 0; i < nb; ++i) Cmax = std::max(Cmax, cfg.block_out_channels[i]);
@@ -692,7 +760,7 @@ void ldiff_unet::forward(const float* x, int B, int h, int w, float tval, float*
   // time embedding: sinusoid -> linear_1 -> SiLU -> linear_2, then SiLU once and all 22 per-resnet projections in one GEMM
   const int td = C0 * 4;
   Act e16 = ex.new_act(1, 1, B, C0);
-  launch_timestep_embed(tval, e16.p, B, C0, cfg.flip_sin_to_cos, cfg.freq_shift, s);
+  launch_timestep_embed(tval, t_dev, e16.p, B, C0, cfg.flip_sin_to_cos, cfg.freq_shift, s);
   float* l1 = ex.tmp<float>((size_t)B * td);
   { ConvOpts o; o.out_f32 = l1; o.ldy_f32 = td; ex.conv(t_lin1, e16, nullptr, o); }
   Act l1h = ex.new_act(1, 1, B, td);

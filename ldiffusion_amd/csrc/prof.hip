@@ -18,6 +18,7 @@ hipEvent_t get_event() {
 }
 }  // namespace
 
+bool prof_enabled() { return g_on && g_filter.empty(); }   // a filtered profile leaves the UNet forward on its graph (those launches are not bracketed)
 bool prof_on(const char* name) { return g_on && (g_filter.empty() || g_filter == name); }
 void prof_begin(const char* name, double flops, double bytes, hipStream_t s) {
   Rec r;

@@ -82,6 +82,15 @@ class UNet2DConditionModel:
         _lib.check(self._lib.ldiff_unet_set_precision(self._h, int(mode)))
         return self
 
+    def set_graph(self, on: bool):
+        """hipGraph replay of the forward's launch sequence (default on; include/ldiff.h ldiff_unet_set_graph)."""
+        _lib.check(self._lib.ldiff_unet_set_graph(self._h, int(bool(on))))
+        return self
+
+    @property
+    def graph_replays(self) -> int:
+        return int(self._lib.ldiff_unet_graph_replays(self._h))
+
     # ---- checkpoint surface ----
     def load_state_dict(self, sd, strict=True):
         _load_state_dict(self._lib, self._lib.ldiff_unet_load, self._h, sd, weights.unet_param_shapes(self._cfg))

@@ -322,6 +322,35 @@ def test_config1_sd15_width_512_five_passes_against_oracle():
         print(f"  decoder precision {dmode}: luma max diff {d2.max()} (!=0: {(d2 > 0).mean():.4f}); mask agreement {(m2 == rmask).mean():.5f}")
 
 
+def test_unet_graph_replay_equals_eager(tiny):
+    """The forward is captured into a hipGraph on its second use with a given (B, h, w, context): replays must equal the eager
+    launches bit for bit for any timestep and any caller buffers, and a new context / shape / checkpoint must not replay stale state."""
+    g = torch.Generator().manual_seed(50)
+    unet = tiny["unet"]
+    xs = [torch.randn((2, 4, 16, 16), generator=g).to(DEV) for _ in range(3)]
+    ctx = (torch.randn((1, 6, 64), generator=g) * 0.5).to(DEV)
+    ctx2 = (torch.randn((1, 9, 64), generator=g) * 0.5).to(DEV)
+    unet.set_graph(False)
+    ref = {(i, t, c): unet(xs[i], t, cc).sample.clone() for i in range(3) for t in (751, 1) for c, cc in (("a", ctx), ("b", ctx2))}
+    unet.set_graph(True)
+    r0 = unet.graph_replays
+    for rep in range(2):
+        for c, cc in (("a", ctx), ("b", ctx2)):
+            for i in range(3):
+                for t in (751, 1):
+                    assert torch.equal(unet(xs[i], t, cc).sample, ref[(i, t, c)]), (rep, c, i, t)
+    assert unet.graph_replays - r0 >= 16          # per context: 1 eager + 1 capture(+replay) + replays
+    big = torch.randn((1, 4, 24, 8), generator=g).to(DEV)      # another shape in between drops the cached graph, results unchanged
+    unet(big, 5, ctx)
+    assert torch.equal(unet(xs[0], 751, ctx).sample, ref[(0, 751, "a")])
+    s2 = torch.cuda.Stream()
+    with torch.cuda.stream(s2):                                 # replay on a non-default stream
+        for _ in range(3):
+            o = unet(xs[1], 1, ctx).sample
+    s2.synchronize()
+    assert torch.equal(o, ref[(1, 1, "a")])
+
+
 def test_precision_modes_tiny(tiny):
     """ldiff_*_set_precision: 0 = all-fp16 storage (round-1 behaviour), 1 = split residual stream, 2 = every operand split.
     The error against the fp32 oracle must fall with the mode; the default (UNet 1, encoder 2, decoder 1) meets 1e-3."""

@@ -38,6 +38,7 @@ HBM_PEAK_GBPS = 8000.0      # HBM3E spec, same guide
 UNET_WEIGHT_BYTES = 1.719e9
 UNET_ACT_BYTES_PER_SAMPLE = 1.014e9
 UNET_FLOP_PER_SAMPLE = 797.3e9
+PATCH_FLOP = 17.68e12       # algorithmic flops of one 5-pass 512x512 patch: encode + 5 x (UNet + decode), SURVEY.md 8d
 
 
 def parse():
@@ -66,20 +67,34 @@ def usable_cpus() -> int:
     return max(1, n)
 
 
+def kernel_source_hash() -> str:
+    """sha256 over the HIP sources and headers of the library, first 12 hex digits: names the PMC traffic file a measurement
+    belongs to, so that a profile taken on other kernel code is never quoted."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "ldiffusion_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "ldiffusion_amd", "csrc", "*.h"))
+                    + [os.path.join(ROOT, "include", "ldiff.h")]):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:12]
+
+
 def pmc_traffic(kernel_name):
-    """HBM bytes per launch of `kernel_name` from the committed rocprofv3 PMC passes over this same workload
-    (profiles/r01_pmc_traffic.json: (2*FETCH_SIZE + WRITE_SIZE)*1024, see its _note); None when no profile is committed.
-    PMC counters cannot be read from inside the process, so this is the offline measurement, not a live one."""
+    """HBM bytes per launch of `kernel_name` from the rocprofv3 PMC passes over this same workload, taken on exactly this kernel
+    source (profiles/pmc_traffic_<source hash>.json, written by scripts/final_profiles.sh: (2*FETCH_SIZE + WRITE_SIZE)*1024, see its
+    _note).  None when no profile of the current sources is committed: PMC counters cannot be read from inside the process, so this
+    is the offline measurement, and a stale one is refused rather than quoted."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+        with open(os.path.join(ROOT, "profiles", f"pmc_traffic_{kernel_source_hash()}.json")) as f:
             return json.load(f)["kernels"][kernel_name]["traffic_bytes"]
     except (OSError, KeyError, ValueError):
         return None
 
 
 def cpu_baseline(ucfg, vcfg, usd, vsd, img, n_passes):
-    """Oracle timed on the host: one VAE encode, one UNet pass and one VAE decode of ONE patch, once each after an
-    untimed tiny warm-up; composed as enc + n_passes*(unet+dec) per patch."""
+    """The CPU oracle (oracle/, plain-torch fp32 restatement) TIMED end to end on ONE patch of the bench workload: the whole
+    n_passes sampler (encode, n x [UNet, PLMS step, decode, uint8, luma]) after a small warm-up of the thread pool."""
     from oracle import pipeline as op
     threads = usable_cpus()
     torch.set_num_threads(threads)
@@ -87,19 +102,14 @@ def cpu_baseline(ucfg, vcfg, usd, vsd, img, n_passes):
     g = torch.Generator().manual_seed(1234)
     x = torch.rand((1, 3, img, img), generator=g)
     ctx = torch.randn((1, 6, ucfg["cross_attention_dim"]), generator=g) * 0.5
-    pipe.vae.encode(torch.rand((1, 3, 64, 64)))  # thread-pool / allocator warm-up
+    op.sample_v6(pipe, torch.rand((1, 3, 64, 64)), ctx, 3)  # thread-pool / allocator warm-up at a small size
     t0 = time.perf_counter()
-    z = pipe.vae.encode(x).latent_dist.mean
-    t1 = time.perf_counter()
-    eps = pipe.unet(z, 501, ctx).sample
-    t2 = time.perf_counter()
-    pipe.decode_latents(eps)
-    t3 = time.perf_counter()
-    per_patch = (t1 - t0) + n_passes * ((t2 - t1) + (t3 - t2))
-    return {"value": 1.0 / per_patch, "unit": "patches/sec", "cores": threads, "kind": "port",
-            "sample": f"1 patch {img}x{img}: 1 VAE encode ({t1 - t0:.2f}s) + 1 UNet pass ({t2 - t1:.2f}s) + 1 VAE decode ({t3 - t2:.2f}s) "
-                      f"timed once each, composed as enc + {n_passes}*(unet+dec); plain-torch fp32 restatement (oracle/), "
-                      f"torch {torch.__version__}, {threads} threads -- not diffusers"}
+    op.sample_v6(pipe, x, ctx, n_passes)
+    per_patch = time.perf_counter() - t0
+    return {"value": 1.0 / per_patch, "unit": "patches/sec", "cores": threads, "kind": "port", "how": "timed",
+            "sample": f"1 patch {img}x{img} through the whole {n_passes}-pass sampler (oracle.pipeline.sample_v6), timed end to end once "
+                      f"({per_patch:.1f} s) after a 64x64 warm-up; plain-torch fp32 restatement (oracle/), torch {torch.__version__}, "
+                      f"{threads} threads -- not diffusers"}
 
 
 def self_launch(args) -> int:
@@ -277,12 +287,20 @@ def main():
                                + (", RCCL all-gather of masks" if world > 1 else ""),
                    "patches_per_gpu": PATCHES_PER_GPU, "image": img, "n_passes": N_PASSES, "parallelism": f"dp{world} (patch sharding)"},
     }
+    result["config"]["precision"] = ("split residual stream (fp16 hi|lo), fp16 MFMA operands, fp32 accumulate; UNet mode 1, VAE encoder "
+                                     "mode 2, decoder mode 1 (include/ldiff.h ldiff_unet_set_precision): latents within 1e-3 of the fp32 oracle")
+    if not args.tiny:
+        sf = total * PATCH_FLOP / elapsed * args.steps / 1e12 / world   # algorithmic TFLOP/s per GPU over the whole timed region
+        result["step"] = {"algorithmic_tflops_per_gpu": sf, "mfma_frac": sf / MFMA_PEAK_TFLOPS,
+                          "note": "17.68 TFLOP per patch (SURVEY 8d) x patches / wall time of the timed region: every kernel, launch gap and the "
+                                  "mask tail included; split-operand contractions execute more MFMA flops than this algorithmic count"}
     if rows:
         dom = max(rows, key=lambda r: r["ms"])          # the one kernel profiled inside the timed region
         tot_ms = sum(r["ms"] for r in rows_all)
         ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
         result["roofline"] = {"bound": "mfma", "kernel": dom["name"], "achieved": ach, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                              "frac": ach / MFMA_PEAK_TFLOPS, "traffic": pmc_traffic(dom["name"]),
+                              "frac": ach / MFMA_PEAK_TFLOPS, "traffic": pmc_traffic(dom["name"]), "kernel_source_hash": kernel_source_hash(),
+                              "flops_counted": "executed MFMA flops (2*M*N*K of the launch as run: parity-folded upsampling convs count 16/36 of the 9-tap flops, split-operand convs twice)",
                               "launches": dom["launches"], "avg_launch_us": 1e3 * dom["ms"] / dom["launches"],
                               "algorithmic_GBps": dom["bytes"] / (dom["ms"] * 1e-3) / 1e9,
                               "share_of_profiled_time": next(r["ms"] for r in rows_all if r["name"] == dom["name"]) / tot_ms,

@@ -53,6 +53,29 @@ TINY_UNET = dict(copy.deepcopy(SD15_UNET), block_out_channels=[64, 128, 256, 256
 TINY_VAE = dict(copy.deepcopy(SD15_VAE), block_out_channels=[32, 64, 128, 128])
 
 
+# diffusers' constructor defaults for the fields the sampling path reads: a config.json written by an older diffusers (or a
+# hand-trimmed one) may omit any of them, and `from_pretrained` then fills these in (UNet2DConditionModel.__init__ /
+# AutoencoderKL.__init__ signatures of diffusers 0.34.0 [mem]).
+UNET_DEFAULTS = {
+    "sample_size": None, "in_channels": 4, "out_channels": 4, "center_input_sample": False, "flip_sin_to_cos": True, "freq_shift": 0,
+    "down_block_types": ["CrossAttnDownBlock2D", "CrossAttnDownBlock2D", "CrossAttnDownBlock2D", "DownBlock2D"],
+    "up_block_types": ["UpBlock2D", "CrossAttnUpBlock2D", "CrossAttnUpBlock2D", "CrossAttnUpBlock2D"],
+    "block_out_channels": [320, 640, 1280, 1280], "layers_per_block": 2, "downsample_padding": 1, "act_fn": "silu",
+    "norm_num_groups": 32, "norm_eps": 1e-5, "cross_attention_dim": 1280, "attention_head_dim": 8, "use_linear_projection": False,
+}
+VAE_DEFAULTS = {
+    "in_channels": 3, "out_channels": 3, "down_block_types": ["DownEncoderBlock2D"], "up_block_types": ["UpDecoderBlock2D"],
+    "block_out_channels": [64], "layers_per_block": 1, "act_fn": "silu", "latent_channels": 4, "norm_num_groups": 32, "sample_size": 32,
+    "scaling_factor": 0.18215,
+}
+
+
+def with_defaults(cfg: dict, defaults: dict) -> dict:
+    out = dict(defaults)
+    out.update(cfg)
+    return out
+
+
 def validate_unet_config(cfg: dict) -> None:
     """Reject configs outside what the HIP executor implements (fail loudly, no fallback)."""
     boc = cfg["block_out_channels"]

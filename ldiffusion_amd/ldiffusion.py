@@ -1,6 +1,6 @@
 """Host-side mirror of the reference's orchestrator `LDiffusionModel` (/root/reference/ldiffusion.py:31-324) for the
-sampling path: same constructor and `inference(...)` signature, same error for an invalid level.  Training
-(`train`, `train_ldiffusion`: DeepSpeed ZeRO-3 fine-tuning, ldiffusion.py:121-315) is a "next" row of SURVEY.md 8f and raises.
+sampling path: same constructor and `inference(...)` signature (cell and tissue levels), same error for an invalid level.
+Training (`train`, `train_ldiffusion`: DeepSpeed ZeRO-3 fine-tuning, ldiffusion.py:121-315) is a "next" row of SURVEY.md 8f and raises.
 """
 from __future__ import annotations
 
@@ -39,13 +39,18 @@ class LDiffusionModel:
         raise NotImplementedError("LDiffusionModel.train (ZeRO-3 fine-tuning, ldiffusion.py:121-315) is outside the sampling hot path "
                                   "this build accelerates (SURVEY.md 8f rank 2)")
 
-    def inference(self, image_path, ldiffusion_weight, segmentor_weight, num_classes, head=None, **_readme_kwargs):
-        """ldiffusion.py:317-324.  `head` = the segmentation head callable (out of scope, see segmentor.py); extra README-era
-        keyword arguments (dtm_path, output_path) are accepted and ignored like the code ignores them."""
+    def inference(self, image_path, ldiffusion_weight, segmentor_weight, num_classes, head=None, predictor=None, output_path=None,
+                  text_embeddings=None, **_readme_kwargs):
+        """ldiffusion.py:317-324.  `head` (cell) / `predictor` (tissue) = the segmentation head callable (out of scope, see
+        segmentor.py); `output_path` is the folder-mode argument of the tissue path; other README-era keyword arguments (dtm_path)
+        are accepted and ignored like the code ignores them."""
         segmentor = Segmentor(train_loader=None, val_loader=None, level=self.level, num_classes=num_classes)
         if self.level == "tissue":
-            raise RuntimeError("tissue inference runs the vendored nnU-Net predictor (segmentor.py:388-488), which is outside the hot-path scope")
+            return segmentor.inference_tissue_model_nnUNetv2(image_path, self.diffusion_path, ldiffusion_weight, segmentor_weight,
+                                                             output_path=output_path, predictor=predictor if predictor is not None else head,
+                                                             text_embeddings=text_embeddings)
         elif self.level == "cell":
-            return segmentor.inference_cell_model(image_path, self.diffusion_path, ldiffusion_weight, segmentor_weight, head=head)
+            return segmentor.inference_cell_model(image_path, self.diffusion_path, ldiffusion_weight, segmentor_weight, head=head,
+                                                  text_embeddings=text_embeddings)
         else:
             raise ValueError("Invalid level specified. Choose 'tissue' or 'cell'.")

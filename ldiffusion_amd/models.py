@@ -49,6 +49,7 @@ class _Output:
 class UNet2DConditionModel:
     def __init__(self, cfg: dict, state_dict, device=None):
         _lib.require_gpu()
+        cfg = configs.with_defaults(cfg, configs.UNET_DEFAULTS)   # fields a config.json may omit get diffusers' defaults
         configs.validate_unet_config(cfg)
         self._cfg = dict(cfg)
         self.config = SimpleNamespace(**cfg)
@@ -186,6 +187,7 @@ class _LatentDist:
 class AutoencoderKL:
     def __init__(self, cfg: dict, state_dict, device=None):
         _lib.require_gpu()
+        cfg = configs.with_defaults(cfg, configs.VAE_DEFAULTS)    # e.g. `scaling_factor` (decode_latents reads vae.config.scaling_factor)
         configs.validate_vae_config(cfg)
         self._cfg = dict(cfg)
         self.config = SimpleNamespace(**cfg)
@@ -200,7 +202,7 @@ class AutoencoderKL:
             c.block_out_channels[i] = v
         c.layers_per_block = cfg["layers_per_block"]
         c.norm_num_groups = cfg["norm_num_groups"]
-        c.scaling_factor = cfg.get("scaling_factor", 0.18215)
+        c.scaling_factor = cfg["scaling_factor"]
         self._h = C.c_void_p()
         _lib.check(self._lib.ldiff_vae_create(C.byref(self._h), C.byref(c), self.device.index or 0))
         sd = weights.normalize_vae_keys(state_dict)

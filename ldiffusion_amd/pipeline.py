@@ -78,6 +78,7 @@ class LaplaceSampler:
         _lib.check(self._lib.ldiff_pipeline_create(C.byref(self._h), pipeline.unet._h, pipeline.vae._h))
         abar = pipeline.scheduler.alphas_cumprod.detach().to("cpu", torch.float32).contiguous()
         _lib.check(self._lib.ldiff_pipeline_set_alphas_cumprod(self._h, C.cast(abar.data_ptr(), C.POINTER(C.c_float)), abar.numel()))
+        self._pending = None
 
     def set_overlap(self, mode):
         """0 / False: everything on the current stream; 1 / True (default): VAE decode of pass k on a side stream beside the UNet
@@ -88,6 +89,7 @@ class LaplaceSampler:
     def join(self):
         """Make the current stream wait for the decodes of this sampler's last sample() call (mode 2)."""
         _lib.check(self._lib.ldiff_pipeline_join(self._h, _lib.stream_ptr()))
+        self._pending = None
 
     def timesteps(self, num_inference_steps: int):
         buf = (C.c_int64 * 1024)()
@@ -113,13 +115,18 @@ class LaplaceSampler:
         rgb = torch.empty((B, H, W, 3), device=vae.device, dtype=torch.uint8) if want_rgb else None
         _lib.check(self._lib.ldiff_sample(self._h, _lib.ptr(x), B, H, W, int(num_inference_steps), _lib.ptr(lat), _lib.ptr(feats), _lib.ptr(rgb),
                                           _lib.stream_ptr()))
+        # deferred join (mode 2): the side stream may still be writing features / rgb after this returns.  Hold a reference until
+        # join() (or the next sample(), which joins inside the library) so that a caller who drops the dict early -- e.g. on an
+        # exception path -- cannot get the block recycled by the caching allocator under the pending decodes.
+        self._pending = (x, feats, rgb)
         return dict(latents=lat, features=feats, rgb=rgb)
 
     def __del__(self):
         try:
             if getattr(self, "_h", None):
-                self._lib.ldiff_pipeline_destroy(self._h)
+                self._lib.ldiff_pipeline_destroy(self._h)   # synchronises the device: pending side-stream decodes finish first
                 self._h = None
+            self._pending = None
         except Exception:
             pass
 

@@ -2,9 +2,12 @@
 
 Mirrors /root/reference/segmentor.py: `_resolve_ldiffusion_dir` (:26-29), `_ensure_ldiffusion_proj` (:31-52),
 `_get_text_embeddings` (:54-60), `load_ldiffusion` (:76-84), `ldiffusion_augment` (:86-112), `_UNetTextAlignWrapper`
-(:183-205), and the sampler part + mask tail of `inference_cell_model` (:490-545).  The segmentation heads themselves
-(`model/conductor.py`, nnU-Net) are outside the hot-path scope: `inference_cell_model` takes the head as
-a callable and raises if none is given instead of silently substituting one.
+(:183-205), the sampler part + mask tail of `inference_cell_model` (:490-545) and of `inference_tissue_model_nnUNetv2`
+(:388-488).  The segmentation heads themselves (`model/conductor.py`, nnU-Net) are outside the hot-path scope (SURVEY.md
+8a/8f): both inference functions take the head as a callable and raise if none is given instead of silently substituting one;
+for the tissue level the callable is applied through the device-resident mirror of nnU-Net's sliding-window predictor
+(`tiling.predict_sliding_window_return_logits`: Gaussian-weighted fp16 accumulation, mirroring TTA) instead of the reference's
+PNG / tmpdir / multiprocess round trip.
 """
 from __future__ import annotations
 
@@ -139,3 +142,59 @@ class Segmentor:
         mask = argmax_mask(logits)[0].cpu().numpy()
         mask = np.array(Image.fromarray(mask.astype(np.uint8)).resize((width, height), resample=Image.NEAREST))
         return decoded.resize((width, height), Image.BILINEAR), mask
+
+    @torch.no_grad()
+    def inference_tissue_model_nnUNetv2(self, image_path, diffusion_path, ldiffusion_weight, segmentor_weight, output_path=None,
+                                        predictor=None, text_embeddings=None, tile_size=(512, 512), tile_step_size=0.5,
+                                        mirror_axes=(0, 1), num_heads=None):
+        """segmentor.py:388-488 with the tissue head injected.
+        * `image_path` a directory: the reference hands the folder to nnU-Net's file predictor and returns `(None, None)`
+          (:399-421).  Here `predictor(image_path, output_path)` is called if it accepts two arguments (a file-level predictor),
+          else every image of the folder goes through the single-image path and its mask is written as PNG to `output_path`.
+        * a single image: Resize(1024) + ImageNet-normalise -> one-pass sampler ONLY when width == height (:427); other aspect
+          ratios skip the diffusion and feed the image as it is (:449-450).  The decoded RGB stays on the device, is handed to
+          `predictor([1, 3, th, tw] float in 0..255 scale as the PNG would hold) -> [1, heads, th, tw]` tile by tile
+          (nnU-Net order, Gaussian fp16 accumulation, mirroring), arg-max on the device, and `(decoded PIL image, uint8 mask)`
+          is returned like :486-488."""
+        from PIL import Image
+        from . import tiling
+        if predictor is None:
+            raise RuntimeError("inference_tissue_model_nnUNetv2: the nnU-Net tissue head is outside the hot-path scope; pass `predictor=`")
+        if os.path.isdir(image_path):
+            if not output_path:
+                raise ValueError("When image_path is a folder, output_path must be specified!")
+            import inspect
+            try:
+                n_args = len(inspect.signature(predictor).parameters)
+            except (TypeError, ValueError):
+                n_args = 1
+            if n_args >= 2:
+                predictor(image_path, output_path)
+                return None, None
+            os.makedirs(output_path, exist_ok=True)
+            for name in sorted(os.listdir(image_path)):
+                if name.lower().endswith((".png", ".jpg", ".jpeg", ".tif", ".tiff", ".bmp")):
+                    _, m = self.inference_tissue_model_nnUNetv2(os.path.join(image_path, name), diffusion_path, ldiffusion_weight, segmentor_weight,
+                                                                None, predictor, text_embeddings, tile_size, tile_step_size, mirror_axes, num_heads)
+                    Image.fromarray(m).save(os.path.join(output_path, os.path.splitext(name)[0] + ".png"))
+            return None, None   # batch mode returns no single mask (segmentor.py:421)
+        pipeline, unet, _ = self.load_ldiffusion(ldiffusion_weight, diffusion_path)
+        image = Image.open(image_path).convert("RGB")
+        width, height = image.size
+        if width == height:
+            mean = torch.tensor(IMAGENET_MEAN, device=self.device).view(1, 3, 1, 1)
+            std = torch.tensor(IMAGENET_STD, device=self.device).view(1, 3, 1, 1)
+            x = torch.from_numpy(np.asarray(image.resize((1024, 1024), Image.BILINEAR), np.float32) / 255.0).permute(2, 0, 1)[None].to(self.device)
+            if text_embeddings is None:
+                text_embeddings = self._get_text_embeddings(PROMPT, 1, pipeline, unet)
+            rgb = self._one_pass((x - mean) / std, text_embeddings, pipeline, unet)["rgb"]   # [1,1024,1024,3] u8, on the device
+            decoded = Image.fromarray(rgb[0].cpu().numpy())
+        else:                                                                                 # non-square: no diffusion (segmentor.py:449-450)
+            rgb = torch.from_numpy(np.asarray(image, np.uint8))[None].to(self.device)
+            decoded = image
+        data = rgb[0].permute(2, 0, 1).float()                                                # what the PNG the reference writes would hold
+        heads = int(num_heads if num_heads is not None else self.num_classes)
+        th, tw = min(tile_size[0], data.shape[1]), min(tile_size[1], data.shape[2])
+        logits = tiling.predict_sliding_window_return_logits(data, predictor, heads, (th, tw), tile_step_size, True, mirror_axes)
+        mask = argmax_mask(logits[None].float())[0].cpu().numpy()
+        return decoded, mask

@@ -7,6 +7,7 @@ timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/stats" -
 f=$(find "$O/stats" -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" "$O/rocprofv3_kernel_stats.csv"
 timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$O/pmc_fetch" -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-unet-step --no-prof > "$O/pmcf.log" 2>&1
 timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$O/pmc_write" -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-unet-step --no-prof > "$O/pmcw.log" 2>&1
-python3 scripts/pmc_traffic.py "$O/pmc_fetch" "$O/pmc_write" "$O/pmc_traffic.json"
+H=$(python3 -c "import bench; print(bench.kernel_source_hash())")
+python3 scripts/pmc_traffic.py "$O/pmc_fetch" "$O/pmc_write" "$O/pmc_traffic_$H.json"   # bench.py only quotes the file of the current kernel sources
 rm -rf "$O/stats" "$O/pmc_fetch" "$O/pmc_write"
 tail -c 400 "$O/bench_under_rocprofv3.json"; head -5 "$O/rocprofv3_kernel_stats.csv" | cut -c1-200

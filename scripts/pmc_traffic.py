@@ -1,5 +1,5 @@
 """Aggregate two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; --kernel-trace only, separate runs) over the bench workload
-into profiles/r01_pmc_traffic.json: per-dispatch HBM traffic of each contraction kernel, keyed by bench.py's row names.
+into profiles/pmc_traffic_<kernel source hash>.json: per-dispatch HBM traffic of each contraction kernel, keyed by bench.py's row names.
 usage: python scripts/pmc_traffic.py <fetch_dir> <write_dir> <out.json>"""
 import csv, glob, json, os, re, sys
 from collections import defaultdict

@@ -241,3 +241,69 @@ def test_tiling_matches_reference_helpers():
         ptiling.merge_tile_logits(torch.zeros((1, 2, 8, 8)), [(0, 0)], (16, 16))
     t, o = ptiling.split_tiles(torch.arange(3 * 16 * 16, dtype=torch.float32).reshape(3, 16, 16), (8, 8), 1.0)
     assert t.shape == (4, 3, 8, 8) and o == [(0, 0), (0, 8), (8, 0), (8, 8)] and torch.equal(t[3], torch.arange(3 * 256.).reshape(3, 16, 16)[:, 8:, 8:])
+
+
+def _sw_network(W):
+    def network(x):   # the stand-in head of scripts/gen_golden_sliding_window.py: integer weights (exact on any device) + a column ramp
+        ramp = torch.arange(x.shape[-1], dtype=torch.float32, device=x.device) * 0.125
+        return torch.einsum("oc,bchw->bohw", W.to(x.device), x.float()) + ramp[None, None, None, :]
+    return network
+
+
+def test_sliding_window_predictor_matches_reference_code_bit_for_bit():
+    """ldiffusion_amd.tiling.predict_sliding_window_return_logits against the outputs of the REFERENCE's own
+    nnUNetPredictor._internal_predict_sliding_window_return_logits / _internal_maybe_mirror_and_predict / compute_gaussian
+    (predict_from_raw_data.py:505-589, run in the build container by scripts/gen_golden_sliding_window.py): tile order, mirroring
+    TTA, the float16 importance map (zeros lifted after the cast) and the float16 accumulation must agree bit for bit."""
+    from ldiffusion_amd import tiling
+    z = np.load(os.path.join(GOLD, "reference_sliding_window.npz"))
+    g16 = tiling.compute_gaussian((32, 32), 1.0 / 8, 10)            # default dtype = the reference's float16
+    assert g16.dtype == torch.float16 and torch.equal(g16, torch.from_numpy(z["gaussian_f16_32x32"]))
+    assert float(g16.min()) > 0
+    net = _sw_network(torch.from_numpy(z["head_weight"]))
+    for tag in "abc":
+        th, tw, step, mm = z[tag + "_cfg"]
+        mirror = None if mm < 0 else tuple(i for i in range(2) if (int(mm) >> i) & 1)
+        got = tiling.predict_sliding_window_return_logits(torch.from_numpy(z[tag + "_image"]), net, 4, (int(th), int(tw)), float(step), True, mirror)
+        assert got.dtype == torch.float16 and torch.equal(got, torch.from_numpy(z[tag + "_logits_f16"])), tag
+        assert len(tiling.tile_origins(tuple(z[tag + "_image"].shape[1:]), (int(th), int(tw)), float(step))) == int(z[tag + "_n_slicers"]) or tag == "c"
+    # an image smaller than the tile is zero padded around its centre and the padding is cut off again
+    small = torch.from_numpy(z["a_image"])[:, :20, :27]
+    out = tiling.predict_sliding_window_return_logits(small, net, 4, (32, 32), 0.5, True, (0, 1))
+    assert out.shape == (4, 20, 27) and torch.isfinite(out.float()).all()
+    with pytest.raises(RuntimeError, match="inf"):
+        tiling.predict_sliding_window_return_logits(torch.full((3, 32, 32), 6e4), lambda x: x[:, :1] * 10.0, 1, (32, 32), 1.0, True, None)
+
+
+def test_oracle_against_real_diffusers_when_pinned():
+    """tests/golden/diffusers_tiny.npz is written by scripts/gen_golden_diffusers.py where real diffusers is importable (it is not in
+    this environment: the oracle's UNet / VAE / PNDM arithmetic is PARITY UNPINNED until that file exists).  When present, the
+    oracle must reproduce real diffusers on the same weights and inputs to fp32 round-off."""
+    path = os.path.join(GOLD, "diffusers_tiny.npz")
+    if not os.path.exists(path):
+        pytest.skip("parity unpinned: no diffusers_tiny.npz (run scripts/gen_golden_diffusers.py where diffusers==0.34.0 is importable)")
+    from ldiffusion_amd import configs, weights
+    from oracle import noise_post, schedule, unet as ounet, vae as ovae
+    z = np.load(path)
+    usd = weights.synthetic_state_dict(weights.unet_param_shapes(configs.TINY_UNET), 42)
+    vsd = weights.synthetic_state_dict(weights.vae_param_shapes(configs.TINY_VAE), 43)
+    close = lambda a, b: np.abs(np.asarray(a) - np.asarray(b)).max() <= 2e-5 * max(1.0, np.abs(np.asarray(b)).max())
+    with torch.no_grad():
+        for t in (1, 501, 751):
+            assert close(ounet.unet_forward(usd, configs.TINY_UNET, torch.from_numpy(z["unet_x"]), t, torch.from_numpy(z["unet_ctx"])).sample, z[f"unet_t{t}"]), t
+        mom = ovae.vae_encode_moments(vsd, configs.TINY_VAE, torch.from_numpy(z["vae_img"]))
+        d = ovae.LatentDist(mom)
+        assert close(d.mean, z["vae_mean"]) and close(d.logvar, z["vae_logvar"])
+        assert close(ovae.vae_decode(vsd, configs.TINY_VAE, torch.from_numpy(z["vae_z"])), z["vae_dec"])
+    assert np.array_equal(schedule.alphas_cumprod().numpy(), z["alphas_cumprod"])
+    for n in (1, 4, 9, 19):
+        sch = schedule.PNDMOracle()
+        sch.set_timesteps(n)
+        assert sch.timesteps.tolist() == z[f"timesteps_{n}"].tolist()
+        x = torch.from_numpy(z[f"plms_{n}_x"][0])
+        for i, t in enumerate(sch.timesteps):
+            x = sch.step(torch.from_numpy(z[f"plms_{n}_eps"][i]), t, x).prev_sample
+            assert close(x, z[f"plms_{n}_x"][i + 1]), (n, i)
+    if "decode_latents" in z:
+        img = noise_post.decode_post(ovae.vae_decode(vsd, configs.TINY_VAE, torch.from_numpy(z["vae_z"]) / 0.18215))
+        assert close(img, z["decode_latents"]) and np.abs(noise_post.to_uint8(z["decode_latents"]).astype(int) - z["numpy_to_pil_u8"].astype(int)).max() == 0

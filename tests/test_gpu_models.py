@@ -633,6 +633,160 @@ def test_segmentor_mirror_inference_cell_model_end_to_end(tiny, tmp_path):
     assert agree > 0.995
 
 
+def _tiny_clip_dirs(root, hidden=32):
+    """A real (tiny) CLIP tokenizer + CLIPTextModel written to <root>/tokenizer and <root>/text_encoder with `transformers`, so that
+    the reference's text path (tokenizer -> text_encoder -> proj, segmentor.py:31-60) runs end to end offline."""
+    import json
+    import os
+    from transformers import CLIPTextConfig, CLIPTextModel, CLIPTokenizer
+    chars = list("abcdefghijklmnopqrstuvwxyz")
+    vocab = {c: i for i, c in enumerate(chars)}
+    vocab.update({c + "</w>": len(chars) + i for i, c in enumerate(chars)})
+    vocab["<|startoftext|>"], vocab["<|endoftext|>"] = len(vocab), len(vocab) + 1
+    td = os.path.join(root, "tokenizer")
+    os.makedirs(td)
+    json.dump(vocab, open(os.path.join(td, "vocab.json"), "w"))
+    open(os.path.join(td, "merges.txt"), "w").write("#version: 0.2\n")
+    CLIPTokenizer(os.path.join(td, "vocab.json"), os.path.join(td, "merges.txt")).save_pretrained(td)
+    torch.manual_seed(0)
+    cfg = CLIPTextConfig(vocab_size=len(vocab), hidden_size=hidden, intermediate_size=2 * hidden, num_hidden_layers=2, num_attention_heads=4,
+                         max_position_embeddings=77, bos_token_id=vocab["<|startoftext|>"], eos_token_id=vocab["<|endoftext|>"],
+                         pad_token_id=vocab["<|endoftext|>"])
+    CLIPTextModel(cfg).save_pretrained(os.path.join(root, "text_encoder"))
+
+
+def _write_sd_dirs(tmp_path, tiny, unet_dtype=torch.float16, vae_dtype=torch.bfloat16):
+    """SD directory + fine-tuned UNet directory in the diffusers layout the reference reads (ldiffusion.py:67,273-277; segmentor.py:77-80),
+    with config.json files TRIMMED of every field that has a diffusers default, fp16 / bf16 safetensors, and proj_weights.pt."""
+    import json
+    from safetensors.torch import save_file
+    sd_dir, w_dir = tmp_path / "sd", tmp_path / "train_save" / "unet" / "25_01_01"
+    for d, cfg, sd, dt in ((sd_dir / "unet", tiny["ucfg"], tiny["usd"], unet_dtype), (sd_dir / "vae", tiny["vcfg"], tiny["vsd"], vae_dtype),
+                           (w_dir, tiny["ucfg"], tiny["usd"], unet_dtype)):
+        d.mkdir(parents=True)
+        keep = ("_class_name", "block_out_channels", "cross_attention_dim", "down_block_types", "up_block_types", "layers_per_block", "latent_channels")
+        json.dump({k: v for k, v in cfg.items() if k in keep}, open(d / "config.json", "w"))   # no scaling_factor, norm_eps, flip_sin_to_cos, ...
+        save_file({k: v.to(dt).contiguous() for k, v in sd.items()}, str(d / weights.WEIGHTS_NAME))
+    _tiny_clip_dirs(str(sd_dir))
+    g = torch.Generator().manual_seed(77)
+    proj = {"weight": torch.randn((64, 32), generator=g) * 0.2, "bias": torch.randn((64,), generator=g) * 0.1}
+    torch.save(proj, str(w_dir / "proj_weights.pt"))
+    return sd_dir, w_dir, proj
+
+
+def test_text_path_and_trimmed_configs_end_to_end(tiny, tmp_path):
+    """(a) `_get_text_embeddings` executed for real: tokenizer (unpadded) -> CLIP text encoder -> Linear(768->cad)
+    loaded strictly from proj_weights.pt (segmentor.py:31-60); (b) a vae/config.json without `scaling_factor` and a unet/config.json
+    without the defaulted fields load with diffusers' defaults, from fp16 and bf16 safetensors."""
+    from transformers import CLIPTextModel, CLIPTokenizer
+    from ldiffusion_amd.segmentor import Segmentor
+    sd_dir, w_dir, proj = _write_sd_dirs(tmp_path, tiny)
+    seg = Segmentor(None, None, "cell", 3)
+    pipeline, unet, vae = seg.load_ldiffusion(str(w_dir), str(sd_dir))
+    assert vae.config.scaling_factor == 0.18215 and unet.config.norm_eps == 1e-5 and unet.config.flip_sin_to_cos is True
+    assert unet.config.cross_attention_dim == 64 and pipeline.text_encoder.config.hidden_size == 32
+    emb = seg._get_text_embeddings("A pathological slide", 2, pipeline, unet)
+    tok = CLIPTokenizer.from_pretrained(str(sd_dir / "tokenizer"))
+    enc = CLIPTextModel.from_pretrained(str(sd_dir / "text_encoder"))
+    ids = torch.tensor(tok(["A pathological slide"] * 2)["input_ids"])
+    assert ids.shape[1] == 20                                    # unpadded: <bos> + 18 characters + <eos>
+    with torch.no_grad():
+        ref = torch.nn.functional.linear(enc(ids)["last_hidden_state"], proj["weight"], proj["bias"])
+    assert emb.shape == (2, 20, 64) and emb.is_cuda and (emb.cpu() - ref).abs().max() <= 1e-4 * ref.abs().max()
+    # the loaded projection is the saved one (strict): a checkpoint with a foreign key is refused
+    assert torch.equal(seg.ldiffusion_proj.weight.cpu(), proj["weight"])
+    torch.save({"weight": proj["weight"], "bias": proj["bias"], "extra": torch.zeros(1)}, str(w_dir / "proj_weights.pt"))
+    with pytest.raises(RuntimeError):
+        Segmentor(None, None, "cell", 3).load_ldiffusion(str(w_dir), str(sd_dir))
+    torch.save(proj, str(w_dir / "proj_weights.pt"))
+    # the checkpoints were written in fp16 / bf16: the loaded graphs equal graphs built from those rounded values
+    x = torch.randn((1, 4, 16, 16), generator=torch.Generator().manual_seed(3)).to(DEV)
+    u16 = UNet2DConditionModel(tiny["ucfg"], {k: v.to(torch.float16).float() for k, v in tiny["usd"].items()}, DEV)
+    assert torch.equal(unet(x, 501, emb[:1]).sample, u16(x, 501, emb[:1]).sample)
+    vbf = AutoencoderKL(tiny["vcfg"], {k: v.to(torch.bfloat16).float() for k, v in tiny["vsd"].items()}, DEV)
+    z = torch.randn((1, 4, 8, 8), generator=torch.Generator().manual_seed(4)).to(DEV)
+    assert torch.equal(vae.decode(z).sample, vbf.decode(z).sample)
+    # decode_latents reads vae.config.scaling_factor (the field the trimmed config.json lacks)
+    assert np.array_equal(pipeline.decode_latents(z), StableDiffusionImg2ImgPipeline(vbf, u16).decode_latents(z))
+
+
+def test_tissue_inference_mirror(tiny, tmp_path):
+    """segmentor.py:388-488 through the mirror and through LDiffusionModel.inference(level="tissue"): a square image goes through the
+    one-pass sampler, a non-square one skips the diffusion (:427,449-450), a folder returns (None, None) (:421); the decoded RGB is
+    handed to the injected tissue head ON THE DEVICE through the sliding-window predictor (Gaussian fp16 accumulation, mirroring)."""
+    from PIL import Image
+    from ldiffusion_amd import tiling
+    from ldiffusion_amd.ldiffusion import LDiffusionModel
+    from ldiffusion_amd.segmentor import IMAGENET_MEAN, IMAGENET_STD, Segmentor
+    sd_dir, w_dir, proj = _write_sd_dirs(tmp_path, tiny, torch.float32, torch.float32)
+    rng = np.random.default_rng(7)
+    sq, rect = tmp_path / "sq.png", tmp_path / "rect.png"
+    Image.fromarray((rng.random((96, 96, 3)) * 255).astype(np.uint8)).save(sq)
+    Image.fromarray((rng.random((80, 120, 3)) * 255).astype(np.uint8)).save(rect)
+    Wh = torch.tensor([[1., -1., 0.], [0., 1., -1.], [-1., 0., 1.], [0.5, 0.5, -1.]])
+    seen = []
+
+    def predictor(x):                                            # stand-in tissue head: 4-class logits, not mirror-equivariant
+        seen.append((x.device.type, tuple(x.shape)))
+        ramp = torch.arange(x.shape[-1], dtype=torch.float32, device=x.device) * 0.01
+        return torch.einsum("oc,bchw->bohw", Wh.to(x.device), x.float() / 255.0) + ramp[None, None, None, :]
+
+    model = LDiffusionModel(str(sd_dir), "tissue")
+    decoded, mask = model.inference(str(sq), str(w_dir), None, 4, predictor=predictor)
+    assert decoded.size == (1024, 1024) and mask.shape == (1024, 1024) and mask.dtype == np.uint8 and mask.max() <= 3
+    assert seen[0] == ("cuda", (1, 3, 512, 512)) and len(seen) == 9 * 4   # 3x3 tiles at step 0.5, x4 mirror combinations
+    # the same by hand on the oracle: text path on the CPU, one-pass sampler, the same head through the same tiling code on the CPU
+    from transformers import CLIPTextModel, CLIPTokenizer
+    tok, enc = CLIPTokenizer.from_pretrained(str(sd_dir / "tokenizer")), CLIPTextModel.from_pretrained(str(sd_dir / "text_encoder"))
+    with torch.no_grad():
+        ctx = torch.nn.functional.linear(enc(torch.tensor(tok(["A pathological slide"])["input_ids"]))["last_hidden_state"], proj["weight"], proj["bias"])
+    mean, std = torch.tensor(IMAGENET_MEAN).view(1, 3, 1, 1), torch.tensor(IMAGENET_STD).view(1, 3, 1, 1)
+    x = torch.from_numpy(np.asarray(Image.open(sq).convert("RGB").resize((1024, 1024), Image.BILINEAR), np.float32) / 255.0).permute(2, 0, 1)[None]
+    r = op.sample_one_pass(tiny["opipe"], (x - mean) / std, ctx)
+    rgbd = np.abs(np.asarray(decoded).astype(int) - r["rgb_u8"][0].astype(int))
+    rl = tiling.predict_sliding_window_return_logits(torch.from_numpy(r["rgb_u8"][0]).permute(2, 0, 1).float(), predictor, 4, (512, 512), 0.5, True, (0, 1))
+    rmask = np.asarray(noise_post.argmax_mask(rl[None].float())[0])
+    agree = (mask == rmask).mean()
+    print(f"tissue mirror: decoded rgb max diff {rgbd.max()}, mask agreement with the oracle {agree:.4f}")
+    assert rgbd.max() <= 1 and agree > 0.995
+    # non-square: the diffusion is skipped, the image itself goes to the head -> exactly the CPU result
+    seg = Segmentor(None, None, "tissue", 4)
+    dec2, mask2 = seg.inference_tissue_model_nnUNetv2(str(rect), str(sd_dir), str(w_dir), None, predictor=predictor, tile_size=(64, 64))
+    img = torch.from_numpy(np.asarray(Image.open(rect).convert("RGB"), np.uint8)).permute(2, 0, 1).float()
+    l2 = tiling.predict_sliding_window_return_logits(img, predictor, 4, (64, 64), 0.5, True, (0, 1))
+    assert dec2.size == (120, 80) and np.array_equal(mask2, np.asarray(noise_post.argmax_mask(l2[None].float())[0]))
+    # folder mode
+    folder, outdir = tmp_path / "imgs", tmp_path / "pred"
+    folder.mkdir()
+    Image.open(rect).save(folder / "case_0000.png")
+    with pytest.raises(ValueError, match="output_path must be specified"):
+        seg.inference_tissue_model_nnUNetv2(str(folder), str(sd_dir), str(w_dir), None, predictor=predictor)
+    assert seg.inference_tissue_model_nnUNetv2(str(folder), str(sd_dir), str(w_dir), None, output_path=str(outdir), predictor=predictor,
+                                               tile_size=(64, 64)) == (None, None)
+    assert np.array_equal(np.asarray(Image.open(outdir / "case_0000.png")), mask2)
+    with pytest.raises(RuntimeError):
+        seg.inference_tissue_model_nnUNetv2(str(sq), str(sd_dir), str(w_dir), None)          # no head: refuses instead of substituting one
+
+
+def test_sliding_window_predictor_on_device_matches_reference_fixture():
+    """The device run of tiling.predict_sliding_window_return_logits against the REFERENCE's own predictor code
+    (tests/golden/reference_sliding_window.npz): fp16 accumulation in the same order -> bit for bit."""
+    import os
+    from ldiffusion_amd import tiling
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "reference_sliding_window.npz"))
+    W = torch.from_numpy(z["head_weight"]).to(DEV)
+
+    def network(x):
+        ramp = torch.arange(x.shape[-1], dtype=torch.float32, device=x.device) * 0.125
+        return torch.einsum("oc,bchw->bohw", W, x.float()) + ramp[None, None, None, :]
+
+    for tag in "abc":
+        th, tw, step, mm = z[tag + "_cfg"]
+        mirror = None if mm < 0 else tuple(i for i in range(2) if (int(mm) >> i) & 1)
+        got = tiling.predict_sliding_window_return_logits(torch.from_numpy(z[tag + "_image"]).to(DEV), network, 4, (int(th), int(tw)), float(step), True, mirror)
+        assert got.is_cuda and torch.equal(got.cpu(), torch.from_numpy(z[tag + "_logits_f16"])), tag
+
+
 def test_orchestrator_mirror_errors(tmp_path):
     """ldiffusion_amd.LDiffusionModel keeps the reference's constructor / inference signature and its error for a bad level
     (ldiffusion.py:32,317-324); what is outside the hot path raises instead of silently doing something else."""
@@ -641,6 +795,6 @@ def test_orchestrator_mirror_errors(tmp_path):
     with pytest.raises(ValueError, match="Invalid level specified"):
         m.inference("x.png", "w", None, 3, head=lambda x: x)
     with pytest.raises(RuntimeError):
-        LDiffusionModel(str(tmp_path), "tissue").inference("x.png", "w", None, 6)
+        LDiffusionModel(str(tmp_path), "tissue").inference("x.png", "w", None, 6)      # no predictor given
     with pytest.raises(NotImplementedError):
         LDiffusionModel(str(tmp_path), "cell", local_rank=0).train(None)

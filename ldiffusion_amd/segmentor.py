@@ -190,7 +190,7 @@ class Segmentor:
             rgb = self._one_pass((x - mean) / std, text_embeddings, pipeline, unet)["rgb"]   # [1,1024,1024,3] u8, on the device
             decoded = Image.fromarray(rgb[0].cpu().numpy())
         else:                                                                                 # non-square: no diffusion (segmentor.py:449-450)
-            rgb = torch.from_numpy(np.asarray(image, np.uint8))[None].to(self.device)
+            rgb = torch.from_numpy(np.array(image, np.uint8))[None].to(self.device)
             decoded = image
         data = rgb[0].permute(2, 0, 1).float()                                                # what the PNG the reference writes would hold
         heads = int(num_heads if num_heads is not None else self.num_classes)

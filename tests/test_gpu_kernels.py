@@ -136,6 +136,14 @@ CONV_CASES = {
     "3x3_wide_cout20_8byte_stores": (1, 128, 0, 24, 40, 20, 3, 1, 0, False, True, True),
     "3x3_wide_160_tile_ragged": (1, 64, 0, 17, 33, 320, 3, 1, 0, False, True, False),
     "1x1_linear_N328_16byte_tail": (1, 64, 0, 1, 200, 328, 1, 1, 0, False, False, True),
+    # large maps (>= 512 workgroups of the 8x16-tile kernel), several 64-channel slabs, ragged widths, parity folding over 3 slabs
+    "3x3_x16_128_128_gn": (8, 128, 0, 128, 128, 128, 3, 1, 0, False, True, True),
+    "3x3_x16_256_128_two_slab_pairs": (8, 256, 0, 128, 128, 128, 3, 1, 0, False, False, True),
+    "3x3_x16_ragged_width_gn": (8, 128, 0, 128, 120, 128, 3, 1, 0, False, True, True),
+    "3x3_x16_concat_bn64_gn": (8, 64, 64, 128, 128, 64, 3, 1, 0, False, True, True),
+    "3x3_x16_upsample_parity": (8, 64, 0, 64, 64, 64, 3, 1, 1, False, False, True),
+    "3x3_x16_upsample_parity_192ch": (8, 192, 0, 64, 64, 128, 3, 1, 1, False, False, False),
+    "3x3_x16_single_slab": (8, 64, 0, 128, 128, 128, 3, 1, 0, False, True, False),
 }
 
 
@@ -345,6 +353,7 @@ FUSED_STATS_CASES = {
     "conv3x3_small_image_8x8": (3, 128, 8, 8, 128, 3, 1),
     "gemm_dma_1x1": (2, 128, 16, 16, 256, 1, 1),
     "igemm_stride2": (2, 64, 32, 32, 64, 3, 2),
+    "conv3x3_x16_tile": (8, 64, 128, 128, 128, 3, 1),
 }
 
 
@@ -435,6 +444,8 @@ SPLIT_CASES = {
     "igemm_stride2_split_operand": (2, 64, 0, 16, 16, 64, 3, 2, 0, True, False),       # downsampler on the split stream
     "wide3x3_upsample_split_operand": (1, 64, 0, 16, 16, 64, 3, 1, 1, True, False),    # upsampler (parity folding on duplicated weights)
     "wide3x3_split_operand": (1, 64, 0, 16, 16, 96, 3, 1, 0, True, False),             # PREC_FULL conv on a normalised split operand
+    "x16_hi_operand_gn": (8, 128, 0, 128, 128, 128, 3, 1, 0, False, True),             # large map, two slabs, split tensors
+    "x16_split_operand_upsample": (8, 64, 0, 64, 64, 64, 3, 1, 1, True, False),
 }
 
 
@@ -505,7 +516,9 @@ def test_conv_on_split_tensors(lib, name):
     err = (got - ref).abs().max().item() / ref.abs().max().item()
     print(f"{name}: split output rel err {err:.2e}")
     # nearest-2x folding pre-sums 2-4 taps and rounds the sums to fp16: a weight rounding (2^-12 rms) the 9-tap form does not have
-    tol = 6e-4 if ups else 1e-5   # fp32 accumulation order over K up to 11,520 terms
+    # fp32 accumulation order over K up to 11,520 terms: 1e-5.  With the GroupNorm prologue the kernel's SiLU (v_exp / v_rcp, 1 ulp)
+    # and torch's differ in the last fp32 bit, which now and then flips the fp16 rounding of an operand element: 1e-4
+    tol = 6e-4 if ups else (1e-4 if use_gn else 1e-5)
     assert torch.isfinite(got).all() and err <= tol, f"{name}: {err:.3e}"
     if R > 0:   # fused statistics describe the fp32 value (hi + lo), not the rounded hi half
         gamma, beta = torch.ones(Cout), torch.zeros(Cout)

@@ -288,7 +288,8 @@ def main():
                    "patches_per_gpu": PATCHES_PER_GPU, "image": img, "n_passes": N_PASSES, "parallelism": f"dp{world} (patch sharding)"},
     }
     result["config"]["precision"] = ("split residual stream (fp16 hi|lo), fp16 MFMA operands, fp32 accumulate; UNet mode 1, VAE encoder "
-                                     "mode 2, decoder mode 1 (include/ldiff.h ldiff_unet_set_precision): latents within 1e-3 of the fp32 oracle")
+                                     "mode 2, decoder mode 0 (include/ldiff.h ldiff_unet_set_precision): latents within 1e-3 of the fp32 oracle, "
+                                     "uint8 features within one grey level")
     if not args.tiny:
         sf = total * PATCH_FLOP / elapsed * args.steps / 1e12 / world   # algorithmic TFLOP/s per GPU over the whole timed region
         result["step"] = {"algorithmic_tflops_per_gpu": sf, "mfma_frac": sf / MFMA_PEAK_TFLOPS,

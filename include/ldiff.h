@@ -99,7 +99,10 @@ typedef struct {
 int ldiff_vae_create(ldiff_vae** out, const ldiff_vae_cfg* cfg, int device);
 int ldiff_vae_load(ldiff_vae*, const char* name, const void* host_ptr, int dtype, const int64_t* shape, int ndim);
 /* storage policy of the encoder and of the decoder graph (see ldiff_unet_set_precision); defaults: encoder 2 (its error is
- * inherited by every later pass of the sampler and it runs once per patch), decoder 1 */
+ * inherited by every later pass of the sampler and it runs once per patch), decoder 0 (its output is only consumed as uint8
+ * images / luma, never fed back into the latents: measured at SD-v1.5 width, 512x512, 5 passes, the luma features are within one
+ * grey level of the fp32 oracle in all three modes -- 6.6 % / 3.5 % / 2.9 % of the pixels differ by one -- and the probe-head
+ * masks are identical in all three; modes 1 / 2 cost +20 % / +96 % decode time) */
 int ldiff_vae_set_precision(ldiff_vae*, int encoder_mode, int decoder_mode);
 int ldiff_vae_missing(ldiff_vae*);
 const char* ldiff_vae_missing_name(ldiff_vae*, int i);

@@ -182,7 +182,7 @@ struct VaeAttnW { NormW gn; MatW qkv, out; int C = 0; };
 struct ldiff_vae {
   ldiff_vae_cfg cfg;
   int device = 0;
-  int prec_enc = PREC_FULL, prec_dec = PREC_STREAM;
+  int prec_enc = PREC_FULL, prec_dec = PREC_FAST;   // the decoder feeds only uint8 images / luma (never the latents): see DESIGN.md section 3
   int prec() const { return cur == &ex_enc ? prec_enc : prec_dec; }
   WeightStore ws;
   // Two workspaces: the decoder's and the encoder's.  A pipelined sampler decodes batch k on the side stream while the encoder

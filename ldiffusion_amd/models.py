@@ -223,7 +223,7 @@ class AutoencoderKL:
     def save_pretrained(self, path):
         weights.save_model_dir(path, self._cfg, self._host_sd)
 
-    def set_precision(self, encoder: int = 2, decoder: int = 1):
+    def set_precision(self, encoder: int = 2, decoder: int = 0):
         """Storage policy of the encoder / decoder graphs (include/ldiff.h ldiff_vae_set_precision)."""
         _lib.check(self._lib.ldiff_vae_set_precision(self._h, int(encoder), int(decoder)))
         return self

@@ -180,11 +180,22 @@ def bilinear_resize(x: torch.Tensor, size) -> torch.Tensor:
 
 
 def laplace_features(pipeline: StableDiffusionImg2ImgPipeline, images: torch.Tensor, text_embeddings: torch.Tensor, num_inference_steps: int,
-                     u_list=None, seed: int = 0, out_hw: int = 64):
+                     u_list=None, seed: int = 0, out_hw: int = 64, decoder_precision: int = 1):
     """The forward part of the reference's training step (ldiffusion.py:228-247): z0 = encode(x).mean is kept
     fixed; per scheduler timestep x_t = z0 + Laplace(0, sqrt(1 - abar_t)), eps = unet(x_t, t, ctx), the UNet output is decoded
     directly, resized to out_hw x out_hw (bilinear) and reduced to a float luma plane; the planes are concatenated.
-    `u_list[i]` (optional) is the uniform draw of step i (parity is defined given u); otherwise the device Philox stream."""
+    `u_list[i]` (optional) is the uniform draw of step i (parity is defined given u); otherwise the device Philox stream.
+    Here the decoder's FLOAT output is the feature (no uint8 quantisation behind it as in the sampler), so the decodes run with the
+    split residual stream (`decoder_precision`, ldiff_vae_set_precision) instead of the sampler's all-fp16 decoder default."""
+    vae, unet, sch = pipeline.vae, pipeline.unet, pipeline.scheduler
+    vae.set_precision(2, decoder_precision)
+    try:
+        return _laplace_features(pipeline, images, text_embeddings, num_inference_steps, u_list, seed, out_hw)
+    finally:
+        vae.set_precision(2, 0)
+
+
+def _laplace_features(pipeline, images, text_embeddings, num_inference_steps, u_list, seed, out_hw):
     vae, unet, sch = pipeline.vae, pipeline.unet, pipeline.scheduler
     z0 = vae.encode(images).latent_dist.mean.to(dtype=torch.float32)
     sch.set_timesteps(num_inference_steps, device=z0.device)

@@ -7,7 +7,8 @@ pairs.  Asserted:
   * sampler latents after every pass, VAE encode mean: <= 1e-3 (measured 0.7e-4 .. 4.7e-4 at SD-v1.5 width, <= 3.6e-4 tiny),
   * one UNet pass (eps): <= 1e-3 at SD-v1.5 width (measured 7.4e-4), <= 1.2e-3 at 1/5 width (measured 6.0e-4 .. 9.1e-4: a
     64-channel graph averages less rounding noise per output than a 320-channel one),
-  * VAE decode (image range, not a latent): <= 3e-3 (measured 1.4e-3 .. 1.7e-3); uint8 images / luma: at most 1 grey level apart,
+  * VAE decode (image range, not a latent; decoder default = all-fp16 storage): <= 4e-3 (measured 2.0e-3 .. 2.3e-3); uint8 images /
+    luma: at most 1 grey level apart,
   * integer kernels given identical inputs (luma, uint8 rounding, argmax): bit exact.
 """
 import numpy as np
@@ -83,7 +84,7 @@ def test_vae_encode_decode_tiny(tiny, B, H, W):
     odec = tiny["opipe"].vae.decode(z).sample
     e_dec = rel_err(dec, odec)
     print(f"vae tiny {B}x{H}x{W}: mean {e_mean:.3e} logvar {e_logvar:.3e} decode {e_dec:.3e}")
-    assert e_mean <= 3e-4 and e_logvar <= 3e-4 and e_dec <= 3e-3
+    assert e_mean <= 3e-4 and e_logvar <= 3e-4 and e_dec <= 4e-3
     assert dist.sample().shape == dist.mean.shape
 
 
@@ -93,7 +94,7 @@ def test_decode_latents_uint8_and_luma(tiny):
     img = tiny["pipe"].decode_latents(z.to(DEV))
     oimg = tiny["opipe"].decode_latents(z)
     assert img.shape == oimg.shape == (2, 64, 64, 3) and img.dtype == np.float32
-    assert np.abs(img - oimg).max() <= 3e-3
+    assert np.abs(img - oimg).max() <= 4e-3
     # fused uint8 + luma slots vs the oracle's integer pipeline applied to the *device* float image: bit exact
     luma = torch.zeros((2, 3, 64, 64), dtype=torch.uint8, device=DEV)
     _, image, rgb = tiny["vae"]._decode(z.to(DEV), 1 / 0.18215, want_image=True, want_rgb=True, luma=luma, slot=1)
@@ -267,7 +268,7 @@ def test_sd15_width_unet_and_vae_against_oracle():
     z = torch.randn((1, 4, 32, 32), generator=g)
     e_d = rel_err(vae.decode(z.to(DEV)).sample, ovae.decode(z).sample)
     print(f"SD15 widths: unet rel err {e_u:.3e}, vae encode {e_e:.3e}, vae decode {e_d:.3e}")
-    assert e_u <= 1e-3 and e_e <= 3e-4 and e_d <= 3e-3
+    assert e_u <= 1e-3 and e_e <= 3e-4 and e_d <= 4e-3
 
 
 @pytest.mark.timeout(2400)
@@ -313,8 +314,8 @@ def test_config1_sd15_width_512_five_passes_against_oracle():
           f"luma max diff {fd.max()} (!=0: {(fd > 0).mean():.4f}, >1: {(fd > 1).mean():.6f}); mask agreement {agree:.5f}")
     assert e_enc <= 1e-3 and max(errs) <= 1e-3, "north-star tolerance: latents within 1e-3 of the reference (relative to the latent range)"
     assert fd.max() <= 1 and agree >= 0.9999
-    # the decoder's storage policy does not touch the latents; what it buys in the uint8 features, for the record
-    for dmode in (0, 2):
+    # the decoder's storage policy (default 0) does not touch the latents; what modes 1 / 2 would buy in the uint8 features, for the record
+    for dmode in (1, 2):
         pipe.vae.set_precision(2, dmode)
         f2 = LaplaceSampler(pipe).sample(x.to(DEV), ctx.to(DEV), N)["features"]
         d2 = np.abs(f2.cpu().numpy().astype(int) - ref["features"].astype(int))
@@ -372,8 +373,8 @@ def test_precision_modes_tiny(tiny):
             ed.append(rel_err(tiny["vae"].decode(z.to(DEV)).sample, ref_d))
     finally:
         tiny["unet"].set_precision(1)
-        tiny["vae"].set_precision(2, 1)
-    print(f"precision modes 0/1/2: unet {[f'{e:.2e}' for e in eu]}  vae encode {[f'{e:.2e}' for e in ee]}  vae decode {[f'{e:.2e}' for e in ed]}")
+        tiny["vae"].set_precision(2, 0)
+    print(f"precision modes 0/1/2 (defaults: UNet 1, VAE encoder 2, decoder 0): unet {[f'{e:.2e}' for e in eu]}  vae encode {[f'{e:.2e}' for e in ee]}  vae decode {[f'{e:.2e}' for e in ed]}")
     assert eu[1] < eu[0] and eu[2] < eu[1] and ee[2] < ee[0] and ed[2] < ed[0]
     assert eu[1] <= 1e-3 and ee[2] <= 3e-4 and eu[2] <= 5e-4
     with pytest.raises(ValueError):
@@ -425,6 +426,50 @@ def test_config4_tiled_roi_20_passes_6_classes(tiny, step):
     if step == 1.0:   # non-overlapping: the merged mask is the tile masks side by side
         tm = argmax_mask(logits)
         assert torch.equal(tiling.merge_tile_masks(tm, origins, (128, 128)).cpu(), torch.from_numpy(mask))
+
+
+@pytest.mark.timeout(2400)
+def test_config3_full_size_roi_1024_four_tiles_20_passes():
+    """BASELINE.json configs[3] at its real size: a 1024x1024 ROI tiled into 4 x 512x512 patches (nnU-Net origins at step 1.0), 20
+    passes, SD-v1.5-width UNet + VAE, 6-class arg-max of a probe head over the per-pixel latent vectors.  The fp32 oracle runs tile 0
+    through all 20 passes (~80 s on the box's cores); the other three tiles are covered by the batch-invariance of the sampler (a
+    tile sampled alone vs inside the batch of four: no cross-sample coupling; the launches pick tile shapes / split-K plans by
+    grid size, so the two runs differ by fp32 summation order only: latents to 1e-4, luma by at most one grey level on < 1 % of the
+    pixels), so the whole ROI is pinned by one oracle tile."""
+    from ldiffusion_amd import tiling
+    ucfg, vcfg = configs.SD15_UNET, configs.SD15_VAE
+    usd = weights.synthetic_state_dict(weights.unet_param_shapes(ucfg), 42, fp16_values=True)
+    vsd = weights.synthetic_state_dict(weights.vae_param_shapes(vcfg), 43, fp16_values=True)
+    N, C = 20, 6
+    g = torch.Generator().manual_seed(44)
+    roi = torch.rand((3, 1024, 1024), generator=g)
+    ctx = torch.randn((1, 6, 768), generator=g) * 0.5
+    pipe = StableDiffusionImg2ImgPipeline(AutoencoderKL(vcfg, vsd, DEV), UNet2DConditionModel(ucfg, usd, DEV))
+    s = LaplaceSampler(pipe)
+    tiles, origins = tiling.split_tiles(roi.to(DEV), (512, 512), 1.0)
+    assert origins == [(0, 0), (0, 512), (512, 0), (512, 512)] and len(s.timesteps(N)) == N
+    out = s.sample(tiles, ctx.to(DEV), N)
+    for k in (1, 3):                                            # batch invariance: tile k alone vs tile k inside the batch
+        alone = s.sample(tiles[k:k + 1].contiguous(), ctx.to(DEV), N)
+        dl = rel_err(alone["latents"][0], out["latents"][k])
+        df = (alone["features"][0].int() - out["features"][k].int()).abs()
+        print(f"  tile {k} alone vs in the batch: latents {dl:.2e}, luma max diff {int(df.max())} (!=0: {(df > 0).float().mean().item():.5f})")
+        assert dl <= 1e-4 and int(df.max()) <= 1 and (df > 0).float().mean().item() < 0.01
+    W, bias = _probe_head(C, N, 5)
+    logits = torch.einsum("cn,bnhw->bchw", W.to(DEV), out["features"].float()) + bias.to(DEV)[None, :, None, None]
+    mask = tiling.merge_tile_masks(argmax_mask(logits), origins, (1024, 1024)).cpu().numpy()
+    merged = tiling.merge_tile_logits(logits, origins, (1024, 1024))
+    assert np.array_equal(argmax_mask(merged[None])[0].cpu().numpy(), mask)       # non-overlapping tiles: the Gaussian merge changes nothing
+    torch.set_num_threads(max(1, min(32, len(__import__("os").sched_getaffinity(0)))))
+    opipe = op.OraclePipeline(op.OracleUNet(usd, ucfg), op.OracleVAE(vsd, vcfg))
+    ref = op.sample_v6(opipe, tiles[:1].cpu(), ctx, N)
+    e = rel_err(out["latents"][:1], ref["latents"][-1])
+    fd = np.abs(out["features"][:1].cpu().numpy().astype(int) - ref["features"].astype(int))
+    rlogits = torch.einsum("cn,bnhw->bchw", W, torch.from_numpy(ref["features"]).float()) + bias[None, :, None, None]
+    agree = (mask[:512, :512] == np.asarray(noise_post.argmax_mask(rlogits))[0]).mean()
+    print(f"configs[3] full size: 4 tiles x {N} passes at SD15 width; tile 0 vs oracle: latents rel err {e:.3e}; luma max diff {fd.max()} "
+          f"(!=0: {(fd > 0).mean():.4f}); mask agreement {agree:.5f}")
+    assert mask.shape == (1024, 1024) and e <= 1e-3 and fd.max() <= 1 and agree >= 0.999
 
 
 def test_tiles_are_independent_units(tiny):

@@ -80,6 +80,11 @@ const char* ldiff_unet_missing_name(ldiff_unet*, int i);
 int ldiff_unet_set_context(ldiff_unet*, const void* ctx_dev, int B_ctx, int L, void* stream);
 /* sample [B,in_channels,h,w] f32 NCHW -> out [B,out_channels,h,w] f32 NCHW */
 int ldiff_unet_forward(ldiff_unet*, const void* sample_dev, int B, int h, int w, float timestep, void* out_dev, void* stream);
+/* ControlNet inputs of the NEXT ldiff_unet_forward (diffusers' down_block_additional_residuals / mid_block_additional_residual,
+ * segmentor.py:357-375): n_down float32 NCHW device tensors in skip-stack order (conv_in output first; shapes of the skip tensors),
+ * added to the skip connections, and one tensor added to the mid block's output (either may be absent: n_down = 0 / NULL).  The
+ * pointers must stay valid until that forward has been enqueued; they are consumed by it. */
+int ldiff_unet_set_additional_residuals(ldiff_unet*, const void* const* down_dev, int n_down, const void* mid_dev);
 void ldiff_unet_destroy(ldiff_unet*);
 
 /* ------------------------------------------------------------------------------------------------

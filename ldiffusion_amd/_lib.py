@@ -52,6 +52,7 @@ SIGNATURES = {
     "ldiff_unet_missing_name": (C.c_char_p, [P, I]),
     "ldiff_unet_set_context": (I, [P, P, I, I, P]),
     "ldiff_unet_forward": (I, [P, P, I, I, I, F, P, P]),
+    "ldiff_unet_set_additional_residuals": (I, [P, C.POINTER(P), I, P]),
     "ldiff_unet_destroy": (None, [P]),
     "ldiff_vae_create": (I, [C.POINTER(P), C.POINTER(VaeCfg), I]),
     "ldiff_vae_load": (I, [P, C.c_char_p, P, I, C.POINTER(I64), I]),

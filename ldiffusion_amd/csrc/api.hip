@@ -76,6 +76,19 @@ int ldiff_unet_forward(ldiff_unet* u, const void* sample_dev, int B, int h, int 
   u->forward((const float*)sample_dev, B, h, w, timestep, (float*)out_dev, (hipStream_t)stream);
   API_END
 }
+int ldiff_unet_set_additional_residuals(ldiff_unet* u, const void* const* down_dev, int n_down, const void* mid_dev) {
+  API_BEGIN
+  LDIFF_CHECK(u, LDIFF_ERR_INVALID, "set_additional_residuals: null handle");
+  LDIFF_CHECK(n_down == 0 || (down_dev && n_down == u->n_skips()), LDIFF_ERR_INVALID,
+              "set_additional_residuals: %d down-block residuals given, this UNet has %d skip tensors", n_down, u->n_skips());
+  u->extra_down.clear();
+  for (int i = 0; i < n_down; ++i) {
+    LDIFF_CHECK(down_dev[i], LDIFF_ERR_INVALID, "set_additional_residuals: residual %d is null", i);
+    u->extra_down.push_back((const float*)down_dev[i]);
+  }
+  u->extra_mid = (const float*)mid_dev;
+  API_END
+}
 void ldiff_unet_destroy(ldiff_unet* u) {
   if (!u) return;
   (void)hipSetDevice(u->device);

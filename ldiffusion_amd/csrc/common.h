@@ -131,6 +131,7 @@ void launch_geglu(const f16* x, f16* y, long long M, int C4, hipStream_t s);  //
 void launch_timestep_embed(float t, const float* t_dev /* overrides t when not null */, f16* y, int B, int dim, int flip_sin_to_cos, float freq_shift,
                            hipStream_t s);
 void launch_set_scalar(float* p, float v, hipStream_t s);
+void launch_add_nchw_residual(f16* act, int ld, int lo, const float* res_nchw_f32, int B, int C, int HW, hipStream_t s);
 bool prof_enabled();   // any per-launch profiling active (graph replay would hide the launches from it)
 void launch_silu_f32_to_f16(const float* x, f16* y, long long n, hipStream_t s);
 void launch_lincomb(const float* coef, const void* const* ops, int nops, float* out, long long n, hipStream_t s);

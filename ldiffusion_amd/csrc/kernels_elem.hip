@@ -37,6 +37,26 @@ void launch_nchw_f32_to_nhwc_f16(const float* x, f16* y, int B, int C, int H, in
   HIP_CHECK(hipGetLastError());
 }
 
+// ---- act[b, pix, c] += r[b, c, pix]: ControlNet residual (fp32 NCHW, segmentor.py:366-372) added to an NHWC activation, plain or split ----
+__global__ void add_nchw_residual_kernel(f16* __restrict__ a, int ld, int lo, const float* __restrict__ r, int B, int C, int HW) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long long)B * HW * C) return;
+  const int c = (int)(i % C);
+  const long long m = i / C;
+  const int b = (int)(m / HW), pix = (int)(m - (long long)b * HW);
+  f16* row = a + m * ld;
+  float v = (float)row[c] + (lo ? (float)row[lo + c] : 0.f) + r[((long long)b * C + c) * HW + pix];
+  const f16 hi = (f16)v;
+  row[c] = hi;
+  if (lo) row[lo + c] = (f16)(v - (float)hi);
+}
+void launch_add_nchw_residual(f16* act, int ld, int lo, const float* res_nchw, int B, int C, int HW, hipStream_t s) {
+  const long long n = (long long)B * HW * C;
+  if (n == 0) return;
+  hipLaunchKernelGGL(add_nchw_residual_kernel, dim3(nblocks(n)), dim3(256), 0, s, act, ld, lo, res_nchw, B, C, HW);
+  HIP_CHECK(hipGetLastError());
+}
+
 // ---- weights of a contraction over a split operand: K doubled, the same weights against the hi and the lo halves ----
 __global__ void dup_weights_kernel(const f16* __restrict__ w, f16* __restrict__ wd, long long rows /* Nrows*taps */, int sstride, int Ca, int Cb,
                                    int dstride) {

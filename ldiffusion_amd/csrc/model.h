@@ -161,6 +161,11 @@ struct ldiff_unet {
   // handle-owned staging buffers, so the replay is valid for any caller pointers and any timestep.
   void forward(const float* x, int B, int h, int w, float t, float* out, hipStream_t s);
   void forward_impl(const float* x, int B, int h, int w, float t, const float* t_dev, float* out, hipStream_t s);
+  // ControlNet inputs of the next forward (down_block_additional_residuals, mid_block_additional_residual: segmentor.py:366-372);
+  // float32 NCHW device pointers in skip-stack order, consumed (cleared) by that forward, which then runs eagerly
+  std::vector<const float*> extra_down;
+  const float* extra_mid = nullptr;
+  int n_skips() const;
   struct GraphCache {
     bool enabled = true;
     int uses = 0;                       // forwards seen with the current key (0: none, 1: ran eagerly once, >= 2: graph ready)

@@ -675,6 +675,11 @@ Act ldiff_unet::transformer(const TransformerW& t, const Act& x) {
   return out;
 }
 
+int ldiff_unet::n_skips() const {
+  int n = 1;
+  for (int i = 0; i < cfg.n_blocks; ++i) n += cfg.layers_per_block + (i != cfg.n_blocks - 1 ? 1 : 0);
+  return n;
+}
 void ldiff_unet::GraphCache::drop() {
   if (exec) (void)hipGraphExecDestroy(exec);
   if (graph) (void)hipGraphDestroy(graph);
@@ -692,7 +697,8 @@ void ldiff_unet::forward(const float* x, int B, int h, int w, float tval, float*
   static const bool env_off = getenv("LDIFF_NO_GRAPH") != nullptr;
   hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
   if (s) (void)hipStreamIsCapturing(s, &cs);   // the legacy default stream cannot be captured
-  if (!gc.enabled || env_off || prof_enabled() || cs != hipStreamCaptureStatusNone || !x || !out || B < 1 || h < 1 || w < 1) {
+  if (!gc.enabled || env_off || prof_enabled() || cs != hipStreamCaptureStatusNone || !x || !out || B < 1 || h < 1 || w < 1 || !extra_down.empty() ||
+      extra_mid) {
     forward_impl(x, B, h, w, tval, nullptr, out, s);   // (argument errors are reported by forward_impl)
     return;
   }
@@ -807,9 +813,27 @@ void ldiff_unet::forward_impl(const float* x, int B, int h, int w, float tval, c
       cur_is_skip = true;
     }
   }
+  auto add_extra = [&](Act& a, const float* r) {   // a += r (fp32 NCHW); the producer's fused GroupNorm statistics no longer describe a
+    launch_add_nchw_residual(a.p, a.ld(), a.lo(), r, a.B, a.C, a.H * a.W, s);
+    if (a.st) { ex.arena.free(a.st); a.st = nullptr; a.st_R = 0; }
+  };
+  if (!extra_down.empty()) {   // UNet2DConditionModel.forward: down_block_res_samples = [s + r for s, r in zip(res_samples, additional)]
+    LDIFF_CHECK(extra_down.size() == skips.size(), LDIFF_ERR_INVALID, "unet: %zu additional down-block residuals for %zu skip tensors",
+                extra_down.size(), skips.size());
+    // the last skip tensor shares its buffer with the mid block's input, which diffusers leaves unmodified (the sums are new
+    // tensors): give the stack its own copy of that one before adding
+    Act own = ex.new_act(cur.B, cur.H, cur.W, cur.C, cur.split);
+    HIP_CHECK(hipMemcpyAsync(own.p, cur.p, cur.bytes(), hipMemcpyDeviceToDevice, s));
+    skips.back() = own;
+    cur_is_skip = false;     // cur's buffer now belongs to the chain only
+    for (size_t i = 0; i < skips.size(); ++i) add_extra(skips[i], extra_down[i]);
+  }
   advance(rb(mid_res[0], cur, nullptr));
   advance(transformer(mid_attn, cur));
   advance(rb(mid_res[1], cur, nullptr));
+  if (extra_mid) add_extra(cur, extra_mid);
+  extra_down.clear();
+  extra_mid = nullptr;
   for (int i = 0; i < nb; ++i) {
     for (size_t j = 0; j < up_res[i].size(); ++j) {
       Act sk = skips.back();

@@ -144,8 +144,7 @@ class UNet2DConditionModel:
         self._ctx_keepalive = (e, ehs)  # holding the source keeps its storage (and thus the cache key) from being recycled
 
     def __call__(self, sample, timestep, encoder_hidden_states, *args, **kwargs):
-        if kwargs.get("down_block_additional_residuals") is not None or kwargs.get("mid_block_additional_residual") is not None:
-            raise NotImplementedError("ControlNet residual inputs (segmentor.py:366-372, variant V7) are outside the sampling hot path")
+        down_res, mid_res = kwargs.get("down_block_additional_residuals"), kwargs.get("mid_block_additional_residual")
         if sample.dim() != 4 or sample.shape[1] != self._cfg["in_channels"]:
             raise ValueError(f"sample must be [B, {self._cfg['in_channels']}, h, w], got {tuple(sample.shape)}")
         B = sample.shape[0]
@@ -154,10 +153,32 @@ class UNet2DConditionModel:
         self.set_context(encoder_hidden_states)
         x = sample.detach().to(self.device, dtype=torch.float32).contiguous()
         out = torch.empty((B, self._cfg["out_channels"], x.shape[2], x.shape[3]), device=self.device, dtype=torch.float32)
+        if down_res is not None or mid_res is not None:   # ControlNet inputs (segmentor.py:357-375): added to the skips / the mid output
+            keep = [t.detach().to(self.device, dtype=torch.float32).contiguous() for t in (down_res or [])]
+            shapes = self._skip_shapes(B, x.shape[2], x.shape[3])
+            if keep and [tuple(t.shape) for t in keep] != shapes:
+                raise ValueError(f"down_block_additional_residuals must have the shapes of the skip tensors {shapes}")
+            mid = mid_res.detach().to(self.device, dtype=torch.float32).contiguous() if mid_res is not None else None
+            if mid is not None and tuple(mid.shape) != shapes[-1]:
+                raise ValueError(f"mid_block_additional_residual must be {shapes[-1]}")
+            arr = (C.c_void_p * max(len(keep), 1))(*[t.data_ptr() for t in keep])
+            _lib.check(self._lib.ldiff_unet_set_additional_residuals(self._h, arr, len(keep), _lib.ptr(mid)))
+            self._residual_keepalive = (keep, mid)
         _lib.check(self._lib.ldiff_unet_forward(self._h, _lib.ptr(x), B, x.shape[2], x.shape[3], float(timestep), _lib.ptr(out), _lib.stream_ptr()))
         return _Output(out)
 
     forward = __call__
+
+    def _skip_shapes(self, B, h, w):
+        """Shapes of the skip tensors in stack order (conv_in, then every resnet/attention output and downsampler of the down path)."""
+        boc, lpb = self._cfg["block_out_channels"], self._cfg["layers_per_block"]
+        shapes = [(B, boc[0], h, w)]
+        for i, c in enumerate(boc):
+            shapes += [(B, c, h, w)] * lpb
+            if i != len(boc) - 1:
+                h, w = h // 2, w // 2
+                shapes.append((B, c, h, w))
+        return shapes
 
     def __del__(self):
         try:

@@ -623,3 +623,4 @@ def test_layernorm_and_groupnorm_statistics_read_split_tensors(lib):
     got = xr * scale.cpu()[:, None, :] + shift.cpu()[:, None, :]
     ref = F.group_norm(xr.permute(0, 2, 1), 32, gam, bet, 1e-5).permute(0, 2, 1)
     assert (got - ref).abs().max() <= 2e-5 * max(1.0, ref.abs().max())
+

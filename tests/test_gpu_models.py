@@ -352,6 +352,30 @@ def test_unet_graph_replay_equals_eager(tiny):
     assert torch.equal(o, ref[(1, 1, "a")])
 
 
+def test_unet_controlnet_additional_residuals(tiny):
+    """V7's ControlNet inputs (segmentor.py:357-375): down_block_additional_residuals are added to the skip tensors (not to the mid
+    block's input), mid_block_additional_residual to the mid block's output; against the oracle's restatement of that forward."""
+    g = torch.Generator().manual_seed(60)
+    B, h, w = 2, 16, 16
+    x = torch.randn((B, 4, h, w), generator=g)
+    ctx = torch.randn((1, 6, 64), generator=g) * 0.5
+    shapes = tiny["unet"]._skip_shapes(B, h, w)
+    assert len(shapes) == 12 and shapes[0] == (B, 64, 16, 16) and shapes[-1] == (B, 256, 2, 2)
+    down = [torch.randn(sh, generator=g) * 0.3 for sh in shapes]
+    mid = torch.randn(shapes[-1], generator=g) * 0.3
+    plain = tiny["unet"](x.to(DEV), 501, ctx.to(DEV)).sample
+    for dr, mr in ((down, mid), (down, None), (None, mid)):
+        got = tiny["unet"](x.to(DEV), 501, ctx.to(DEV), down_block_additional_residuals=None if dr is None else [t.to(DEV) for t in dr],
+                           mid_block_additional_residual=None if mr is None else mr.to(DEV)).sample
+        ref = tiny["opipe"].unet(x, 501, ctx, down_block_additional_residuals=dr, mid_block_additional_residual=mr).sample
+        e = rel_err(got, ref)
+        print(f"controlnet residuals down={dr is not None} mid={mr is not None}: rel err {e:.3e}")
+        assert e <= 1.2e-3 and not torch.equal(got, plain)
+    assert torch.equal(tiny["unet"](x.to(DEV), 501, ctx.to(DEV)).sample, plain)     # the inputs are consumed by one forward
+    with pytest.raises(ValueError):
+        tiny["unet"](x.to(DEV), 501, ctx.to(DEV), down_block_additional_residuals=[t.to(DEV) for t in down[:-1]])
+
+
 def test_precision_modes_tiny(tiny):
     """ldiff_*_set_precision: 0 = all-fp16 storage (round-1 behaviour), 1 = split residual stream, 2 = every operand split.
     The error against the fp32 oracle must fall with the mode; the default (UNet 1, encoder 2, decoder 1) meets 1e-3."""

@@ -220,6 +220,38 @@ int ldiff_op_geglu(const void* x, void* y, int64_t M, int C4, void* stream);
 int ldiff_op_nchw_to_nhwc(const void* x_f32, void* y_f16, int B, int C, int H, int W, int Cpad, int lo_off, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Backward-pass primitives of the fine-tuning step  --  `engine.backward(loss)` / `engine.step()`
+ *   ldiffusion.py:227-255 (V5 loop), model/loss.py:44-126 (loss); the reference trains at 64x64 images = 8x8 latents, where a step
+ * is bound by the 859 M weights it reads and writes, so the contractions of the backward pass reuse ldiff_op_conv:
+ *   dgrad: dx = ldiff_op_conv(dy, W rearranged to [Cin][ky'][kx'][Cout] with the taps flipped)          (a layout cast by the caller)
+ *   wgrad: dW[n][tap*C+c] = ldiff_op_conv as a GEMM over K = M on dyT = ldiff_op_transpose(dy) and xcolT = ldiff_op_im2col_t(x)
+ * and the entry points below add what has no forward counterpart.  Activations / gradients NHWC f16, parameter gradients f32.
+ * ldiffusion_amd/autograd.py wraps them as torch.autograd.Function objects (the tape is torch's; every FLOP is in this library).
+ * ---------------------------------------------------------------------------------------------- */
+/* out[(tap*C + c)][m] (rows of Mpad columns, Mpad % 8 == 0, zero padded) = the im2col matrix of x, transposed; m = (b, oy, ox) */
+int ldiff_op_im2col_t(const void* x, void* out, int B, int H, int W, int C, int ks, int stride, int pad, int ups, int Ho, int Wo, int Mpad, void* stream);
+/* out[n][m] = x[m][n], rows of Mpad columns (zero padded) */
+int ldiff_op_transpose(const void* x, void* out, int M, int N, int ldx, int Mpad, void* stream);
+/* db[n] = sum_m dy[m, n]  (bias gradient, f32) */
+int ldiff_op_colsum(const void* dy, void* db_f32, int M, int N, int ld, void* stream);
+/* GroupNorm (+SiLU) forward that keeps mean / rstd [B, groups] f32, and its backward: dx f16; dgamma / dbeta f32 are ACCUMULATED
+ * (atomics over the batch; zero them first) */
+int ldiff_op_gn_train_fwd(const void* x, void* y, const void* gamma, const void* beta, void* mean, void* rstd, int B, int HW, int C, int groups, float eps,
+                          int silu, void* stream);
+int ldiff_op_gn_train_bwd(const void* x, const void* dy, const void* gamma, const void* beta, const void* mean, const void* rstd, void* dx, void* dgamma,
+                          void* dbeta, int B, int HW, int C, int groups, int silu, void* stream);
+/* LayerNorm backward (statistics recomputed from x); dgamma / dbeta accumulated */
+int ldiff_op_ln_bwd(const void* x, const void* dy, const void* gamma, void* dx, void* dgamma, void* dbeta, int rows, int C, float eps, void* stream);
+/* GEGLU backward: x [M, 2*C4] = [h | gate], dy [M, C4] -> dx [M, 2*C4] */
+int ldiff_op_geglu_bwd(const void* x, const void* dy, void* dx, int64_t M, int C4, void* stream);
+/* softmax(scale Q K^T) V backward for short sequences (Lq * Lk <= 8192: the 8x8-latent fine-tuning step); layouts as ldiff_op_attention */
+int ldiff_op_attention_bwd(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, const void* dO, int ldo, void* dq, void* dk, void* dv,
+                           int B, int heads, int Lq, int Lk, int d, int64_t q_bstride, int64_t kv_bstride, int64_t o_bstride, float scale, void* stream);
+/* one AdamW update of n f32 parameters (torch.optim.AdamW semantics; step counts from 1) */
+int ldiff_op_adamw(void* p, const void* g, void* m, void* v, int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+                   void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Live measurement for bench.py's roofline line: when enabled, every conv/linear, attention and
  * GroupNorm-statistics launch is bracketed by two HIP events recorded on the launch stream.
  * ldiff_prof_collect waits for them and returns one row per kernel (time, launches, algorithmic flops/bytes).

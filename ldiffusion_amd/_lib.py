@@ -86,6 +86,15 @@ SIGNATURES = {
     "ldiff_op_dup_weights": (I, [P, P, I, I, I, I, I, I, P]),
     "ldiff_op_geglu": (I, [P, P, I64, I, P]),
     "ldiff_op_nchw_to_nhwc": (I, [P, P, I, I, I, I, I, I, P]),
+    "ldiff_op_im2col_t": (I, [P, P, I, I, I, I, I, I, I, I, I, I, I, P]),
+    "ldiff_op_transpose": (I, [P, P, I, I, I, I, P]),
+    "ldiff_op_colsum": (I, [P, P, I, I, I, P]),
+    "ldiff_op_gn_train_fwd": (I, [P, P, P, P, P, P, I, I, I, I, F, I, P]),
+    "ldiff_op_gn_train_bwd": (I, [P, P, P, P, P, P, P, P, P, I, I, I, I, I, P]),
+    "ldiff_op_ln_bwd": (I, [P, P, P, P, P, P, I, I, F, P]),
+    "ldiff_op_geglu_bwd": (I, [P, P, P, I64, I, P]),
+    "ldiff_op_attention_bwd": (I, [P, I, P, I, P, I, P, I, P, P, P, I, I, I, I, I, I64, I64, I64, F, P]),
+    "ldiff_op_adamw": (I, [P, P, P, P, I64, F, F, F, F, F, I, P]),
     "ldiff_prof_enable": (I, [I]),
     "ldiff_prof_set_filter": (I, [C.c_char_p]),
     "ldiff_prof_collect": (I, [P, I]),

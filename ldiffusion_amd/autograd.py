@@ -1,0 +1,268 @@
+"""torch.autograd.Function wrappers over the forward / backward HIP kernels: the tape is torch's, every contraction, normalisation,
+activation and attention FLOP of both passes runs in libldiff_hip.so (include/ldiff.h, "Backward-pass primitives").
+
+This is the arithmetic layer of the reference's fine-tuning step (/root/reference/ldiffusion.py:227-255: V5 loop, `engine.backward`,
+`engine.step`): UNet2DConditionModel + the 768->768 text projection are trained on 64 x 64 images = 8 x 8 latents, where a step is bound
+by the weights it reads and writes.  Conventions: activations and their gradients are NHWC float16 CUDA tensors, parameters are float32
+masters in the torch / diffusers layouts ([Cout, Cin, k, k], [out, in]) and receive float32 gradients.
+  * dgrad = the forward conv kernel on the weights rearranged to [Cin][k][k][Cout] with the taps flipped (a layout cast in torch),
+  * wgrad = the forward GEMM kernel over K = M on dy^T (ldiff_op_transpose) and im2col(x)^T (ldiff_op_im2col_t),
+  * GroupNorm(+SiLU), LayerNorm, GEGLU, attention: dedicated backward kernels (csrc/kernels_bwd.hip).
+There is no CPU or torch-op fallback for those; reshapes / layout casts / the residual `+` are torch tensor plumbing.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib
+
+
+def _sp():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _r(x, m):
+    return (x + m - 1) // m * m
+
+
+def _check_act(x, what):
+    if not (x.is_cuda and x.dtype == torch.float16 and x.is_contiguous()):
+        raise ValueError(f"{what} must be a contiguous float16 CUDA tensor")
+
+
+def pack_weight(w: torch.Tensor) -> torch.Tensor:
+    """[Cout, Cin, k, k] (or [out, in]) float32 -> the kernel layout [roundup(Cout,16)][k*k*roundup(Cin,8)] float16 (rows >= Cout zero)."""
+    if w.dim() == 2:
+        w = w[:, :, None, None]
+    Cout, Cin, k, _ = w.shape
+    out = torch.zeros((_r(Cout, 16), k, k, _r(Cin, 8)), dtype=torch.float16, device=w.device)
+    out[:Cout, :, :, :Cin] = w.detach().permute(0, 2, 3, 1).to(torch.float16)
+    return out.reshape(out.shape[0], -1)
+
+
+def _conv_call(x, w16, Cout, k, stride, ups, bias=None, Ho=None, Wo=None, out_f32=False, pad=None):
+    """ldiff_op_conv on NHWC x [B,H,W,C] with packed weights; returns [B,Ho,Wo,roundup(Cout,8)] f16 (or f32 [.., roundup(Cout,4)])."""
+    lib = _lib.load()
+    B, H, W, Cin = x.shape
+    pad = k // 2 if pad is None else pad
+    He, We = H << ups, W << ups
+    Ho = (He + 2 * pad - k) // stride + 1 if Ho is None else Ho
+    Wo = (We + 2 * pad - k) // stride + 1 if Wo is None else Wo
+    a = _lib.ConvArgs()
+    a.x, a.C1, a.B, a.Hin, a.Win, a.Hout, a.Wout = x.data_ptr(), Cin, B, H, W, Ho, Wo
+    a.ks, a.stride, a.pad_t, a.pad_l, a.ups = k, stride, pad, pad, ups
+    a.w, a.N, a.Nrows = w16.data_ptr(), _r(Cout, 4), w16.shape[0]
+    keep = []
+    if bias is not None:
+        b = torch.zeros(w16.shape[0], dtype=torch.float32, device=x.device)
+        b[:Cout] = bias.detach().float()
+        a.bias = b.data_ptr()
+        keep.append(b)
+    ld = _r(Cout, 4) if out_f32 else _r(Cout, 8)
+    y = torch.zeros((B, Ho, Wo, ld), dtype=torch.float32 if out_f32 else torch.float16, device=x.device)
+    a.y, a.ldy, a.out_f32 = y.data_ptr(), ld, int(out_f32)
+    _lib.check(lib.ldiff_op_conv(C.byref(a), _sp()))
+    return y
+
+
+class Conv2dFn(torch.autograd.Function):
+    """y = conv2d(nearest_up(x, 2**ups), weight, bias, stride, padding=k//2) on NHWC float16 activations (k in {1, 3}).
+    Channel counts of x must be multiples of 8 (pad the 4-channel latents); y has roundup(Cout, 8) channels, the pad columns zero."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, stride=1, ups=0):
+        _check_act(x, "x")
+        Cout, Cin, k = weight.shape[0], weight.shape[1], (weight.shape[2] if weight.dim() == 4 else 1)
+        if x.shape[-1] != _r(Cin, 8):
+            raise ValueError(f"x has {x.shape[-1]} channels, the weight expects {Cin} (padded to {_r(Cin, 8)})")
+        y = _conv_call(x, pack_weight(weight), Cout, k, stride, ups, bias)
+        ctx.save_for_backward(x, weight)
+        ctx.meta = (stride, ups, bias is not None, k, Cout, Cin)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        x, weight = ctx.saved_tensors
+        stride, ups, has_bias, k, Cout, Cin = ctx.meta
+        dy = dy.contiguous()
+        B, H, W, Cx = x.shape
+        _, Ho, Wo, Cy = dy.shape
+        w4 = weight if weight.dim() == 4 else weight[:, :, None, None]
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            # dgrad: conv (stride 1) of dy -- zero-inserted for a stride-2 forward -- with the weights [Cin][k][k][Cout], taps flipped
+            wd = torch.zeros((_r(Cx, 16), k, k, Cy), dtype=torch.float16, device=x.device)
+            wd[:Cin, :, :, :Cout] = w4.detach().flip(2, 3).permute(1, 2, 3, 0).to(torch.float16)
+            g = dy
+            He, We = H << ups, W << ups
+            if stride == 2:
+                g = torch.zeros((B, He, We, Cy), dtype=torch.float16, device=x.device)
+                g[:, ::2, ::2] = dy
+            dxu = _conv_call(g, wd.reshape(wd.shape[0], -1), Cx, k, 1, 0)
+            dx = dxu if ups == 0 else dxu.view(B, H, 2, W, 2, Cx).float().sum((2, 4)).to(torch.float16)
+        if ctx.needs_input_grad[1]:
+            # wgrad: dW[n][tap*Cx + c] = sum_m dy[m, n] * xcol[m, tap*Cx + c]  as a GEMM over K = M
+            M = B * Ho * Wo
+            Mpad = _r(M, 8)
+            Kc = k * k * Cx
+            dyT = torch.empty((Cy, Mpad), dtype=torch.float16, device=x.device)
+            _lib.check(lib.ldiff_op_transpose(dy.data_ptr(), dyT.data_ptr(), M, Cy, Cy, Mpad, _sp()))
+            xcolT = torch.zeros((_r(Kc, 16), Mpad), dtype=torch.float16, device=x.device)
+            _lib.check(lib.ldiff_op_im2col_t(x.data_ptr(), xcolT.data_ptr(), B, H, W, Cx, k, stride, k // 2, ups, Ho, Wo, Mpad, _sp()))
+            g = _conv_call(dyT.view(1, 1, Cy, Mpad), xcolT, Kc, 1, 1, 0, out_f32=True)        # [1,1,Cy,Kc] f32
+            dw = g.view(Cy, -1)[:Cout, :Kc].view(Cout, k, k, Cx)[..., :Cin].permute(0, 3, 1, 2).contiguous()
+            if weight.dim() == 2:
+                dw = dw[:, :, 0, 0]
+        if has_bias and ctx.needs_input_grad[2]:
+            db = torch.empty(Cy, dtype=torch.float32, device=x.device)
+            _lib.check(lib.ldiff_op_colsum(dy.data_ptr(), db.data_ptr(), B * Ho * Wo, Cy, Cy, _sp()))
+            db = db[:Cout]
+        return dx, dw, db, None, None
+
+
+def linear(x, weight, bias=None):
+    """F.linear on float16 rows [..., Cin] through the conv kernels (k = 1)."""
+    shp = x.shape
+    y = Conv2dFn.apply(x.reshape(1, 1, -1, shp[-1]).contiguous(), weight, bias, 1, 0)
+    y = y.reshape(*shp[:-1], y.shape[-1])
+    return y if y.shape[-1] == weight.shape[0] else y[..., :weight.shape[0]]
+
+
+class GroupNormFn(torch.autograd.Function):
+    """y = act(group_norm(x, groups, gamma, beta, eps)) on NHWC float16 [B, H, W, C]; act = SiLU when `silu`."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, groups, eps, silu):
+        _check_act(x, "x")
+        lib = _lib.load()
+        B, H, W, Cc = x.shape
+        y = torch.empty_like(x)
+        mean = torch.empty((B, groups), dtype=torch.float32, device=x.device)
+        rstd = torch.empty_like(mean)
+        g32, b32 = gamma.detach().float().contiguous(), beta.detach().float().contiguous()
+        _lib.check(lib.ldiff_op_gn_train_fwd(x.data_ptr(), y.data_ptr(), g32.data_ptr(), b32.data_ptr(), mean.data_ptr(), rstd.data_ptr(), B, H * W, Cc,
+                                             groups, float(eps), int(silu), _sp()))
+        ctx.save_for_backward(x, g32, b32, mean, rstd)
+        ctx.meta = (groups, int(silu))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        x, g32, b32, mean, rstd = ctx.saved_tensors
+        groups, silu = ctx.meta
+        B, H, W, Cc = x.shape
+        dy = dy.contiguous()
+        dx = torch.empty_like(x)
+        dg, db = torch.zeros(Cc, dtype=torch.float32, device=x.device), torch.zeros(Cc, dtype=torch.float32, device=x.device)
+        _lib.check(lib.ldiff_op_gn_train_bwd(x.data_ptr(), dy.data_ptr(), g32.data_ptr(), b32.data_ptr(), mean.data_ptr(), rstd.data_ptr(), dx.data_ptr(),
+                                             dg.data_ptr(), db.data_ptr(), B, H * W, Cc, groups, silu, _sp()))
+        return dx, dg, db, None, None, None
+
+
+class LayerNormFn(torch.autograd.Function):
+    """F.layer_norm over the last dim of float16 rows [..., C]."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        _check_act(x, "x")
+        lib = _lib.load()
+        Cc = x.shape[-1]
+        rows = x.numel() // Cc
+        y = torch.empty_like(x)
+        g32, b32 = gamma.detach().float().contiguous(), beta.detach().float().contiguous()
+        _lib.check(lib.ldiff_op_layernorm(x.data_ptr(), 0, 0, y.data_ptr(), rows, Cc, g32.data_ptr(), b32.data_ptr(), float(eps), _sp()))
+        ctx.save_for_backward(x, g32)
+        ctx.eps = float(eps)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        x, g32 = ctx.saved_tensors
+        Cc = x.shape[-1]
+        rows = x.numel() // Cc
+        dy = dy.contiguous()
+        dx = torch.empty_like(x)
+        dg, db = torch.zeros(Cc, dtype=torch.float32, device=x.device), torch.zeros(Cc, dtype=torch.float32, device=x.device)
+        _lib.check(lib.ldiff_op_ln_bwd(x.data_ptr(), dy.data_ptr(), g32.data_ptr(), dx.data_ptr(), dg.data_ptr(), db.data_ptr(), rows, Cc, ctx.eps, _sp()))
+        return dx, dg, db, None
+
+
+class GegluFn(torch.autograd.Function):
+    """[M, 2*C4] = [h | gate] -> h * gelu_erf(gate)   (diffusers GEGLU)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        _check_act(x, "x")
+        lib = _lib.load()
+        C4 = x.shape[-1] // 2
+        M = x.numel() // x.shape[-1]
+        y = torch.empty(x.shape[:-1] + (C4,), dtype=torch.float16, device=x.device)
+        _lib.check(lib.ldiff_op_geglu(x.data_ptr(), y.data_ptr(), M, C4, _sp()))
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        (x,) = ctx.saved_tensors
+        C4 = x.shape[-1] // 2
+        M = x.numel() // x.shape[-1]
+        dx = torch.empty_like(x)
+        _lib.check(lib.ldiff_op_geglu_bwd(x.data_ptr(), dy.contiguous().data_ptr(), dx.data_ptr(), M, C4, _sp()))
+        return dx
+
+
+class AttentionFn(torch.autograd.Function):
+    """softmax(q k^T / sqrt(d)) v per head on float16 [B, L, heads*d] tensors (K/V given per batch entry, not broadcast)."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, heads):
+        for t, n in ((q, "q"), (k, "k"), (v, "v")):
+            _check_act(t, n)
+        lib = _lib.load()
+        B, Lq, Cc = q.shape
+        Lk = k.shape[1]
+        d = Cc // heads
+        o = torch.empty_like(q)
+        scale = 1.0 / d ** 0.5
+        _lib.check(lib.ldiff_op_attention(q.data_ptr(), Cc, k.data_ptr(), Cc, v.data_ptr(), Cc, o.data_ptr(), Cc, B, heads, Lq, Lk, d, Lq * Cc, Lk * Cc, Lq * Cc,
+                                          scale, _sp()))
+        ctx.save_for_backward(q, k, v)
+        ctx.meta = (heads, scale)
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        lib = _lib.load()
+        q, k, v = ctx.saved_tensors
+        heads, scale = ctx.meta
+        B, Lq, Cc = q.shape
+        Lk = k.shape[1]
+        do = do.contiguous()
+        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        _lib.check(lib.ldiff_op_attention_bwd(q.data_ptr(), Cc, k.data_ptr(), Cc, v.data_ptr(), Cc, do.data_ptr(), Cc, dq.data_ptr(), dk.data_ptr(), dv.data_ptr(),
+                                              B, heads, Lq, Lk, Cc // heads, Lq * Cc, Lk * Cc, Lq * Cc, scale, _sp()))
+        return dq, dk, dv, None
+
+
+def adamw_step(params, grads, state, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01):
+    """One AdamW update (torch.optim.AdamW semantics; the reference's DeepSpeed config, ldiffusion.py:168-171) of float32 CUDA
+    parameters, in place.  `state` is a dict the caller keeps: it holds the step count and the two moment buffers per parameter."""
+    lib = _lib.load()
+    state["step"] = state.get("step", 0) + 1
+    for i, (p, g) in enumerate(zip(params, grads)):
+        if g is None:
+            continue
+        if not (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous()):
+            raise ValueError("adamw_step: parameters must be contiguous float32 CUDA tensors")
+        if i not in state:
+            state[i] = (torch.zeros_like(p), torch.zeros_like(p))
+        m, v = state[i]
+        g = g.detach().to(torch.float32).contiguous()
+        _lib.check(lib.ldiff_op_adamw(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), float(lr), float(betas[0]), float(betas[1]), float(eps),
+                                      float(weight_decay), int(state["step"]), _sp()))

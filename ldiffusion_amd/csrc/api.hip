@@ -491,6 +491,71 @@ int ldiff_op_dup_weights(const void* w, void* wd, int Nrows, int taps, int src_t
   launch_dup_weights((const f16*)w, (f16*)wd, Nrows, taps, src_tap_stride, Ca, Cb, dst_tap_stride, (hipStream_t)stream);
   API_END
 }
+// ---- backward-pass primitives (kernels_bwd.hip) ----
+int ldiff_op_im2col_t(const void* x, void* out, int B, int H, int W, int Cc, int ks, int stride, int pad, int ups, int Ho, int Wo, int Mpad, void* stream) {
+  API_BEGIN
+  LDIFF_CHECK(x && out, LDIFF_ERR_INVALID, "op_im2col_t: null argument");
+  launch_im2col_t((const f16*)x, (f16*)out, B, H, W, Cc, ks, stride, pad, ups, Ho, Wo, Mpad, (hipStream_t)stream);
+  API_END
+}
+int ldiff_op_transpose(const void* x, void* out, int M, int N, int ldx, int Mpad, void* stream) {
+  API_BEGIN
+  LDIFF_CHECK(x && out, LDIFF_ERR_INVALID, "op_transpose: null argument");
+  launch_transpose_rows((const f16*)x, (f16*)out, M, N, ldx, Mpad, (hipStream_t)stream);
+  API_END
+}
+int ldiff_op_colsum(const void* dy, void* db_f32, int M, int N, int ld, void* stream) {
+  API_BEGIN
+  LDIFF_CHECK(dy && db_f32, LDIFF_ERR_INVALID, "op_colsum: null argument");
+  launch_colsum((const f16*)dy, (float*)db_f32, M, N, ld, (hipStream_t)stream);
+  API_END
+}
+int ldiff_op_gn_train_fwd(const void* x, void* y, const void* gamma, const void* beta, void* mean, void* rstd, int B, int HW, int Cc, int groups, float eps,
+                          int silu, void* stream) {
+  API_BEGIN
+  LDIFF_CHECK(x && y && gamma && beta && mean && rstd, LDIFF_ERR_INVALID, "op_gn_train_fwd: null argument");
+  launch_gn_train_fwd((const f16*)x, (f16*)y, (const float*)gamma, (const float*)beta, (float*)mean, (float*)rstd, B, HW, Cc, groups, eps, silu,
+                      (hipStream_t)stream);
+  API_END
+}
+int ldiff_op_gn_train_bwd(const void* x, const void* dy, const void* gamma, const void* beta, const void* mean, const void* rstd, void* dx, void* dgamma,
+                          void* dbeta, int B, int HW, int Cc, int groups, int silu, void* stream) {
+  API_BEGIN
+  LDIFF_CHECK(x && dy && gamma && beta && mean && rstd && dx && dgamma && dbeta, LDIFF_ERR_INVALID, "op_gn_train_bwd: null argument");
+  launch_gn_train_bwd((const f16*)x, (const f16*)dy, (const float*)gamma, (const float*)beta, (const float*)mean, (const float*)rstd, (f16*)dx,
+                      (float*)dgamma, (float*)dbeta, B, HW, Cc, groups, silu, (hipStream_t)stream);
+  API_END
+}
+int ldiff_op_ln_bwd(const void* x, const void* dy, const void* gamma, void* dx, void* dgamma, void* dbeta, int rows, int Cc, float eps, void* stream) {
+  API_BEGIN
+  LDIFF_CHECK(x && dy && gamma && dx && dgamma && dbeta, LDIFF_ERR_INVALID, "op_ln_bwd: null argument");
+  launch_ln_bwd((const f16*)x, (const f16*)dy, (const float*)gamma, (f16*)dx, (float*)dgamma, (float*)dbeta, rows, Cc, eps, (hipStream_t)stream);
+  API_END
+}
+int ldiff_op_geglu_bwd(const void* x, const void* dy, void* dx, int64_t M, int C4, void* stream) {
+  API_BEGIN
+  LDIFF_CHECK(x && dy && dx, LDIFF_ERR_INVALID, "op_geglu_bwd: null argument");
+  launch_geglu_bwd((const f16*)x, (const f16*)dy, (f16*)dx, M, C4, (hipStream_t)stream);
+  API_END
+}
+int ldiff_op_attention_bwd(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, const void* dO, int ldo, void* dq, void* dk, void* dv,
+                           int B, int heads, int Lq, int Lk, int d, int64_t q_bstride, int64_t kv_bstride, int64_t o_bstride, float scale, void* stream) {
+  API_BEGIN
+  LDIFF_CHECK(q && k && v && dO && dq && dk && dv && B >= 0 && heads >= 1, LDIFF_ERR_INVALID, "op_attention_bwd: bad arguments");
+  AttnParams p;
+  p.q = (const f16*)q; p.ldq = ldq; p.k = (const f16*)k; p.ldk = ldk; p.v = (const f16*)v; p.ldv = ldv; p.o = nullptr; p.ldo = ldo;
+  p.B = B; p.heads = heads; p.Lq = Lq; p.Lk = Lk; p.d = d;
+  p.q_bstride = q_bstride; p.kv_bstride = kv_bstride; p.o_bstride = o_bstride; p.scale = scale;
+  launch_attn_bwd(p, (const f16*)dO, (f16*)dq, (f16*)dk, (f16*)dv, (hipStream_t)stream);
+  API_END
+}
+int ldiff_op_adamw(void* p, const void* g, void* m, void* v, int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+                   void* stream) {
+  API_BEGIN
+  LDIFF_CHECK(p && g && m && v && n >= 0, LDIFF_ERR_INVALID, "op_adamw: bad arguments");
+  launch_adamw((float*)p, (const float*)g, (float*)m, (float*)v, n, lr, beta1, beta2, eps, weight_decay, step, (hipStream_t)stream);
+  API_END
+}
 int ldiff_op_geglu(const void* x, void* y, int64_t M, int C4, void* stream) {
   API_BEGIN
   LDIFF_CHECK(x && y, LDIFF_ERR_INVALID, "op_geglu: null argument");

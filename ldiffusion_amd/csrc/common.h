@@ -147,6 +147,19 @@ void launch_fold_gn_weights(const f16* w, const float* bias, const float* scale,
 void launch_bilinear_resize(const float* x, float* y, int B, int C, int H, int W, int oh, int ow, hipStream_t s);
 void launch_luma_float(const float* rgb_nchw, float* gray, int B, int H, int W, hipStream_t s);
 
+// ---- backward-pass primitives of the fine-tuning step (kernels_bwd.hip) -------------------------------------
+void launch_im2col_t(const f16* x, f16* out, int B, int H, int W, int C, int ks, int stride, int pad, int ups, int Ho, int Wo, int Mpad, hipStream_t s);
+void launch_transpose_rows(const f16* x, f16* out, int M, int N, int ldx, int Mpad, hipStream_t s);
+void launch_colsum(const f16* dy, float* db, int M, int N, int ld, hipStream_t s);
+void launch_gn_train_fwd(const f16* x, f16* y, const float* gamma, const float* beta, float* mean, float* rstd, int B, int HW, int C, int G, float eps,
+                         int silu, hipStream_t s);
+void launch_gn_train_bwd(const f16* x, const f16* dy, const float* gamma, const float* beta, const float* mean, const float* rstd, f16* dx, float* dgamma,
+                         float* dbeta, int B, int HW, int C, int G, int silu, hipStream_t s);
+void launch_ln_bwd(const f16* x, const f16* dy, const float* gamma, f16* dx, float* dgamma, float* dbeta, int rows, int C, float eps, hipStream_t s);
+void launch_geglu_bwd(const f16* x, const f16* dy, f16* dx, long long M, int C4, hipStream_t s);
+void launch_attn_bwd(const AttnParams& p, const f16* dO, f16* dq, f16* dk, f16* dv, hipStream_t s);
+void launch_adamw(float* p, const float* g, float* m, float* v, long long n, float lr, float b1, float b2, float eps, float wd, int step, hipStream_t s);
+
 // ---- device arena: bump/free-list allocator over one hipMalloc'd slab ------------------------
 // No hipMalloc/hipFree in a forward pass (graph-capturable, no implicit syncs).  Stream-ordered reuse:
 // all kernels of one handle run on one stream, so a block may be reused as soon as it is released on the host.

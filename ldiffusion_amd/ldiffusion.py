@@ -1,6 +1,8 @@
 """Host-side mirror of the reference's orchestrator `LDiffusionModel` (/root/reference/ldiffusion.py:31-324) for the
 sampling path: same constructor and `inference(...)` signature (cell and tissue levels), same error for an invalid level.
-Training (`train`, `train_ldiffusion`: DeepSpeed ZeRO-3 fine-tuning, ldiffusion.py:121-315) is a "next" row of SURVEY.md 8f and raises.
+Training (`train`, `train_ldiffusion`: DeepSpeed ZeRO-3 fine-tuning, ldiffusion.py:121-315): the arithmetic core of a step lives in
+`ldiffusion_amd.train` (forward and backward on the HIP kernels, parity-tested against torch.autograd over the oracle); the
+orchestration around it (dataset, VGG19 content loss, ZeRO-3) is not built and `train` raises.
 """
 from __future__ import annotations
 
@@ -36,8 +38,10 @@ class LDiffusionModel:
         return pipeline, pipeline.vae
 
     def train(self, args, component="all", ldiffusion_weight=None, **_ignored):
-        raise NotImplementedError("LDiffusionModel.train (ZeRO-3 fine-tuning, ldiffusion.py:121-315) is outside the sampling hot path "
-                                  "this build accelerates (SURVEY.md 8f rank 2)")
+        raise NotImplementedError("LDiffusionModel.train (ldiffusion.py:121-315) is not wired end to end: its data loading, the VGG19 content "
+                                  "loss and DeepSpeed ZeRO-3 are outside this build.  The arithmetic of the step -- V5 feature loop, contrastive "
+                                  "loss, backward through the VAE decoder and the UNet on the HIP kernels, gradient all-reduce, AdamW -- is "
+                                  "ldiffusion_amd.train.train_step (tests/test_gpu_train.py)")
 
     def inference(self, image_path, ldiffusion_weight, segmentor_weight, num_classes, head=None, predictor=None, output_path=None,
                   text_embeddings=None, **_readme_kwargs):

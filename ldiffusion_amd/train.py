@@ -1,0 +1,249 @@
+"""Fine-tuning step of the reference on the HIP kernels (forward AND backward): trainable UNet2DConditionModel + text projection,
+frozen AutoencoderKL decoder in the gradient path, the V5 feature loop and the contrastive (InfoNCE) feature loss, AdamW.
+
+Mirrors /root/reference/ldiffusion.py:121-295 (`train_ldiffusion`): per batch
+    z0 = vae.encode(Resize(64)(image)).mean                       # 8 x 8 latents                     :212,228
+    for t in scheduler.timesteps:                                 # V5 loop                           :231-247
+        noisy = z0 + Laplace(0, sqrt(1 - abar_t))                                                     :234-237
+        den   = unet(noisy, t, proj(text_embeddings)).sample      # trainable                         :238
+        rgb   = bilinear64(vae.decode(den).sample)                # frozen weights, gradient flows    :240
+        gray  = (rgb * [0.2989, 0.5870, 0.1140]).sum(1)           # one feature plane per step        :241-247
+    loss = InfoNceLoss.compute_loss(image, rgb_1024, features, label)                                 :251-252, model/loss.py:44-126
+    engine.backward(loss); engine.step()                          # ZeRO-3 AdamW, lr 1e-5             :165-193,254-255
+Graph structure follows the same diffusers restatement as csrc/model.hip / oracle/unet.py.
+
+Scope of this module: every contraction, normalisation, activation and attention of the forward and backward pass
+runs in libldiff_hip.so through ldiffusion_amd.autograd; torch provides the tape, the residual `+`, concatenation and the loss reduction
+over the sampled pixel pairs.  Not built: the VGG19 content term of the loss (model/loss.py:21-42 needs ImageNet weights that are not
+available offline), DeepSpeed's ZeRO-3 partitioning / CPU offload (a replicated-parameter gradient all-reduce is provided instead:
+`allreduce_gradients`), bf16.  `LDiffusionModel.train` therefore still raises; this is the tested arithmetic core of that step.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+import torch.nn.functional as F
+
+from . import autograd as ag
+
+LUMA = (0.2989, 0.5870, 0.1140)  # ldiffusion.py:241
+
+
+def _nhwc16(x_nchw_f32, pad_to=8):
+    B, Cc, H, W = x_nchw_f32.shape
+    Cp = (Cc + pad_to - 1) // pad_to * pad_to
+    out = torch.zeros((B, H, W, Cp), dtype=torch.float16, device=x_nchw_f32.device)
+    out[..., :Cc] = x_nchw_f32.permute(0, 2, 3, 1)
+    return out
+
+
+class _Graph:
+    """Parameter dict + the block builders shared by the UNet and the VAE decoder (NHWC float16 activations)."""
+
+    def __init__(self, state_dict, device, trainable):
+        self.device = torch.device(device)
+        self.p = {k: torch.nn.Parameter(v.detach().to(self.device, torch.float32).contiguous(), requires_grad=trainable) for k, v in state_dict.items()}
+
+    def parameters(self):
+        return [v for v in self.p.values() if v.requires_grad]
+
+    def named_parameters(self):
+        return [(k, v) for k, v in self.p.items() if v.requires_grad]
+
+    def conv(self, name, x, stride=1, ups=0):
+        w = self.p[name + ".weight"]
+        return ag.Conv2dFn.apply(x, w, self.p.get(name + ".bias"), stride, ups)   # roundup(Cout, 8) channels; pad columns (if any) are zero
+
+    def lin(self, name, x):
+        return ag.linear(x, self.p[name + ".weight"], self.p.get(name + ".bias"))
+
+    def gn(self, name, x, groups, eps, silu):
+        return ag.GroupNormFn.apply(x, self.p[name + ".weight"], self.p[name + ".bias"], groups, eps, silu)
+
+    def ln(self, name, x):
+        return ag.LayerNormFn.apply(x, self.p[name + ".weight"], self.p[name + ".bias"], 1e-5)
+
+    def resnet(self, name, x, temb_act, groups, eps):
+        """ResnetBlock2D; temb_act = SiLU(time embedding) rows [B, D] or None (VAE)."""
+        h = self.gn(name + ".norm1", x, groups, eps, True)
+        h = self.conv(name + ".conv1", h)
+        if temb_act is not None:
+            h = h + self.lin(name + ".time_emb_proj", temb_act)[:, None, None, :]
+        h = self.gn(name + ".norm2", h, groups, eps, True)
+        h = self.conv(name + ".conv2", h)
+        if (name + ".conv_shortcut.weight") in self.p:
+            x = self.conv(name + ".conv_shortcut", x)
+        return x + h
+
+    def attention(self, name, x, ctx, heads):
+        q = self.lin(name + ".to_q", x)
+        kv = x if ctx is None else ctx
+        k, v = self.lin(name + ".to_k", kv), self.lin(name + ".to_v", kv)
+        o = ag.AttentionFn.apply(q.contiguous(), k.contiguous(), v.contiguous(), heads)
+        return self.lin(name + ".to_out.0", o)
+
+
+class TrainableUNet(_Graph):
+    """UNet2DConditionModel (SD-v1.5 style configs, ldiffusion_amd/configs.py) with float32 master parameters in the diffusers key layout."""
+
+    def __init__(self, cfg, state_dict, device="cuda:0"):
+        super().__init__(state_dict, device, trainable=True)
+        self.cfg = dict(cfg)
+
+    def transformer(self, name, x, ctx, heads, groups):
+        B, H, W, Cc = x.shape
+        h = self.gn(name + ".norm", x, groups, 1e-6, False)
+        h = self.conv(name + ".proj_in", h).reshape(B, H * W, Cc)
+        b = name + ".transformer_blocks.0"
+        h = self.attention(b + ".attn1", self.ln(b + ".norm1", h), None, heads) + h
+        h = self.attention(b + ".attn2", self.ln(b + ".norm2", h), ctx, heads) + h
+        f = ag.GegluFn.apply(self.lin(b + ".ff.net.0.proj", self.ln(b + ".norm3", h)).contiguous())
+        h = self.lin(b + ".ff.net.2", f) + h
+        return self.conv(name + ".proj_out", h.reshape(B, H, W, Cc).contiguous()) + x
+
+    def __call__(self, sample, timestep, encoder_hidden_states):
+        """sample [B, 4, h, w] float32 NCHW, timestep scalar, encoder_hidden_states [B or 1, L, cross_attention_dim] float32 (may require grad:
+        the text projection is trained through it) -> eps [B, 4, h, w] float32."""
+        cfg = self.cfg
+        boc, groups, eps, heads, lpb = cfg["block_out_channels"], cfg["norm_num_groups"], cfg["norm_eps"], cfg["attention_head_dim"], cfg["layers_per_block"]
+        B = sample.shape[0]
+        ctx = encoder_hidden_states.to(self.device)
+        ctx = ctx.expand(B, -1, -1) if ctx.shape[0] != B else ctx
+        ctx16 = ctx.to(torch.float16).contiguous()
+        half = boc[0] // 2
+        freq = torch.exp(-math.log(10000.0) * torch.arange(half, dtype=torch.float32, device=self.device) / (half - cfg["freq_shift"]))
+        arg = torch.as_tensor(float(timestep), dtype=torch.float32, device=self.device) * freq
+        emb = torch.cat([torch.sin(arg), torch.cos(arg)])
+        if cfg["flip_sin_to_cos"]:
+            emb = torch.cat([emb[half:], emb[:half]])
+        emb = emb[None].expand(B, -1).to(torch.float16).contiguous()
+        temb = self.lin("time_embedding.linear_2", F.silu(self.lin("time_embedding.linear_1", emb)))
+        temb_act = F.silu(temb).contiguous()
+        x = self.conv("conv_in", _nhwc16(sample.to(self.device, torch.float32)))
+        skips = [x]
+        for i, bt in enumerate(cfg["down_block_types"]):
+            for j in range(lpb):
+                x = self.resnet(f"down_blocks.{i}.resnets.{j}", x, temb_act, groups, eps)
+                if bt == "CrossAttnDownBlock2D":
+                    x = self.transformer(f"down_blocks.{i}.attentions.{j}", x, ctx16, heads, groups)
+                skips.append(x)
+            if i != len(boc) - 1:
+                x = self.conv(f"down_blocks.{i}.downsamplers.0.conv", x, stride=2)
+                skips.append(x)
+        x = self.resnet("mid_block.resnets.0", x, temb_act, groups, eps)
+        x = self.transformer("mid_block.attentions.0", x, ctx16, heads, groups)
+        x = self.resnet("mid_block.resnets.1", x, temb_act, groups, eps)
+        for i, bt in enumerate(cfg["up_block_types"]):
+            for j in range(lpb + 1):
+                x = torch.cat([x, skips.pop()], -1).contiguous()
+                x = self.resnet(f"up_blocks.{i}.resnets.{j}", x, temb_act, groups, eps)
+                if bt == "CrossAttnUpBlock2D":
+                    x = self.transformer(f"up_blocks.{i}.attentions.{j}", x, ctx16, heads, groups)
+            if i != len(boc) - 1:
+                x = self.conv(f"up_blocks.{i}.upsamplers.0.conv", x, ups=1)
+        x = self.gn("conv_norm_out", x, groups, eps, True)
+        out = self.conv("conv_out", x)[..., :cfg["out_channels"]]
+        return out.permute(0, 3, 1, 2).float()
+
+
+class FrozenVAEDecoder(_Graph):
+    """AutoencoderKL.decode (post_quant_conv + Decoder) with frozen parameters: gradients flow to its input only."""
+
+    def __init__(self, cfg, state_dict, device="cuda:0"):
+        sd = {k: v for k, v in state_dict.items() if k.startswith(("decoder.", "post_quant_conv."))}
+        super().__init__(sd, device, trainable=False)
+        self.cfg = dict(cfg)
+
+    def mid_attention(self, name, x, groups):
+        B, H, W, Cc = x.shape
+        h = self.gn(name + ".group_norm", x, groups, 1e-6, False).reshape(B, H * W, Cc)
+        return self.attention(name, h, None, 1).reshape(B, H, W, Cc) + x
+
+    def __call__(self, z):
+        """z [B, 4, h, w] float32 NCHW (requires grad) -> decoded image [B, 3, 8h, 8w] float32."""
+        cfg = self.cfg
+        groups, boc, lpb = cfg["norm_num_groups"], cfg["block_out_channels"], cfg["layers_per_block"]
+        x = self.conv("post_quant_conv", _nhwc16_grad(z.to(self.device)))
+        x = self.conv("decoder.conv_in", x)
+        x = self.resnet("decoder.mid_block.resnets.0", x, None, groups, 1e-6)
+        x = self.mid_attention("decoder.mid_block.attentions.0", x, groups)
+        x = self.resnet("decoder.mid_block.resnets.1", x, None, groups, 1e-6)
+        for i in range(len(boc)):
+            for j in range(lpb + 1):
+                x = self.resnet(f"decoder.up_blocks.{i}.resnets.{j}", x, None, groups, 1e-6)
+            if i != len(boc) - 1:
+                x = self.conv(f"decoder.up_blocks.{i}.upsamplers.0.conv", x, ups=1)
+        x = self.gn("decoder.conv_norm_out", x, groups, 1e-6, True)
+        return self.conv("decoder.conv_out", x)[..., :cfg["out_channels"]].permute(0, 3, 1, 2).float()
+
+
+def _nhwc16_grad(z):
+    """NCHW float32 (may require grad) -> NHWC float16 padded to 8 channels, differentiable."""
+    B, Cc, H, W = z.shape
+    zp = F.pad(z.permute(0, 2, 3, 1), (0, (8 - Cc % 8) % 8))
+    return zp.to(torch.float16).contiguous()
+
+
+def v5_features(unet, vae_dec, z0, text_embeddings, timesteps, abar, u_list, out_hw=64):
+    """The V5 loop (ldiffusion.py:231-247) given the uniform draws: returns (features [B, n, out_hw, out_hw] float32, last rgb)."""
+    from .pipeline import laplace_noise
+    grays, rgb = [], None
+    for i, t in enumerate(timesteps):
+        scale = float(torch.sqrt(1 - abar[int(t)]))
+        noisy = laplace_noise(z0, scale, u=u_list[i])
+        den = unet(noisy, t, text_embeddings)
+        rgb = F.interpolate(vae_dec(den), size=(out_hw, out_hw), mode="bilinear", align_corners=False)
+        w = torch.tensor(LUMA, device=rgb.device, dtype=torch.float32).view(1, 3, 1, 1)
+        grays.append((rgb * w).sum(1, keepdim=True))
+    return torch.cat(grays, 1), rgb
+
+
+def contrastive_loss(features, pairs, temperature=0.5):
+    """InfoNceLoss.compute_contrastive_loss (model/loss.py:44-109) for GIVEN sample triples: `pairs[b]` = list of
+    (anchor_index, positive_index, [negative indices]) into the flattened H*W pixels of image b (the reference draws them with
+    torch.randperm / randint; parity is defined given the draw).  Mean cross-entropy of [pos | negs] similarities / temperature."""
+    B, n, H, W = features.shape
+    feat = features.view(B, n, H * W).permute(0, 2, 1)
+    total, count = features.new_zeros(()), 0
+    for b in range(B):
+        for a, p, negs in pairs[b]:
+            anchor = feat[b, a][None]
+            logits = torch.cat([anchor @ feat[b, p][None].t(), anchor @ feat[b, negs].t()], -1) / temperature
+            total = total + F.cross_entropy(logits, torch.zeros(1, dtype=torch.long, device=features.device))
+            count += 1
+    if count == 0:
+        return features.sum() * 0.0
+    return total / count
+
+
+def allreduce_gradients(params, world_size=None):
+    """Replicated-parameter data parallelism: average the float32 gradients over the ranks with ONE flattened all-reduce (RCCL on
+    ROCm; xGMI is point-to-point, so one large bucket per step beats many small ones).  No-op without a process group."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return
+    grads = [p.grad for p in params if p.grad is not None]
+    flat = torch.cat([g.reshape(-1) for g in grads])
+    dist.all_reduce(flat)
+    flat /= dist.get_world_size() if world_size is None else world_size
+    off = 0
+    for g in grads:
+        g.copy_(flat[off:off + g.numel()].view_as(g))
+        off += g.numel()
+
+
+def train_step(unet, vae_dec, proj, z0, text_hidden, timesteps, abar, u_list, pairs, opt_state, lr=1e-5, weight_decay=0.01):
+    """One fine-tuning step (ldiffusion.py:209-255 without the VGG19 content term): text projection -> V5 features -> contrastive loss ->
+    backward through the VAE decoder and the UNet -> gradient all-reduce -> AdamW on the UNet and projection parameters.
+    `proj` = (weight [D, 768], bias [D]) float32 CUDA parameters of the text projection; returns the loss value."""
+    params = unet.parameters() + list(proj)
+    for p in params:
+        p.grad = None
+    ctx = F.linear(text_hidden, proj[0], proj[1])
+    feats, _ = v5_features(unet, vae_dec, z0, ctx, timesteps, abar, u_list)
+    loss = contrastive_loss(feats, pairs)
+    loss.backward()
+    allreduce_gradients(params)
+    ag.adamw_step(params, [p.grad for p in params], opt_state, lr=lr, weight_decay=weight_decay)
+    return float(loss.detach())

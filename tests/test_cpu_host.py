@@ -123,6 +123,37 @@ def test_gather_masks_world_size_2_gloo(tmp_path):
     assert (tmp_path / "rank0.ok").exists() and (tmp_path / "rank1.ok").exists(), r.stdout[-2000:] + r.stderr[-2000:]
 
 
+_GRAD_WORKER = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, {root!r})
+from ldiffusion_amd import train
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+ps = [torch.nn.Parameter(torch.zeros(s)) for s in ((5,), (3, 4), (1,))]
+for i, p in enumerate(ps[:2]):
+    p.grad = torch.full(p.shape, float(rank + 1 + i))          # the third parameter has no gradient (unused in the step)
+train.allreduce_gradients(ps)
+for i, p in enumerate(ps[:2]):
+    assert torch.equal(p.grad, torch.full(p.shape, (1 + 2) / 2 + i)), (rank, i, p.grad)
+assert ps[2].grad is None
+dist.barrier()
+dist.destroy_process_group()
+open(os.path.join({out!r}, "grad%d.ok" % rank), "w").write("ok")
+"""
+
+
+def test_gradient_allreduce_world_size_2_gloo(tmp_path):
+    """The training step's one collective (ldiffusion_amd.train.allreduce_gradients: one flattened all-reduce of the float32 gradients,
+    RCCL on the GPUs) on gloo with two ranks."""
+    script = tmp_path / "gworker.py"
+    script.write_text(_GRAD_WORKER.format(root=ROOT, out=str(tmp_path)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", "29547", str(script)]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=240, env=dict(os.environ, OMP_NUM_THREADS="1"))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert (tmp_path / "grad0.ok").exists() and (tmp_path / "grad1.ok").exists()
+
+
 def test_bench_self_launches_n_ranks_without_a_launcher():
     """`python bench.py --gpus 2` with no WORLD_SIZE around it must spawn its own ranks (the driver starts it that way) and
     rank 0 must print the JSON line with n_gpus=2; --launch-check stops after the rendezvous so it runs without a GPU."""

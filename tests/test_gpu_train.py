@@ -1,0 +1,101 @@
+"""-m gpu: the fine-tuning step (ldiffusion_amd/train.py; /root/reference/ldiffusion.py:209-255) -- forward AND backward on the HIP
+kernels -- against torch.autograd over the CPU oracle's plain-torch graphs (oracle/unet.py, oracle/vae.py) at reduced width and the
+reference's training size (64 x 64 images = 8 x 8 latents).
+
+Tolerance: float16 activations / activation gradients with float32 accumulation through ~500 chained forward and ~1000 backward ops:
+the features within 1e-2 of their range (all-fp16 storage here: the inference path's split residual stream is not used in training), the
+loss within 2e-3, every parameter gradient within 5e-2 of its largest reference entry (tensors whose gradient is mathematically zero --
+q/k projections of the 1-token self-attention at the 1x1 level -- are measured against 1e-3 of the largest gradient entry of the model),
+and the direction of the whole gradient (cosine over all 688 parameter tensors) >= 0.9995.  Measured values are printed."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from ldiffusion_amd import configs, train, weights
+from oracle import noise_post, schedule, unet as ounet, vae as ovae
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _setup():
+    ucfg, vcfg = configs.TINY_UNET, configs.TINY_VAE
+    usd = weights.synthetic_state_dict(weights.unet_param_shapes(ucfg), 42, fp16_values=True)
+    vsd = weights.synthetic_state_dict(weights.vae_param_shapes(vcfg), 43, fp16_values=True)
+    g = torch.Generator().manual_seed(77)
+    B = 2
+    z0 = torch.randn((B, 4, 8, 8), generator=g) * 0.8
+    hidden = torch.randn((1, 6, 32), generator=g) * 0.5                                   # text_encoder(ids).last_hidden_state stand-in
+    proj_w = (torch.randn((64, 32), generator=g) / 32 ** 0.5).to(torch.float16).float()
+    proj_b = (torch.randn(64, generator=g) * 0.05).to(torch.float16).float()
+    sch = schedule.PNDMOracle()
+    sch.set_timesteps(2)
+    ts = [int(t) for t in sch.timesteps]
+    eps32 = torch.finfo(torch.float32).eps
+    u_list = [torch.rand((B, 4, 8, 8), generator=g) * (2 - eps32) + (eps32 - 1) for _ in ts]
+    pairs = []
+    for b in range(B):                                                                    # (anchor, positive, negatives) pixel indices of a 64x64 map
+        pairs.append([(int(torch.randint(0, 4096, (1,), generator=g)), int(torch.randint(0, 4096, (1,), generator=g)),
+                       torch.randint(0, 4096, (64,), generator=g).tolist()) for _ in range(6)])
+    return ucfg, vcfg, usd, vsd, z0, hidden, proj_w, proj_b, sch, ts, u_list, pairs
+
+
+def _oracle_loss_and_grads(ucfg, vcfg, usd, vsd, z0, hidden, proj_w, proj_b, sch, ts, u_list, pairs):
+    sd = {k: v.clone().requires_grad_(True) for k, v in usd.items()}
+    pw, pb = proj_w.clone().requires_grad_(True), proj_b.clone().requires_grad_(True)
+    ctx = F.linear(hidden, pw, pb)
+    grays = []
+    for i, t in enumerate(ts):
+        noisy = noise_post.laplace_forward_noise(z0, sch.alphas_cumprod[t], u_list[i])
+        den = ounet.unet_forward(sd, ucfg, noisy, t, ctx).sample
+        rgb = F.interpolate(ovae.vae_decode(vsd, vcfg, den), size=(64, 64), mode="bilinear", align_corners=False)
+        grays.append((rgb * torch.tensor(train.LUMA).view(1, 3, 1, 1)).sum(1, keepdim=True))
+    feats = torch.cat(grays, 1)
+    loss = train.contrastive_loss(feats, pairs)
+    loss.backward()
+    return loss.detach(), feats.detach(), {k: v.grad for k, v in sd.items()}, pw.grad, pb.grad
+
+
+@pytest.mark.timeout(900)
+def test_training_step_gradients_match_autograd_over_the_oracle():
+    ucfg, vcfg, usd, vsd, z0, hidden, proj_w, proj_b, sch, ts, u_list, pairs = _setup()
+    rloss, rfeats, rgrads, rpw, rpb = _oracle_loss_and_grads(ucfg, vcfg, usd, vsd, z0, hidden, proj_w, proj_b, sch, ts, u_list, pairs)
+    unet = train.TrainableUNet(ucfg, usd, DEV)
+    dec = train.FrozenVAEDecoder(vcfg, vsd, DEV)
+    pw, pb = proj_w.to(DEV).requires_grad_(True), proj_b.to(DEV).requires_grad_(True)
+    ctx = F.linear(hidden.to(DEV), pw, pb)
+    feats, _ = train.v5_features(unet, dec, z0.to(DEV), ctx, ts, sch.alphas_cumprod, [u.to(DEV) for u in u_list])
+    loss = train.contrastive_loss(feats, pairs)
+    loss.backward()
+    e_f = ((feats.detach().cpu() - rfeats).abs().max() / rfeats.abs().max()).item()
+    e_l = abs(loss.item() - rloss.item()) / abs(rloss.item())
+    worst, dots, n1, n2 = (0.0, ""), 0.0, 0.0, 0.0
+    gmax = max(float(v.abs().max()) for v in rgrads.values())
+    missing = [k for k, p in unet.p.items() if p.grad is None]
+    assert not missing, f"no gradient reached {missing[:5]}"
+    for k, p in list(unet.p.items()) + [("proj.weight", pw), ("proj.bias", pb)]:
+        ref = rgrads[k] if k in rgrads else (rpw if k == "proj.weight" else rpb)
+        got = p.grad.detach().cpu()
+        e = ((got - ref).abs().max() / ref.abs().max().clamp_min(1e-3 * gmax)).item()
+        if e > worst[0]:
+            worst = (e, k)
+        dots += (got.double() * ref.double()).sum().item(); n1 += got.double().pow(2).sum().item(); n2 += ref.double().pow(2).sum().item()
+    cos = dots / (n1 ** 0.5 * n2 ** 0.5)
+    print(f"training step (tiny width, 8x8 latents, {len(ts)} V5 steps): features {e_f:.2e}, loss {loss.item():.5f} vs {rloss.item():.5f} ({e_l:.2e}); "
+          f"{len(unet.p) + 2} parameter gradients: worst {worst[0]:.2e} ({worst[1]}), cosine {cos:.6f}")
+    assert e_f <= 1e-2 and e_l <= 2e-3 and worst[0] <= 5e-2 and cos >= 0.9995
+    assert all(not p.requires_grad and p.grad is None for p in dec.p.values())            # the VAE is frozen: no parameter gradients
+
+
+def test_train_step_runs_and_updates_parameters():
+    ucfg, vcfg, usd, vsd, z0, hidden, proj_w, proj_b, sch, ts, u_list, pairs = _setup()
+    unet = train.TrainableUNet(ucfg, usd, DEV)
+    dec = train.FrozenVAEDecoder(vcfg, vsd, DEV)
+    proj = (proj_w.to(DEV).requires_grad_(True), proj_b.to(DEV).requires_grad_(True))
+    before = {k: v.detach().clone() for k, v in list(unet.p.items())[:5]}
+    state = {}
+    losses = [train.train_step(unet, dec, proj, z0.to(DEV), hidden.to(DEV), ts, sch.alphas_cumprod, [u.to(DEV) for u in u_list], pairs, state, lr=1e-4)
+              for _ in range(3)]
+    print(f"three AdamW steps on one batch: loss {[round(x, 5) for x in losses]}")
+    assert all(torch.isfinite(torch.tensor(losses))) and losses[-1] < losses[0]
+    assert state["step"] == 3 and all(not torch.equal(unet.p[k].detach(), v) for k, v in before.items())

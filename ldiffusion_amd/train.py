@@ -185,13 +185,14 @@ def _nhwc16_grad(z):
     return zp.to(torch.float16).contiguous()
 
 
-def v5_features(unet, vae_dec, z0, text_embeddings, timesteps, abar, u_list, out_hw=64):
-    """The V5 loop (ldiffusion.py:231-247) given the uniform draws: returns (features [B, n, out_hw, out_hw] float32, last rgb)."""
+def v5_features(unet, vae_dec, z0, text_embeddings, timesteps, abar, u_list=None, out_hw=64, seed=0, offset=0):
+    """The V5 loop (ldiffusion.py:231-247): returns (features [B, n, out_hw, out_hw] float32, last rgb).  The Laplace noise comes from the
+    given uniform draws `u_list[i]` (parity is defined given u) or from the device Philox stream (seed, offset + i * numel)."""
     from .pipeline import laplace_noise
     grays, rgb = [], None
     for i, t in enumerate(timesteps):
         scale = float(torch.sqrt(1 - abar[int(t)]))
-        noisy = laplace_noise(z0, scale, u=u_list[i])
+        noisy = laplace_noise(z0, scale, u=None if u_list is None else u_list[i], seed=seed, offset=offset + i * z0.numel())
         den = unet(noisy, t, text_embeddings)
         rgb = F.interpolate(vae_dec(den), size=(out_hw, out_hw), mode="bilinear", align_corners=False)
         w = torch.tensor(LUMA, device=rgb.device, dtype=torch.float32).view(1, 3, 1, 1)
@@ -224,6 +225,8 @@ def allreduce_gradients(params, world_size=None):
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return
     grads = [p.grad for p in params if p.grad is not None]
+    if not grads:
+        return
     flat = torch.cat([g.reshape(-1) for g in grads])
     dist.all_reduce(flat)
     flat /= dist.get_world_size() if world_size is None else world_size
@@ -233,17 +236,34 @@ def allreduce_gradients(params, world_size=None):
         off += g.numel()
 
 
-def train_step(unet, vae_dec, proj, z0, text_hidden, timesteps, abar, u_list, pairs, opt_state, lr=1e-5, weight_decay=0.01):
-    """One fine-tuning step (ldiffusion.py:209-255 without the VGG19 content term): text projection -> V5 features -> contrastive loss ->
-    backward through the VAE decoder and the UNet -> gradient all-reduce -> AdamW on the UNet and projection parameters.
-    `proj` = (weight [D, 768], bias [D]) float32 CUDA parameters of the text projection; returns the loss value."""
+def clip_grad_norm(params, max_norm):
+    """DeepSpeed's `gradient_clipping` (ldiffusion.py:187: 1.0): scale all gradients by max_norm / max(global L2 norm, max_norm)."""
+    grads = [p.grad for p in params if p.grad is not None]
+    if not grads:
+        return 0.0
+    total = torch.sqrt(sum((g.float() ** 2).sum() for g in grads))
+    coef = float(max_norm) / max(float(total), float(max_norm))
+    if coef < 1.0:
+        for g in grads:
+            g.mul_(coef)
+    return float(total)
+
+
+def train_step(unet, vae_dec, proj, z0, text_hidden, timesteps, abar, u_list, pairs, opt_state, lr=1e-5, weight_decay=0.01, loss_fn=None,
+               max_grad_norm=None, seed=0, offset=0):
+    """One fine-tuning step (ldiffusion.py:209-255): text projection -> V5 features -> loss -> backward through the VAE decoder and the
+    UNet -> gradient all-reduce -> (clipping) -> AdamW on the UNet and projection parameters.
+    `proj` = (weight [D, 768], bias [D]) float32 CUDA parameters of the text projection.  `loss_fn(features, last_rgb)` defaults to the
+    contrastive loss on the given sample triples `pairs`.  Returns the loss value."""
     params = unet.parameters() + list(proj)
     for p in params:
         p.grad = None
     ctx = F.linear(text_hidden, proj[0], proj[1])
-    feats, _ = v5_features(unet, vae_dec, z0, ctx, timesteps, abar, u_list)
-    loss = contrastive_loss(feats, pairs)
+    feats, rgb = v5_features(unet, vae_dec, z0, ctx, timesteps, abar, u_list, seed=seed, offset=offset)
+    loss = contrastive_loss(feats, pairs) if loss_fn is None else loss_fn(feats, rgb)
     loss.backward()
     allreduce_gradients(params)
+    if max_grad_norm is not None:
+        clip_grad_norm(params, max_grad_norm)
     ag.adamw_step(params, [p.grad for p in params], opt_state, lr=lr, weight_decay=weight_decay)
     return float(loss.detach())

@@ -307,3 +307,21 @@ def test_oracle_against_real_diffusers_when_pinned():
     if "decode_latents" in z:
         img = noise_post.decode_post(ovae.vae_decode(vsd, configs.TINY_VAE, torch.from_numpy(z["vae_z"]) / 0.18215))
         assert close(img, z["decode_latents"]) and np.abs(noise_post.to_uint8(z["decode_latents"]).astype(int) - z["numpy_to_pil_u8"].astype(int)).max() == 0
+
+
+def test_infonce_mirror_matches_reference_code():
+    """ldiffusion_amd.loss.InfoNceLoss.compute_contrastive_loss against the REFERENCE's own function (model/loss.py:44-109, run in the build
+    container by scripts/gen_golden_loss.py): with the same torch seed the mirror must draw the same (anchor, positive, negatives) triples
+    -- same loss value, and the random stream left in the same state."""
+    from ldiffusion_amd.loss import InfoNceLoss
+    z = np.load(os.path.join(GOLD, "reference_infonce.npz"))
+    for tag in "abc":
+        torch.manual_seed(int(z[tag + "_seed"]))
+        loss = InfoNceLoss().compute_contrastive_loss(torch.from_numpy(z[tag + "_features"]), torch.from_numpy(z[tag + "_labels"]))
+        assert abs(float(loss) - float(z[tag + "_loss"])) <= 1e-6 * abs(float(z[tag + "_loss"])), tag
+        assert torch.rand(1).item() == float(z[tag + "_next_rand"]), tag
+    with pytest.raises(RuntimeError, match="VGG19"):
+        InfoNceLoss().compute_loss(torch.zeros((1, 3, 8, 8)), torch.zeros((1, 3, 8, 8)), torch.zeros((1, 2, 8, 8)), torch.zeros((1, 1, 8, 8)))
+    vgg = lambda x: x.mean((2, 3))                                      # an injected feature extractor enables the content term
+    l2 = InfoNceLoss(vgg_features=vgg).compute_content_loss(torch.ones((1, 3, 8, 8)), torch.zeros((1, 3, 8, 8)))
+    assert abs(float(l2) - 1.0) < 1e-6

@@ -871,5 +871,35 @@ def test_orchestrator_mirror_errors(tmp_path):
         m.inference("x.png", "w", None, 3, head=lambda x: x)
     with pytest.raises(RuntimeError):
         LDiffusionModel(str(tmp_path), "tissue").inference("x.png", "w", None, 6)      # no predictor given
+    with pytest.raises(RuntimeError, match="train_loader"):
+        LDiffusionModel(str(tmp_path), "cell", local_rank=0).train(None)                 # the dataset pipeline is injected, not rebuilt
     with pytest.raises(NotImplementedError):
-        LDiffusionModel(str(tmp_path), "cell", local_rank=0).train(None)
+        LDiffusionModel(str(tmp_path), "cell", local_rank=0).train(None, component="segmentor", ldiffusion_weight="w")
+
+
+def test_train_ldiffusion_mirror_end_to_end(tiny, tmp_path):
+    """LDiffusionModel.train(component="ldiffusion") (ldiffusion.py:121-295,297-305) with an injected loader: two epochs over two batches on
+    the HIP kernels (forward and backward), CSV log, best-epoch checkpoint in the layout Segmentor.load_ldiffusion reads back."""
+    import csv
+    from types import SimpleNamespace
+    from ldiffusion_amd.ldiffusion import LDiffusionModel
+    from ldiffusion_amd.segmentor import Segmentor
+    sd_dir, _, _ = _write_sd_dirs(tmp_path, tiny, torch.float32, torch.float32)
+    g = torch.Generator().manual_seed(21)
+    loader = [(torch.rand((2, 3, 96, 96), generator=g), None, torch.randint(0, 3, (2, 1, 96, 96), generator=g).to(torch.uint8)) for _ in range(2)]
+    args = SimpleNamespace(diffusion_path=str(sd_dir), num_inference_steps=5, batch_size=2, ldiffusion_epochs=2, output_root=str(tmp_path / "out"))
+    torch.manual_seed(5)
+    model = LDiffusionModel(str(sd_dir), "cell")
+    saved = model.train(args, component="ldiffusion", train_loader=loader)
+    assert saved.startswith(str(tmp_path / "out")) and (tmp_path / "out" / "LDiffusion" / "train_save" / "unet").is_dir()
+    import os
+    assert {"config.json", weights.WEIGHTS_NAME, "proj_weights.pt"} <= set(os.listdir(saved))
+    rows = list(csv.reader(open(next((tmp_path / "out" / "train_save" / "loss").glob("*/contrast_loss.csv")))))
+    assert rows[0] == ["epoch", "loss"] and [r[0] for r in rows[1:]] == ["1", "2"] and all(np.isfinite(float(r[1])) for r in rows[1:])
+    print(f"train_ldiffusion mirror: epoch losses {[round(float(r[1]), 4) for r in rows[1:]]}")
+    # the checkpoint loads through the inference path and differs from the starting weights
+    pipeline, unet, _ = Segmentor(None, None, "cell", 3).load_ldiffusion(saved, str(sd_dir))
+    x = torch.randn((1, 4, 8, 8), generator=g).to(DEV)
+    ctx = torch.randn((1, 6, 64), generator=g).to(DEV)
+    assert not torch.equal(unet(x, 1, ctx).sample, tiny["unet"](x, 1, ctx).sample)
+    assert tuple(torch.load(os.path.join(saved, "proj_weights.pt"))["weight"].shape) == (64, 32)

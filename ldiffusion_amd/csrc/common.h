@@ -86,6 +86,10 @@ int conv3x3_splitk_plan(const ConvParams& p);
 // w_par[q][n][t][c] from w[n][ky][kx][c]  (2.25x fewer MACs than gathering 9 taps from the upsampled image)
 void launch_make_parity_weights(const f16* w, f16* w_par, int Nrows, int Cin, hipStream_t s);                  // 1 = no split; >1 needs splitk_ws of splitk*M*N floats
 void launch_conv3x3(const ConvParams& p, hipStream_t s);       // kernels_conv3x3.hip
+// 16x16-tile ping-pong variant for the maps that fill the chip (kernels_conv3x3p.hip); launch_conv3x3 dispatches to it
+bool conv3x3p_selected(const ConvParams& p);
+int conv3x3p_stats_blocks(const ConvParams& p);
+void launch_conv3x3p(const ConvParams& p, hipStream_t s);
 bool gemm_dma_eligible(const ConvParams& p);
 void launch_gemm_dma(const ConvParams& p, hipStream_t s);      // kernels_gemm.hip
 
@@ -231,6 +235,31 @@ __device__ __forceinline__ float row16_sum(float v) {
   v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));   // row_half_mirror
   v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));   // row_mirror
   return v;
+}
+// Sum NV values per lane over the 16 lanes of an MFMA row group, all at once: at every step a lane keeps half of its values, adds the
+// partner lane's copies of them and hands the other half over (row_mirror, row_half_mirror, quad xor 2, quad xor 1: the partner
+// differs in exactly the lane bit that selects).  NV - 1 adds instead of 4 NV, and the totals end up spread over the lanes (value
+// index j in lane bits: bit0 = l15 & 8, bit1 = l15 & 4, bit2 = l15 & 2, bit3 = l15 & 1), so ONE store per lane writes them all.
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true)); }
+template <int NV>
+__device__ __forceinline__ float row16_reduce_spread(float (&x)[NV], int l15) {
+  static_assert(NV == 8 || NV == 16, "values per lane");
+  int n = NV;
+  auto step = [&](auto ctrlc, bool bit) __attribute__((always_inline)) {
+    constexpr int CTRL = decltype(ctrlc)::value;
+    if (n > 1) {
+      n >>= 1;
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        if (i < n) { const float keep = bit ? x[2 * i + 1] : x[2 * i], send = bit ? x[2 * i] : x[2 * i + 1]; x[i] = keep + dpp_f<CTRL>(send); }
+    } else x[0] += dpp_f<CTRL>(x[0]);
+  };
+  step(std::integral_constant<int, 0x140>{}, (l15 & 8) != 0);
+  step(std::integral_constant<int, 0x141>{}, (l15 & 4) != 0);
+  step(std::integral_constant<int, 0x4E>{}, (l15 & 2) != 0);
+  step(std::integral_constant<int, 0xB1>{}, (l15 & 1) != 0);
+  return x[0];
 }
 // Per-wave reduction used by the epilogues: `o[a][m][r]` = final (fp16-rounded) value of pixel (m, l15), channel
 // ncol + 16a + r; `ok[m]` = pixel valid.  Tiles m in [M0, M1) form one row block.  Lanes with l15 == 0 write 4 channels.

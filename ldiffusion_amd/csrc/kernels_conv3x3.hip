@@ -650,6 +650,33 @@ __global__ __launch_bounds__(256, BN > 128 ? 1 : 2) void conv3x3w_kernel(const C
     // per wave: sums over its 64 pixels (in-lane over the m-tiles, DPP over the 16 pixels of a row group); the two waves that
     // share a channel half (wave_m = 0, 1) are combined through LDS (free after the main loop's last barrier), so the
     // finalize kernel reads half as many partials as with one block per wave
+    if constexpr (NT == 2 || NT == 4) {
+      // all NT*4 channel sums of the wave reduced over the 16 pixel lanes at once, totals spread over the lanes (common.h,
+      // row16_reduce_spread): a quarter of the DPP adds, and one LDS write / one read / one store per lane instead of 16 by one lane in 16
+      constexpr int NV = NT * 4;
+      float sv[NV], qv[NV];
+#pragma unroll
+      for (int j = 0; j < NV; ++j) { sv[j] = 0.f; qv[j] = 0.f; }
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+#pragma unroll
+        for (int a = 0; a < NT; ++a)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { const float v = mrow[m] < 0 ? 0.f : acc[a][m][r]; sv[a * 4 + r] += v; qv[a * 4 + r] += v * v; }
+      }
+      const float st_s = row16_reduce_spread<NV>(sv, l15), st_q = row16_reduce_spread<NV>(qv, l15);
+      const int jv = ((l15 >> 3) & 1) | ((l15 >> 1) & 2) | ((l15 << 1) & 4) | ((l15 << 3) & 8);   // value index a*4 + r of this lane's totals
+      float2* xch = reinterpret_cast<float2*>(smem_raw) + (wave_n * 4 + g) * 16 + jv;        // [wave_n][g][16]
+      if (wave_m == 1) *xch = make_float2(st_s, st_q);
+      __syncthreads();
+      const int n = ncol + (jv >> 2) * 16 + (jv & 3);
+      if (wave_m == 0 && (NV == 16 || jv < NV) && n < p.N) {
+        const long long R = p.stats_R, rblk = ((long long)q_par * tiles_y + ty) * tiles_x + tx;
+        const float2 t = *xch;
+        *reinterpret_cast<float2*>(p.stats + ((long long)b * p.N * R + rblk) * 2 + (long long)n * R * 2) = make_float2(st_s + t.x, st_q + t.y);
+      }
+      return;
+    }
     float2 sq[NT][4];
 #pragma unroll
     for (int a = 0; a < NT; ++a) {
@@ -779,6 +806,7 @@ void launch_c3_gn(const ConvParams& p, hipStream_t s) {
 static inline int c3_tile_w(const ConvParams& p) { return (p.w_par ? p.Win : p.Wout) >= 16 ? 16 : 8; }
 
 int conv3x3_stats_blocks(const ConvParams& p) {
+  if (conv3x3p_selected(p)) return conv3x3p_stats_blocks(p);
   const int TW = c3_tile_w(p);
   const int Ht = p.w_par ? p.Hin : p.Hout, Wt = p.w_par ? p.Win : p.Wout;
   // 8x16 tiles (wide kernel): one block per workgroup; 8x8 tiles: one per wave half
@@ -831,6 +859,7 @@ int conv3x3_splitk_plan(const ConvParams& p) {
 void launch_conv3x3(const ConvParams& p, hipStream_t s) {
   LDIFF_CHECK(p.splitk <= 1 || (p.splitk_ws && !p.stats), LDIFF_ERR_INVALID, "conv3x3: split-K needs a workspace and cannot emit fused statistics");
   LDIFF_CHECK(!p.w_par || (p.ups == 1 && p.splitk <= 1), LDIFF_ERR_INVALID, "conv3x3: parity weights need ups=1 and no split-K");
+  if (conv3x3p_selected(p)) { launch_conv3x3p(p, s); return; }
   const bool wide = c3_tile_w(p) == 16;
   const int bn = (p.N % 128 != 0 && p.N % 160 == 0) ? 160 : (p.N <= 32 ? 32 : (p.N <= 64 ? 64 : 128));
   if (wide) {

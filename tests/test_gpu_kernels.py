@@ -144,6 +144,14 @@ CONV_CASES = {
     "3x3_x16_upsample_parity": (8, 64, 0, 64, 64, 64, 3, 1, 1, False, False, True),
     "3x3_x16_upsample_parity_192ch": (8, 192, 0, 64, 64, 128, 3, 1, 1, False, False, False),
     "3x3_x16_single_slab": (8, 64, 0, 128, 128, 128, 3, 1, 0, False, True, False),
+    # persistent 16x16-tile kernel (kernels_conv3x3p.hip: no GroupNorm prologue, tile lists that fill the chip evenly): two tiles per
+    # workgroup, exactly one, ragged tiles on every border, 64- and 128-channel n-tiles, two n-tiles, parity folding
+    "3x3_p16_128_128_res": (8, 128, 0, 128, 128, 128, 3, 1, 0, False, False, True),
+    "3x3_p16_one_tile_per_workgroup": (1, 128, 0, 256, 256, 128, 3, 1, 0, False, False, True),
+    "3x3_p16_ragged_72x88": (8, 64, 0, 72, 88, 128, 3, 1, 0, False, False, True),
+    "3x3_p16_bn64_concat": (8, 64, 64, 128, 128, 64, 3, 1, 0, False, False, False),
+    "3x3_p16_two_ntiles_256": (4, 64, 0, 128, 128, 256, 3, 1, 0, False, False, True),
+    "3x3_p16_upsample_parity_ragged": (8, 64, 0, 56, 72, 128, 3, 1, 1, False, False, False),
 }
 
 
@@ -354,6 +362,8 @@ FUSED_STATS_CASES = {
     "gemm_dma_1x1": (2, 128, 16, 16, 256, 1, 1),
     "igemm_stride2": (2, 64, 32, 32, 64, 3, 2),
     "conv3x3_x16_tile": (8, 64, 128, 128, 128, 3, 1),
+    "conv3x3_p16_one_tile_per_workgroup": (1, 64, 256, 256, 128, 3, 1),
+    "conv3x3_p16_ragged_72x88": (8, 64, 72, 88, 128, 3, 1),
 }
 
 
@@ -446,6 +456,11 @@ SPLIT_CASES = {
     "wide3x3_split_operand": (1, 64, 0, 16, 16, 96, 3, 1, 0, True, False),             # PREC_FULL conv on a normalised split operand
     "x16_hi_operand_gn": (8, 128, 0, 128, 128, 128, 3, 1, 0, False, True),             # large map, two slabs, split tensors
     "x16_split_operand_upsample": (8, 64, 0, 64, 64, 64, 3, 1, 1, True, False),
+    # persistent 16x16-tile kernel with every epilogue option at once (split residual, split output, fused statistics)
+    "p16_split_operand_res_lo_stats": (8, 64, 0, 128, 128, 128, 3, 1, 0, True, False),
+    "p16_hi_operand_res_lo_stats": (8, 128, 0, 128, 128, 128, 3, 1, 0, False, False),
+    "p16_split_operand_one_tile_per_workgroup": (1, 64, 0, 256, 256, 128, 3, 1, 0, True, False),
+    "p16_split_operand_ragged_40x100": (8, 64, 0, 40, 100, 128, 3, 1, 0, True, False),
 }
 
 
@@ -530,6 +545,62 @@ def test_conv_on_split_tensors(lib, name):
         gotn = got.float() * scale.cpu()[:, :, None, None] + shift.cpu()[:, :, None, None]
         refn = F.group_norm(got.float(), 32, gamma, beta, 1e-5)
         assert (gotn - refn).abs().max() <= 2e-4 * max(1.0, refn.abs().max())
+
+
+@pytest.mark.parametrize("shape", ["one_tile_per_workgroup", "two_tiles_per_workgroup"])
+@pytest.mark.parametrize("res,lo,stats", [(r, l, s_) for r in (0, 1) for l in (0, 1) for s_ in (0, 1)])
+def test_conv3x3_persistent_kernel_epilogue_configs(lib, shape, res, lo, stats):
+    """Every epilogue configuration the persistent 16x16-tile kernel is instantiated for (residual x split output x fused statistics), on
+    a tile list with exactly one tile per workgroup (prologue -> last step -> epilogue with nothing in between) and with two.  Three
+    launches each: the kernel's two wave groups run half a step apart, and a missing wait shows up as a now-and-then wrong patch."""
+    B, Cin, H, W, Cout = (1, 64, 256, 256, 128) if shape == "one_tile_per_workgroup" else (8, 64, 128, 128, 128)
+    g = torch.Generator().manual_seed(res * 4 + lo * 2 + stats)
+    x = torch.randn((B, H, W, Cin), generator=g).to(torch.float16)
+    w = (torch.randn((Cout, 3, 3, Cin), generator=g) / math.sqrt(9 * Cin)).to(torch.float16)
+    bias = torch.randn(Cout, generator=g) * 0.1
+    ref = F.conv2d(x.float().permute(0, 3, 1, 2), w.float().permute(0, 3, 1, 2), bias, padding=1)
+    xd, wd, bd = x.to(DEV), w.reshape(Cout, -1).contiguous().to(DEV), bias.to(DEV)
+    a_ = _lib.ConvArgs()
+    a_.x, a_.C1, a_.B, a_.Hin, a_.Win, a_.Hout, a_.Wout = xd.data_ptr(), Cin, B, H, W, H, W
+    a_.ks, a_.stride, a_.pad_t, a_.pad_l = 3, 1, 1, 1
+    a_.w, a_.N, a_.Nrows, a_.bias = wd.data_ptr(), Cout, Cout, bd.data_ptr()
+    ld = 2 * Cout if lo else Cout
+    y = torch.empty((B, H, W, ld), dtype=torch.float16, device=DEV)
+    a_.y, a_.ldy, a_.y_lo = y.data_ptr(), ld, Cout if lo else 0
+    if res:
+        r = (torch.randn((B, H, W, Cout), generator=g) * 2.0).to(torch.float16)
+        rd = r.to(DEV)
+        a_.res, a_.ld_res = rd.data_ptr(), Cout
+        ref = ref + r.float().permute(0, 3, 1, 2)
+    if stats:
+        R = lib.ldiff_op_conv_stats_blocks(C.byref(a_))
+        assert R > 0
+        st = torch.empty((B, Cout, R, 2), device=DEV)
+        a_.stats = st.data_ptr()
+    gamma, beta = torch.ones(Cout), torch.zeros(Cout)
+    for it in range(3):
+        y.fill_(float("nan"))
+        if stats:
+            st.fill_(float("nan"))
+        _lib.check(lib.ldiff_op_conv(C.byref(a_), sp()))
+        torch.cuda.synchronize()
+        yc = y.float().cpu()
+        got = (yc[..., :Cout] + (yc[..., Cout:] if lo else 0.0)).permute(0, 3, 1, 2)
+        assert torch.isfinite(got).all(), f"launch {it}: non-finite output"
+        err = (got - ref).abs().max().item() / ref.abs().max().item()
+        assert err <= (2e-5 if lo else 1e-3), f"launch {it}: rel err {err:.3e}"
+        if lo:   # the lo half is a rounding remainder: anything larger is a sum that was read before it was complete
+            assert yc[..., Cout:].abs().max() <= 2.0 ** -10 * max(1.0, yc[..., :Cout].abs().max().item())
+        if stats:
+            scale, shift = torch.empty((B, Cout), device=DEV), torch.empty((B, Cout), device=DEV)
+            gd, btd = gamma.to(DEV), beta.to(DEV)
+            _lib.check(lib.ldiff_op_gn_finalize(st.data_ptr(), R, Cout, None, 0, 0, B, H * W, 32, 1e-5, gd.data_ptr(), btd.data_ptr(),
+                                                scale.data_ptr(), shift.data_ptr(), sp()))
+            torch.cuda.synchronize()
+            seen = got if lo else yc[..., :Cout].permute(0, 3, 1, 2)   # statistics describe what the consumer reads
+            gotn = seen * scale.cpu()[:, :, None, None] + shift.cpu()[:, :, None, None]
+            refn = F.group_norm(seen, 32, gamma, beta, 1e-5)
+            assert (gotn - refn).abs().max() <= 2e-4 * max(1.0, refn.abs().max().item()), f"launch {it}: fused statistics"
 
 
 def test_split_operand_beats_plain_operand(lib):

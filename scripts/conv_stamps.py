@@ -30,6 +30,10 @@ for name, (B, Cin, H, Cout, gn) in SHAPES.items():
     a.w, a.N, a.Nrows, a.bias, a.y, a.ldy = w.data_ptr(), Cout, Cout, bias.data_ptr(), y.data_ptr(), Cout
     if gn:
         a.gn_scale, a.gn_shift, a.silu_in = sc.data_ptr(), sh.data_ptr(), 1
+    if os.environ.get('LDIFF_BENCH_STATS'):   # with fused GroupNorm statistics (epilogue configuration 4)
+        R = lib.ldiff_op_conv_stats_blocks(C.byref(a))
+        st = torch.empty((B, Cout, R, 2), device='cuda')
+        a.stats = st.data_ptr()
     for _ in range(3):
         _lib.check(lib.ldiff_op_conv(C.byref(a), sp))
     torch.cuda.synchronize()

@@ -19,6 +19,8 @@ def load(d, counter):
 def bench_name(k):
     m = re.search(r"conv3x3w_kernel<(\d+), (true|false)>", k)
     if m: return f"conv3x3<8x16,{m.group(1)}{',gn' if m.group(2) == 'true' else ''}>"
+    m = re.search(r"conv3x3p_kernel<(\d+), (true|false), (\d+)>", k)   # persistent 16x16 kernel: every epilogue configuration / parity mode of a tile width
+    if m: return f"conv3x3<16x16,{m.group(1)}>"
     m = re.search(r"conv3x3_kernel<(\d+), (\d+), (\d+), (true|false)>", k)
     if m: return f"conv3x3<{m.group(1)}x{m.group(2)},{m.group(3)}{',gn' if m.group(4) == 'true' else ''}>"
     m = re.search(r"gemm_dma_kernel<(\d+), (\d+)>", k)
@@ -35,10 +37,14 @@ out = {"_note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes,
                 "(2*FETCH_SIZE + WRITE_SIZE)*1024: gfx950 reports half the bytes of 16 B/lane streaming reads (MI355X_MICROARCH.md, HBM); "
                 "the factor was calibrated on the conv3x3 kernel with a known byte count (128->128 at 8x512x512: FETCH_SIZE 264.5 MB "
                 "for 537 MB of input).", "kernels": {}}
+agg = defaultdict(lambda: [0.0, 0, 0.0, 0])   # several kernel instantiations can share one bench row
 for k, (fs, n) in fetch.items():
     name = bench_name(k)
     if not name or k not in write or n == 0: continue
     ws, wn = write[k]
+    a = agg[name]
+    a[0] += fs; a[1] += n; a[2] += ws; a[3] += wn
+for name, (fs, n, ws, wn) in agg.items():
     f_kb, w_kb = fs / n, ws / max(wn, 1)
     out["kernels"][name] = dict(dispatches=n, fetch_kb=round(f_kb, 1), write_kb=round(w_kb, 1), traffic_bytes=round((2 * f_kb + w_kb) * 1024))
 json.dump(out, open(sys.argv[3], "w"), indent=1)

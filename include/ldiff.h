@@ -250,6 +250,18 @@ int ldiff_op_attention_bwd(const void* q, int ldq, const void* k, int ldk, const
 /* one AdamW update of n f32 parameters (torch.optim.AdamW semantics; step counts from 1) */
 int ldiff_op_adamw(void* p, const void* g, void* m, void* v, int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay, int step,
                    void* stream);
+/* Weight layouts of the training step (the float32 master [Cout, Cin, k, k] of torch / diffusers -> what ldiff_op_conv reads):
+ *   mode 0, forward: dst[n][ky][kx][c] = w[n][c][ky][kx]           rows >= Cout, Cpad >= Cin, the rest zero
+ *   mode 1, dgrad:   dst[c][ky][kx][n] = w[n][c][k-1-ky][k-1-kx]   rows >= Cin,  Cpad >= Cout, the rest zero
+ * and back: the wgrad GEMM's g[n][tap*Cx + c] (row pitch ldg) -> dw[n][c][ky][kx] (loss.backward() of /root/reference/ldiffusion.py:254). */
+int ldiff_op_pack_weight(const void* w_f32, void* dst_f16, int Cout, int Cin, int k, int rows, int Cpad, int mode, void* stream);
+int ldiff_op_unpack_wgrad(const void* g_f32, void* dw_f32, int Cout, int Cin, int k, int Cx, int ldg, void* stream);
+
+/* All parameters of a model in one launch (the reference's optimiser step, /root/reference/ldiffusion.py:168-171,255: engine.step()).
+ * Device tables: tensors[t] = {float* p, float* m, float* v, int64 n} (32 bytes), grads[t] = const float* (gradient of tensor t),
+ * chunks[c] = {int32 tensor, int32 pad, int64 first element} (16 bytes): workgroup c updates elements [first, first + 16384) of its tensor. */
+int ldiff_op_adamw_multi(const void* tensors, const void* grads, const void* chunks, int64_t nchunks, float lr, float beta1, float beta2, float eps,
+                         float weight_decay, int step, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Live measurement for bench.py's roofline line: when enabled, every conv/linear, attention and

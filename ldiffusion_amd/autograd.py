@@ -32,14 +32,24 @@ def _check_act(x, what):
         raise ValueError(f"{what} must be a contiguous float16 CUDA tensor")
 
 
-def pack_weight(w: torch.Tensor) -> torch.Tensor:
-    """[Cout, Cin, k, k] (or [out, in]) float32 -> the kernel layout [roundup(Cout,16)][k*k*roundup(Cin,8)] float16 (rows >= Cout zero)."""
+def pack_weight(w: torch.Tensor, dgrad: bool = False, cols: int | None = None) -> torch.Tensor:
+    """[Cout, Cin, k, k] (or [out, in]) float32 -> the kernel layout, float16, one launch (ldiff_op_pack_weight):
+    forward  [roundup(Cout,16)][k*k*roundup(Cin,8)]        rows >= Cout zero;
+    dgrad    [roundup(cols_x,16)][k*k*cols]  = the weights rearranged to [Cin][k][k][Cout] with the taps flipped (`cols` = channels of dy)."""
+    lib = _lib.load()
+    w = w.detach()
     if w.dim() == 2:
         w = w[:, :, None, None]
+    if not (w.is_cuda and w.dtype == torch.float32 and w.is_contiguous()):
+        w = w.float().contiguous()
     Cout, Cin, k, _ = w.shape
-    out = torch.zeros((_r(Cout, 16), k, k, _r(Cin, 8)), dtype=torch.float16, device=w.device)
-    out[:Cout, :, :, :Cin] = w.detach().permute(0, 2, 3, 1).to(torch.float16)
-    return out.reshape(out.shape[0], -1)
+    if dgrad:
+        rows, cp = _r(_r(Cin, 8), 16), (cols if cols is not None else _r(Cout, 8))
+    else:
+        rows, cp = _r(Cout, 16), _r(Cin, 8)
+    out = torch.empty((rows, k * k * cp), dtype=torch.float16, device=w.device)
+    _lib.check(lib.ldiff_op_pack_weight(w.data_ptr(), out.data_ptr(), Cout, Cin, k, rows, cp, int(dgrad), _sp()))
+    return out
 
 
 def _conv_call(x, w16, Cout, k, stride, ups, bias=None, Ho=None, Wo=None, out_f32=False, pad=None):
@@ -56,12 +66,16 @@ def _conv_call(x, w16, Cout, k, stride, ups, bias=None, Ho=None, Wo=None, out_f3
     a.w, a.N, a.Nrows = w16.data_ptr(), _r(Cout, 4), w16.shape[0]
     keep = []
     if bias is not None:
-        b = torch.zeros(w16.shape[0], dtype=torch.float32, device=x.device)
-        b[:Cout] = bias.detach().float()
+        b = bias.detach()
+        if not (b.dtype == torch.float32 and b.is_contiguous() and b.numel() == w16.shape[0]):   # the kernel reads Nrows floats
+            bp = torch.zeros(w16.shape[0], dtype=torch.float32, device=x.device)
+            bp[:Cout] = b.float()
+            b = bp
         a.bias = b.data_ptr()
         keep.append(b)
     ld = _r(Cout, 4) if out_f32 else _r(Cout, 8)
-    y = torch.zeros((B, Ho, Wo, ld), dtype=torch.float32 if out_f32 else torch.float16, device=x.device)
+    alloc = torch.empty if ld == _r(Cout, 4) else torch.zeros   # the kernel writes roundup(Cout, 4) columns; pad columns beyond must be zero
+    y = alloc((B, Ho, Wo, ld), dtype=torch.float32 if out_f32 else torch.float16, device=x.device)
     a.y, a.ldy, a.out_f32 = y.data_ptr(), ld, int(out_f32)
     _lib.check(lib.ldiff_op_conv(C.byref(a), _sp()))
     return y
@@ -94,14 +108,13 @@ class Conv2dFn(torch.autograd.Function):
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             # dgrad: conv (stride 1) of dy -- zero-inserted for a stride-2 forward -- with the weights [Cin][k][k][Cout], taps flipped
-            wd = torch.zeros((_r(Cx, 16), k, k, Cy), dtype=torch.float16, device=x.device)
-            wd[:Cin, :, :, :Cout] = w4.detach().flip(2, 3).permute(1, 2, 3, 0).to(torch.float16)
+            wd = pack_weight(w4, dgrad=True, cols=Cy)
             g = dy
             He, We = H << ups, W << ups
             if stride == 2:
                 g = torch.zeros((B, He, We, Cy), dtype=torch.float16, device=x.device)
                 g[:, ::2, ::2] = dy
-            dxu = _conv_call(g, wd.reshape(wd.shape[0], -1), Cx, k, 1, 0)
+            dxu = _conv_call(g, wd, Cx, k, 1, 0)
             dx = dxu if ups == 0 else dxu.view(B, H, 2, W, 2, Cx).float().sum((2, 4)).to(torch.float16)
         if ctx.needs_input_grad[1]:
             # wgrad: dW[n][tap*Cx + c] = sum_m dy[m, n] * xcol[m, tap*Cx + c]  as a GEMM over K = M
@@ -110,12 +123,13 @@ class Conv2dFn(torch.autograd.Function):
             Kc = k * k * Cx
             dyT = torch.empty((Cy, Mpad), dtype=torch.float16, device=x.device)
             _lib.check(lib.ldiff_op_transpose(dy.data_ptr(), dyT.data_ptr(), M, Cy, Cy, Mpad, _sp()))
-            xcolT = torch.zeros((_r(Kc, 16), Mpad), dtype=torch.float16, device=x.device)
+            xcolT = torch.empty((_r(Kc, 16), Mpad), dtype=torch.float16, device=x.device)   # im2col_t writes rows < Kc (columns >= M zero)
+            if xcolT.shape[0] > Kc:
+                xcolT[Kc:].zero_()
             _lib.check(lib.ldiff_op_im2col_t(x.data_ptr(), xcolT.data_ptr(), B, H, W, Cx, k, stride, k // 2, ups, Ho, Wo, Mpad, _sp()))
             g = _conv_call(dyT.view(1, 1, Cy, Mpad), xcolT, Kc, 1, 1, 0, out_f32=True)        # [1,1,Cy,Kc] f32
-            dw = g.view(Cy, -1)[:Cout, :Kc].view(Cout, k, k, Cx)[..., :Cin].permute(0, 3, 1, 2).contiguous()
-            if weight.dim() == 2:
-                dw = dw[:, :, 0, 0]
+            dw = torch.empty(weight.shape, dtype=torch.float32, device=x.device)
+            _lib.check(lib.ldiff_op_unpack_wgrad(g.data_ptr(), dw.data_ptr(), Cout, Cin, k, Cx, g.shape[-1], _sp()))
         if has_bias and ctx.needs_input_grad[2]:
             db = torch.empty(Cy, dtype=torch.float32, device=x.device)
             _lib.check(lib.ldiff_op_colsum(dy.data_ptr(), db.data_ptr(), B * Ho * Wo, Cy, Cy, _sp()))
@@ -250,19 +264,38 @@ class AttentionFn(torch.autograd.Function):
         return dq, dk, dv, None
 
 
+ADAMW_CHUNK = 16384   # elements per workgroup of ldiff_op_adamw_multi (csrc/common.h)
+
+
 def adamw_step(params, grads, state, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01):
     """One AdamW update (torch.optim.AdamW semantics; the reference's DeepSpeed config, ldiffusion.py:168-171) of float32 CUDA
-    parameters, in place.  `state` is a dict the caller keeps: it holds the step count and the two moment buffers per parameter."""
+    parameters, in place, ALL tensors in one launch (ldiff_op_adamw_multi).  `state` is a dict the caller keeps: the step count, the two
+    moment buffers per parameter and the device tables of the launch (parameter / moment pointers and the chunk list are built once;
+    only the gradient pointers change from step to step)."""
     lib = _lib.load()
     state["step"] = state.get("step", 0) + 1
-    for i, (p, g) in enumerate(zip(params, grads)):
-        if g is None:
-            continue
+    live = [(i, p, g) for i, (p, g) in enumerate(zip(params, grads)) if g is not None]
+    if not live:
+        return
+    dev = live[0][1].device
+    for i, p, g in live:
         if not (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous()):
             raise ValueError("adamw_step: parameters must be contiguous float32 CUDA tensors")
         if i not in state:
             state[i] = (torch.zeros_like(p), torch.zeros_like(p))
-        m, v = state[i]
-        g = g.detach().to(torch.float32).contiguous()
-        _lib.check(lib.ldiff_op_adamw(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), float(lr), float(betas[0]), float(betas[1]), float(eps),
-                                      float(weight_decay), int(state["step"]), _sp()))
+    key = tuple((i, p.data_ptr(), p.numel()) for i, p, _ in live)
+    tab = state.get("_tables")
+    if tab is None or tab[0] != key:
+        tensors, chunks = [], []
+        for t, (i, p, _) in enumerate(live):
+            m, v = state[i]
+            tensors += [p.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel()]
+            for first in range(0, p.numel(), ADAMW_CHUNK):
+                chunks += [t, first]        # {int32 tensor, int32 pad} packed into one int64 (little endian), then int64 first
+        tab = (key, torch.tensor(tensors, dtype=torch.int64).to(dev), torch.tensor(chunks, dtype=torch.int64).to(dev), len(chunks) // 2)
+        state["_tables"] = tab
+    keep = [g.detach().to(torch.float32).contiguous() for _, _, g in live]
+    gptr = torch.tensor([g.data_ptr() for g in keep], dtype=torch.int64).to(dev)
+    _lib.check(lib.ldiff_op_adamw_multi(tab[1].data_ptr(), gptr.data_ptr(), tab[2].data_ptr(), tab[3], float(lr), float(betas[0]), float(betas[1]), float(eps),
+                                        float(weight_decay), int(state["step"]), _sp()))
+    state["_keep"] = (keep, gptr)   # the launch is asynchronous: the pointer table and converted gradients must outlive it

@@ -556,6 +556,27 @@ int ldiff_op_adamw(void* p, const void* g, void* m, void* v, int64_t n, float lr
   launch_adamw((float*)p, (const float*)g, (float*)m, (float*)v, n, lr, beta1, beta2, eps, weight_decay, step, (hipStream_t)stream);
   API_END
 }
+int ldiff_op_pack_weight(const void* w_f32, void* dst_f16, int Cout, int Cin, int k, int rows, int Cpad, int mode, void* stream) {
+  API_BEGIN
+  LDIFF_CHECK(w_f32 && dst_f16 && Cout >= 1 && Cin >= 1 && (k == 1 || k == 3) && (mode == 0 || mode == 1) && rows >= (mode ? Cin : Cout) &&
+                  Cpad >= (mode ? Cout : Cin), LDIFF_ERR_INVALID, "op_pack_weight: bad arguments");
+  launch_pack_weight((const float*)w_f32, (f16*)dst_f16, Cout, Cin, k, rows, Cpad, mode, (hipStream_t)stream);
+  API_END
+}
+int ldiff_op_unpack_wgrad(const void* g_f32, void* dw_f32, int Cout, int Cin, int k, int Cx, int ldg, void* stream) {
+  API_BEGIN
+  LDIFF_CHECK(g_f32 && dw_f32 && Cout >= 1 && Cin >= 1 && (k == 1 || k == 3) && Cx >= Cin && ldg >= k * k * Cx, LDIFF_ERR_INVALID, "op_unpack_wgrad: bad arguments");
+  launch_unpack_wgrad((const float*)g_f32, (float*)dw_f32, Cout, Cin, k, Cx, ldg, (hipStream_t)stream);
+  API_END
+}
+int ldiff_op_adamw_multi(const void* tensors, const void* grads, const void* chunks, int64_t nchunks, float lr, float beta1, float beta2, float eps,
+                         float weight_decay, int step, void* stream) {
+  API_BEGIN
+  LDIFF_CHECK(nchunks >= 0 && (nchunks == 0 || (tensors && grads && chunks)), LDIFF_ERR_INVALID, "op_adamw_multi: bad arguments");
+  launch_adamw_multi((const AdamTensor*)tensors, (const float* const*)grads, (const AdamChunk*)chunks, nchunks, lr, beta1, beta2, eps, weight_decay, step,
+                     (hipStream_t)stream);
+  API_END
+}
 int ldiff_op_geglu(const void* x, void* y, int64_t M, int C4, void* stream) {
   API_BEGIN
   LDIFF_CHECK(x && y, LDIFF_ERR_INVALID, "op_geglu: null argument");

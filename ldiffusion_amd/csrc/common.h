@@ -162,6 +162,14 @@ void launch_gn_train_bwd(const f16* x, const f16* dy, const float* gamma, const 
 void launch_ln_bwd(const f16* x, const f16* dy, const float* gamma, f16* dx, float* dgamma, float* dbeta, int rows, int C, float eps, hipStream_t s);
 void launch_geglu_bwd(const f16* x, const f16* dy, f16* dx, long long M, int C4, hipStream_t s);
 void launch_attn_bwd(const AttnParams& p, const f16* dO, f16* dq, f16* dk, f16* dv, hipStream_t s);
+void launch_pack_weight(const float* w, f16* dst, int Cout, int Cin, int k, int R, int Cp, int mode, hipStream_t s);
+void launch_unpack_wgrad(const float* g, float* dw, int Cout, int Cin, int k, int Cx, int ldg, hipStream_t s);
+// multi-tensor AdamW (kernels_bwd.hip): device tables built by the host side (ldiffusion_amd/autograd.py)
+#define ADAMW_CHUNK 16384
+struct AdamTensor { float* p; float* m; float* v; long long n; };
+struct AdamChunk { int tensor; int pad; long long first; };
+void launch_adamw_multi(const AdamTensor* tensors, const float* const* grads, const AdamChunk* chunks, long long nchunks, float lr, float b1, float b2, float eps,
+                        float wd, int step, hipStream_t s);
 void launch_adamw(float* p, const float* g, float* m, float* v, long long n, float lr, float b1, float b2, float eps, float wd, int step, hipStream_t s);
 
 // ---- device arena: bump/free-list allocator over one hipMalloc'd slab ------------------------

@@ -46,6 +46,10 @@ SHAPES = {
     "lin_L2_ff2_5120_1280": (1, 5120, 0, 1, 2048, 1280, 1, 1, 0, 0),
     "conv1x1_L0_320_320_gn": (8, 320, 0, 64, 64, 320, 1, 1, 0, 1),
     "down_L0_320_320_s2": (8, 320, 0, 64, 64, 320, 3, 2, 0, 0),
+    "down_L1_640_640_s2": (8, 640, 0, 32, 32, 640, 3, 2, 0, 0),
+    "down_vae_128_128_s2": (8, 128, 0, 512, 512, 128, 3, 2, 0, 0),
+    "down_vae_256_256_s2": (8, 256, 0, 256, 256, 256, 3, 2, 0, 0),
+    "down_vae_512_512_s2": (8, 512, 0, 128, 128, 512, 3, 2, 0, 0),
 }
 # name: (B, heads, Lq, Lk, d)
 ATTN = {

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define LDIFF_VERSION 110 /* 0.1.1 */
+#define LDIFF_VERSION 120 /* 0.1.2: + ldiff_op_adamw_multi, ldiff_op_pack_weight, ldiff_op_unpack_wgrad */
 #define LDIFF_MAX_BLOCKS 8
 
 typedef enum { LDIFF_OK = 0, LDIFF_ERR_INVALID = -1, LDIFF_ERR_RUNTIME = -2, LDIFF_ERR_STATE = -3 } ldiff_status;

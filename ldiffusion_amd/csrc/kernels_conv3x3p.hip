@@ -1,5 +1,6 @@
-// 3x3 stride-1 convolution for gfx950, persistent "ping-pong" variant for the large feature maps (VAE decoder / encoder levels,
-// UNet level 0): the dominant kernel of the sampling path.
+// 3x3 stride-1 convolution for gfx950, persistent "ping-pong" variant for the large feature maps WITHOUT a GroupNorm prologue (the
+// nearest-2x upsampling convs of the VAE decoder, the PREC_FULL convs of the VAE encoder on normalised operands): 35 of the 285
+// conv3x3 launches of a bench step; the others stay on the 8 x 16 kernel (kernels_conv3x3.hip), see conv3x3p_selected.
 //
 // Same algorithm and operand images as conv3x3w_kernel (kernels_conv3x3.hip: one halo image per 64-channel slab, one MFMA step per tap
 // on the shifted halo, weight slices by LDS-DMA), but ONE persistent 512-thread workgroup per CU that walks a list of 16 x 16-pixel
@@ -9,7 +10,7 @@
 //      group A   compute(k)   | load(k)      | compute(k+1) | load(k+1)    |        `|` = s_barrier of the whole workgroup
 //      group B   load(k-1)    | compute(k)   | load(k)      | compute(k+1) |
 //
-// so on every SIMD one wave is in its matrix segment (16 ds_read_b128 + 32 MFMA, nothing else) while its partner is in its load
+// so on every SIMD one wave is in its matrix segment (32 MFMA + the 8 operand reads of the second k-half) while its partner is in its load
 // segment.  Measured before this kernel (profiles/r01_conv3x3_issue_profile.md, MI355X_MICROARCH.md "Two waves per SIMD"): with two
 // independent 256-thread workgroups per CU the matrix segments of co-resident waves coincide (MFMA busy 41 % of the cycles), and a
 // non-persistent 16 x 16 tile pays 8-13 us of un-overlapped prologue + epilogue per tile (as much as the 18 steps of a 128-channel layer).

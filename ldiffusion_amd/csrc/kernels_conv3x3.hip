@@ -493,10 +493,10 @@ __global__ __launch_bounds__(256, BN > 128 ? 1 : 2) void conv3x3w_kernel(const C
         float fx = 0.f;                       // even element waiting for its odd neighbour
         unsigned pk[NE > 0 ? NE / 2 : 1];     // normalised elements, packed f16 pairs
         f16x8 wf[2][NT], xf[2][MT];
+        // k-half 0 up front; the k-half-1 reads go out between the first MFMA groups (an LDS instruction issues while the matrix pipe
+        // works: all sixteen in front of the first MFMA cost ~100 cycles of every step)
         static_for<0, MT>([&](auto mc) { constexpr int m = decltype(mc)::value; lds_read128<(m + kyi) * ROWB>(xf[0][m], xc[kxi]); });
         static_for<0, NT>([&](auto ac) { constexpr int a = decltype(ac)::value; lds_read128<a * 2048>(wf[0][a], wc[T & 1]); });
-        static_for<0, MT>([&](auto mc) { constexpr int m = decltype(mc)::value; lds_read128<(m + kyi) * ROWB>(xf[1][m], xc1[kxi]); });
-        static_for<0, NT>([&](auto ac) { constexpr int a = decltype(ac)::value; lds_read128<a * 2048>(wf[1][a], wc1[T & 1]); });
         __builtin_amdgcn_sched_barrier(0);
         // next step's weight slice -> the other slot (read last in the previous step); issued while the operand reads fly
         if (!LAST) issue_w(((T + 1) * Cin + c * 64) * 2, sp ^ (unsigned)((T + 1) & 1));
@@ -505,12 +505,16 @@ __global__ __launch_bounds__(256, BN > 128 ? 1 : 2) void conv3x3w_kernel(const C
         __builtin_amdgcn_sched_barrier(0);
         static_for<0, 2 * NT>([&](auto ic) {
           constexpr int kk = decltype(ic)::value / NT, a = decltype(ic)::value % NT;
-          constexpr int pending = (1 - kk) * NF + (NT - 1 - a);   // reads issued after W_a of this k-half
+          constexpr int WI = NT > 1 ? 1 : 0;   // the k-half-1 X reads follow group 0 of k-half 0, the W reads group WI
+          // reads issued after W_a of this k-half at the time of the wait
+          constexpr int pending = kk == 1 ? NT - 1 - a : (NT - 1 - a) + (a >= 1 ? MT : 0) + (a > WI ? NT : 0);
           if constexpr (a == 0) lds_wait<pending>(xf[kk][0], xf[kk][1], xf[kk][2], xf[kk][3], wf[kk][0]);
           else lds_wait<pending>(wf[kk][a]);
 #pragma unroll
           for (int m = 0; m < MT; ++m)
             acc[a][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[kk][a], xf[kk][m], acc[a][m], 0, 0, 0);
+          if constexpr (kk == 0 && a == 0) static_for<0, MT>([&](auto mc) { constexpr int m = decltype(mc)::value; lds_read128<(m + kyi) * ROWB>(xf[1][m], xc1[kxi]); });
+          if constexpr (kk == 0 && a == WI) static_for<0, NT>([&](auto bc) { constexpr int b2 = decltype(bc)::value; lds_read128<b2 * 2048>(wf[1][b2], wc1[T & 1]); });
           static_for<(kk == 1 ? a * EPG : NE), (kk == 1 ? ((a + 1) * EPG < NE ? (a + 1) * EPG : NE) : NE)>([&](auto ec) {
             constexpr int e = decltype(ec)::value;
             const float f = xform_elem(std::integral_constant<int, C0 + e / 8>{}, std::integral_constant<int, e % 8>{}, siluc);

@@ -100,7 +100,7 @@ def main():
         a.B, a.Hin, a.Win, a.Hout, a.Wout, a.ks, a.stride, a.pad_t, a.pad_l, a.ups = B, H, W, Ho, Wo, ks, stride, ks // 2, ks // 2, ups
         a.w, a.N, a.Nrows, a.bias = w.data_ptr(), Nst, Nrows, bias.data_ptr()
         if gn:
-            a.gn_scale, a.gn_shift, a.silu_in = sc.data_ptr(), sh.data_ptr(), 1
+            a.gn_scale, a.gn_shift, a.silu_in = sc.data_ptr(), sh.data_ptr(), int(os.environ.get("LDIFF_BENCH_SILU", "1"))
         a.y, a.ldy = y.data_ptr(), Nst
         if os.environ.get('LDIFF_BENCH_STATS'):
             R = lib.ldiff_op_conv_stats_blocks(C.byref(a))

@@ -78,6 +78,7 @@ struct ConvParams {
   int splitk;             // conv3x3 only: >1 => K (input-channel slabs) split over blockIdx.y, fp32 partials to splitk_ws
   float* splitk_ws;       // [splitk][M][N] fp32 workspace (then reduced + epilogue by splitk_reduce)
   const f16* w_par;       // conv3x3 with ups=1 only: parity weights [4][Nrows][4*Cin] (see kernels_conv3x3.hip); nullptr => 9-tap gather
+  unsigned div_ntn, div_tx, div_ty;   // conv3x3 8x16 kernel only, set by its launcher: reciprocals of its tile decode (0 = divisor 1)
 };
 void launch_igemm(const ConvParams& p, hipStream_t s);   // dispatches to the halo-tile 3x3 kernel when eligible
 bool conv3x3_eligible(const ConvParams& p);

@@ -343,11 +343,16 @@ __global__ __launch_bounds__(256, BN > 128 ? 1 : 2) void conv3x3w_kernel(const C
   int nwg = gridDim.x, id = blockIdx.x;
   int q8 = nwg >> 3, r8 = nwg & 7, xcd = id & 7, idx = id >> 3;
   int sw = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
-  const int tile_n = sw % ntn;
-  int tm = sw / ntn;
-  const int tx = tm % tiles_x; tm /= tiles_x;
-  const int ty = tm % tiles_y;
-  const int b = tm / tiles_y;
+  // tile decode with the launcher's reciprocals (q = umulhi(n, floor(2^32 / d) + 1), exact while n * d < 2^32): a run-time integer
+  // division is ~25 dependent scalar / vector instructions with a VALU -> SALU round trip, and three of them stood in front of the
+  // first halo load of every tile
+  auto fdiv = [](int n, unsigned m) { return m ? (int)__umulhi((unsigned)n, m) : n; };   // m = 0 encodes a divisor of 1
+  const int tm = fdiv(sw, p.div_ntn);
+  const int tile_n = sw - tm * ntn;
+  const int tq = fdiv(tm, p.div_tx);
+  const int tx = tm - tq * tiles_x;
+  const int b = fdiv(tq, p.div_ty);
+  const int ty = tq - b * tiles_y;
   const int n0 = tile_n * BN, oy0 = ty * TH, ox0 = tx * TW;
   const int sh = par ? 0 : p.ups;
   const int He = p.Hin << sh, We = p.Win << sh;
@@ -382,6 +387,13 @@ __global__ __launch_bounds__(256, BN > 128 ? 1 : 2) void conv3x3w_kernel(const C
       gt0 = *reinterpret_cast<const float4*>(st); gt1 = *reinterpret_cast<const float4*>(st + 4);
     }
   };
+  // the first slab's halo goes out before the rest of the set-up (weight descriptor, operand addresses, accumulators), which then runs
+  // under the global round trip
+  const int nslab_all = Cin >> 6, S = p.splitk > 1 ? p.splitk : 1, ksplit = blockIdx.y;
+  int c_begin = 0, nslab = nslab_all;
+  if (S > 1) { c_begin = ksplit * nslab_all / S; nslab = (ksplit + 1) * nslab_all / S; }
+  load_halo(c_begin);
+  __builtin_amdgcn_sched_barrier(0);
   const bool silu = p.silu_in != 0;
   auto xform_store = [&](auto ic, unsigned bufoff) {   // chunk i of the staged slab -> LDS (normalised, activated, masked)
     constexpr int i = decltype(ic)::value;
@@ -444,9 +456,6 @@ __global__ __launch_bounds__(256, BN > 128 ? 1 : 2) void conv3x3w_kernel(const C
   const int wrow = wave_n * (BN / 2) + l15;   // + a*16: same swizzle phase, +2048 B per a
   const unsigned w_lane = lds0 + W_OFF + (unsigned)(wrow * 128 + ((g ^ ((wrow >> 1) & 7)) << 4));
 
-  const int nslab_all = Cin / 64, S = p.splitk > 1 ? p.splitk : 1, ksplit = blockIdx.y;
-  const int c_begin = ksplit * nslab_all / S, nslab = (ksplit + 1) * nslab_all / S;
-  load_halo(c_begin);
   issue_w(c_begin * 128, 0);
   static_for<0, A_IT>([&](auto ic) { xform_store(ic, 0u); });
   __syncthreads();
@@ -787,7 +796,12 @@ void launch_c3w(const ConvParams& p, hipStream_t s) {
   // flops = MFMA work actually executed: parity mode (nearest-2x folded into 4 taps) runs 16/36 of the 9-tap MACs
   ProfScope prof(pname.c_str(), 2.0 * p.M * (double)p.N * p.K * (par ? 16.0 / 36.0 : 1.0), bytes, s);
   const int S = p.splitk > 1 ? p.splitk : 1;
-  hipLaunchKernelGGL(kern, dim3(tiles * ntn, S, par ? 4 : 1), dim3(256), smem, s, p);
+  const int tiles_x = (Wt + TW - 1) / TW, tiles_y = (Ht + TH - 1) / TH;
+  LDIFF_CHECK((long long)tiles * ntn * std::max(ntn, std::max(tiles_x, tiles_y)) < (1LL << 32), LDIFF_ERR_INVALID, "conv3x3: %d tiles x %d channel tiles exceed the tile decode's range", tiles, ntn);
+  ConvParams q = p;
+  auto recip = [](int d) { return d == 1 ? 0u : (unsigned)((1ULL << 32) / (unsigned)d + 1ULL); };   // 0 encodes a divisor of 1
+  q.div_ntn = recip(ntn); q.div_tx = recip(tiles_x); q.div_ty = recip(tiles_y);
+  hipLaunchKernelGGL(kern, dim3(tiles * ntn, S, par ? 4 : 1), dim3(256), smem, s, q);
   HIP_CHECK(hipGetLastError());
   if (S > 1) {
     const long long n = (long long)p.M * (p.N >> 2);

@@ -75,7 +75,7 @@ struct ConvParams {
   long long w_bstride;    // gemm_dma only: > 0 => one weight matrix (and bias vector, bias_bstride) PER IMAGE: image b = row / (Hout*Wout)
   int bias_bstride;       //   (GroupNorm folded into a 1x1 conv: W_b = W diag(scale_b), bias_b = bias + W shift_b); tiles never straddle images
   int geglu;              // gemm_dma only: weight rows are x/gate-interleaved by 16 (MatW::geglu); y[m, n/2..] = x * gelu_erf(gate), ldy counts the N/2 outputs
-  int splitk;             // conv3x3 only: >1 => K (input-channel slabs) split over blockIdx.y, fp32 partials to splitk_ws
+  int splitk;             // conv3x3 / igemm: >1 => K (input-channel slabs) split over blockIdx.y, fp32 partials to splitk_ws
   float* splitk_ws;       // [splitk][M][N] fp32 workspace (then reduced + epilogue by splitk_reduce)
   const f16* w_par;       // conv3x3 with ups=1 only: parity weights [4][Nrows][4*Cin] (see kernels_conv3x3.hip); nullptr => 9-tap gather
   unsigned div_ntn, div_tx, div_ty;   // conv3x3 8x16 kernel only, set by its launcher: reciprocals of its tile decode (0 = divisor 1)
@@ -83,6 +83,8 @@ struct ConvParams {
 void launch_igemm(const ConvParams& p, hipStream_t s);   // dispatches to the halo-tile 3x3 kernel when eligible
 bool conv3x3_eligible(const ConvParams& p);
 int conv3x3_splitk_plan(const ConvParams& p);
+int igemm_splitk_plan(const ConvParams& p);              // same contract for the register-staged implicit GEMM (stride-2 convs with few tiles)
+void launch_splitk_reduce(const ConvParams& p, hipStream_t s);   // sums p.splitk fp32 partials of splitk_ws and applies the epilogue
 // nearest-2x upsample + conv3x3 == four 2x2 convs on the source grid (one per output parity) with pre-summed taps:
 // w_par[q][n][t][c] from w[n][ky][kx][c]  (2.25x fewer MACs than gathering 9 taps from the upsampled image)
 void launch_make_parity_weights(const f16* w, f16* w_par, int Nrows, int Cin, hipStream_t s);                  // 1 = no split; >1 needs splitk_ws of splitk*M*N floats

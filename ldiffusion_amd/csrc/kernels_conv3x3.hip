@@ -755,6 +755,12 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const ConvParams p) 
   }
 }
 
+void launch_splitk_reduce_impl(const ConvParams& p, hipStream_t s) {
+  const long long n = (long long)p.M * (p.N >> 2);
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p);
+  HIP_CHECK(hipGetLastError());
+}
+
 template <int TH, int TW, int BN, bool GN>
 void launch_c3(const ConvParams& p, hipStream_t s) {
   constexpr int HP = (TH + 2) * (TW + 2);
@@ -860,6 +866,8 @@ bool conv3x3_eligible(const ConvParams& p) {
   return p.ks == 3 && p.stride == 1 && p.pad_t == 1 && p.pad_l == 1 && Cin % 64 == 0 && p.C1 % 64 == 0 && (long long)p.Nrows * 9 * Cin * 2 < (1LL << 32) &&
          p.Hout == (p.Hin << p.ups) && p.Wout == (p.Win << p.ups);
 }
+
+void launch_splitk_reduce(const ConvParams& p, hipStream_t s) { launch_splitk_reduce_impl(p, s); }
 
 int conv3x3_splitk_plan(const ConvParams& p) {
   if (p.w_par) return 1;

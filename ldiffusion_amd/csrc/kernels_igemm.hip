@@ -140,14 +140,17 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const ConvParams p) {   /
 #pragma unroll
     for (int b = 0; b < MT; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  const int nk = (p.K + BK - 1) / BK;
+  // split-K (few tiles, long K: the stride-2 convs of the deep UNet levels): blockIdx.y owns a contiguous range of K-steps and writes
+  // raw fp32 partials; splitk_reduce_kernel (kernels_conv3x3.hip) sums them and applies the epilogue
+  const int nk_all = (p.K + BK - 1) / BK, S = p.splitk > 1 ? p.splitk : 1, ksplit = blockIdx.y;
+  const int kt0 = S > 1 ? ksplit * nk_all / S : 0, nk = S > 1 ? (ksplit + 1) * nk_all / S : nk_all;
   const int g = lane >> 4, l15 = lane & 15;
 
-  load_tiles(0);
-  store_tiles(0);
+  load_tiles(kt0);
+  store_tiles(kt0 & 1);
   __syncthreads();
 
-  for (int kt = 0; kt < nk; ++kt) {
+  for (int kt = kt0; kt < nk; ++kt) {
     const int cur = kt & 1;
     if (kt + 1 < nk) load_tiles(kt + 1);
     const uint4* cA = sA + cur * BM * CPR;
@@ -179,6 +182,19 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const ConvParams p) {   /
   // Loads (bias, time embedding, residual) are issued back to back before any use: a load -> wait -> store chain per
   // 16x16 tile costs one memory round trip per tile.
   const int ncol = n0 + wave_n * (BN / 2) + g * 4;
+  if (S > 1) {
+#pragma unroll
+    for (int b = 0; b < MT; ++b) {
+      const int m = m0 + wave_m * (BM / 2) + b * 16 + l15;
+      if (m >= p.M) continue;
+#pragma unroll
+      for (int a = 0; a < NT; ++a) {
+        const int n = ncol + a * 16;
+        if (n < p.N) *reinterpret_cast<f32x4*>(p.splitk_ws + ((long long)ksplit * p.M + m) * p.N + n) = acc[a][b];
+      }
+    }
+    return;
+  }
   f32x4 bb[NT];
 #pragma unroll
   for (int a = 0; a < NT; ++a) {
@@ -262,8 +278,11 @@ static void launch_cfg(const ConvParams& p, hipStream_t s) {
   const double in_bytes = (double)p.B * p.Hin * p.Win * (p.C1 + p.C2) * esz;
   const double bytes = in_bytes + (double)p.N * p.K * esz + (double)p.M * p.N * (p.out_f32 || p.y_lo ? 4.0 : esz) + (p.res ? (double)p.M * p.N * (p.res_lo ? 4.0 : esz) : 0.0);
   ProfScope prof(pname.c_str(), 2.0 * p.M * (double)p.N * p.K, bytes, s);
-  hipLaunchKernelGGL(kern, dim3(ntm * ntn), dim3(256), smem, s, p);
+  const int S = p.splitk > 1 ? p.splitk : 1;
+  LDIFF_CHECK(S == 1 || (p.splitk_ws && !p.stats && !p.geglu), LDIFF_ERR_INVALID, "igemm: split-K needs a workspace and cannot emit fused statistics");
+  hipLaunchKernelGGL(kern, dim3(ntm * ntn, S), dim3(256), smem, s, p);
   HIP_CHECK(hipGetLastError());
+  if (S > 1) launch_splitk_reduce(p, s);
 }
 
 template <int BM, int BN>
@@ -280,6 +299,22 @@ int conv_stats_blocks_per_image(const ConvParams& p) {
   if (conv3x3_eligible(p)) return conv3x3_stats_blocks(p);
   const int hw = p.Hout * p.Wout;
   return hw % 32 == 0 ? hw / 32 : 0;
+}
+
+// Split-K for the register-staged kernel: only where its launcher picks 64x64 tiles, the tiles leave most workgroup slots empty and the
+// K loop is long (stride-2 3x3 convs of the UNet's 16x16 -> 8x8 level: 160 tiles x 180-360 K-steps)
+int igemm_splitk_plan(const ConvParams& p) {
+  if (p.out_f32 || p.stats || p.geglu || p.M <= 0) return 1;
+  if (conv3x3_eligible(p) || gemm_dma_eligible(p)) return 1;
+  auto tiles = [&](int bm, int bn) { return (long long)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn); };
+  if (tiles(128, 64) >= 384) return 1;
+  const int nk = (p.K + BK - 1) / BK;
+  auto splits = [&](long long t) { int S = (int)(512 / t); S = S > nk / 16 ? nk / 16 : S; return S > 8 ? 8 : S; };
+  // 128x64 tiles (half the operand bytes per flop of 64x64) when their splits fill the chip; launch_igemm picks the tile by tiles x S
+  const int S128 = splits(tiles(128, 64));
+  if (S128 >= 2 && tiles(128, 64) * S128 >= 384) return S128;
+  const int S64 = splits(tiles(64, 64));
+  return S64 >= 2 ? S64 : 1;
 }
 
 void launch_igemm(const ConvParams& p, hipStream_t s) {
@@ -302,9 +337,10 @@ void launch_igemm(const ConvParams& p, hipStream_t s) {
   LDIFF_CHECK(!p.geglu, LDIFF_ERR_INVALID, "GEGLU epilogue: only on 1x1 / linear layers with K %% 64 == 0, N %% 32 == 0, fp16 output, no residual");
   const bool fast = (Cin % BK == 0) && (p.C1 % BK == 0);
   // Tile choice: largest tile that still yields >= ~2 workgroups per CU worth of tiles; narrow N gets BN=64.
+  const int S = p.splitk > 1 ? p.splitk : 1;   // split-K multiplies the workgroups of a tile shape (igemm_splitk_plan)
   auto tiles = [&](int bm, int bn) { return (long long)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn); };
   const bool n_small = p.N <= 64 || (p.N % 128 != 0 && p.N % 128 <= 64 && p.N < 512);
-  if (!n_small && tiles(128, 128) >= 384) launch_bmn<128, 128>(p, fast, s);
-  else if (tiles(128, 64) >= 384) launch_bmn<128, 64>(p, fast, s);
+  if (!n_small && S == 1 && tiles(128, 128) >= 384) launch_bmn<128, 128>(p, fast, s);
+  else if (tiles(128, 64) * S >= 384) launch_bmn<128, 64>(p, fast, s);
   else launch_bmn<64, 64>(p, fast, s);
 }

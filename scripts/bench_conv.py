@@ -47,6 +47,10 @@ SHAPES = {
     "conv1x1_L0_320_320_gn": (8, 320, 0, 64, 64, 320, 1, 1, 0, 1),
     "down_L0_320_320_s2": (8, 320, 0, 64, 64, 320, 3, 2, 0, 0),
     "down_L1_640_640_s2": (8, 640, 0, 32, 32, 640, 3, 2, 0, 0),
+    "down_L2_1280_1280_s2": (8, 1280, 0, 16, 16, 1280, 3, 2, 0, 0),
+    "down_L2x2_2560_1280_s2": (8, 2560, 0, 16, 16, 1280, 3, 2, 0, 0),
+    "down_L1x2_1280_640_s2": (8, 1280, 0, 32, 32, 640, 3, 2, 0, 0),
+    "down_L0x2_640_320_s2": (8, 640, 0, 64, 64, 320, 3, 2, 0, 0),
     "down_vae_128_128_s2": (8, 128, 0, 512, 512, 128, 3, 2, 0, 0),
     "down_vae_256_256_s2": (8, 256, 0, 256, 256, 256, 3, 2, 0, 0),
     "down_vae_512_512_s2": (8, 512, 0, 128, 128, 512, 3, 2, 0, 0),

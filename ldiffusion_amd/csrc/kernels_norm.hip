@@ -168,6 +168,48 @@ void launch_gn_finalize(const float* part1, int R1, int C1, const float* part2, 
 
 static inline SrcView norm_view(SrcView v) { if (v.p && v.ld == 0) v.ld = v.C; return v; }
 
+// Small maps (UNet levels 1-3: 8x8 ... 32x32 pixels): statistics AND scale / shift in ONE launch.  grid (groups, B), block 256: the
+// workgroup reads the group's channels of every pixel (the 16-byte chunks that overlap [c0, c0 + Cg), elements outside masked; a chunk
+// never straddles the two sources because C1 % 8 == 0), fp32 per thread, fp64 across threads.  The two-launch form (partial + finalize)
+// costs 18-30 us on these tensors of 1-10 MB: both launches are latency-, not bandwidth-bound.
+__global__ __launch_bounds__(256) void gn_small_kernel(SrcView s1, SrcView s2, int HW, int groups, float eps, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, float* __restrict__ scale, float* __restrict__ shift) {
+  const int grp = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  const int C1 = s1.C, C = C1 + (s2.p ? s2.C : 0), Cg = C / groups, c0 = grp * Cg, c1 = c0 + Cg;
+  const int k0 = c0 >> 3, nk = ((c1 + 7) >> 3) - k0;   // chunks [k0, k0 + nk) overlap the group
+  const int items = HW * nk;
+  float a = 0.f, q = 0.f;
+  for (int i = tid; i < items; i += 256) {
+    const int pix = i / nk, k = k0 + (i - pix * nk), c = k * 8;
+    float f[8];
+    if (c < C1) load8(s1.p + ((long long)b * HW + pix) * s1.ld + c, s1.lo, f);
+    else load8(s2.p + ((long long)b * HW + pix) * s2.ld + (c - C1), s2.lo, f);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float v = (c + j >= c0 && c + j < c1) ? f[j] : 0.f;
+      a += v; q += v * v;
+    }
+  }
+  double da = (double)a, dq = (double)q;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { da += __shfl_xor(da, o); dq += __shfl_xor(dq, o); }
+  __shared__ double red[2][4];
+  if ((tid & 63) == 0) { red[0][tid >> 6] = da; red[1][tid >> 6] = dq; }
+  __syncthreads();
+  da = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+  dq = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+  const double n = (double)HW * Cg;
+  const double mean = da / n;
+  double var = dq / n - mean * mean;
+  if (var < 0.0) var = 0.0;
+  const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+  for (int c = c0 + tid; c < c1; c += 256) {
+    const float gsc = gamma[c] * rstd;
+    scale[(long long)b * C + c] = gsc;
+    shift[(long long)b * C + c] = beta[c] - (float)mean * gsc;
+  }
+}
+
 void launch_gn_stats(SrcView x1, SrcView x2, int B, int HW, int groups, float eps, const float* gamma,
                      const float* beta, float* partial, size_t partial_bytes, float* scale, float* shift, hipStream_t s) {
   x1 = norm_view(x1); x2 = norm_view(x2);
@@ -177,6 +219,12 @@ void launch_gn_stats(SrcView x1, SrcView x2, int B, int HW, int groups, float ep
   LDIFF_CHECK(x1.ld % 8 == 0 && x1.lo % 8 == 0 && (!x2.p || (x2.ld % 8 == 0 && x2.lo % 8 == 0)), LDIFF_ERR_INVALID, "gn_stats: pitches must be multiples of 8");
   LDIFF_CHECK(C % groups == 0, LDIFF_ERR_INVALID, "gn_stats: C=%d not divisible by groups=%d", C, groups);
   LDIFF_CHECK(gn_partial_bytes(B, HW, C) <= partial_bytes, LDIFF_ERR_INVALID, "gn_stats: workspace too small");
+  if (HW <= 1024 && B * groups >= 64) {   // small map, enough (image, group) workgroups: one launch
+    ProfScope prof("gn_stats", 3.0 * B * HW * (double)C, 2.0 * B * HW * ((double)C1 * (x1.lo ? 2 : 1) + (double)C2 * (x2.lo ? 2 : 1)), s);
+    hipLaunchKernelGGL(gn_small_kernel, dim3(groups, B), dim3(256), 0, s, x1, x2, HW, groups, eps, gamma, beta, scale, shift);
+    HIP_CHECK(hipGetLastError());
+    return;
+  }
   const int nchunk = gn_chunks(HW);
   const int pix = (HW + nchunk - 1) / nchunk;
   const size_t smem = 2 * 2048 * sizeof(float);  // [2][R][C] with R*C <= 256*8

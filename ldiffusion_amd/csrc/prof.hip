@@ -40,10 +40,13 @@ extern "C" int ldiff_prof_set_filter(const char* kernel_name_or_null) {
 extern "C" int ldiff_prof_collect(ldiff_prof_row* rows, int cap) {
   try {
     std::map<std::string, ldiff_prof_row> agg;
+    const bool dump = getenv("LDIFF_PROF_DUMP") != nullptr;   // diagnostic: one stderr line per launch, in launch order
     for (auto& r : g_recs) {
       HIP_CHECK(hipEventSynchronize(r.e1));
       float ms = 0.f;
       HIP_CHECK(hipEventElapsedTime(&ms, r.e0, r.e1));
+      if (dump) fprintf(stderr, "[ldiff_prof] %-28s %9.1f us %9.2f GFLOP %8.1f TFLOP/s %9.2f MB %7.1f GB/s\n", r.name.c_str(), ms * 1e3, r.flops * 1e-9,
+                        ms > 0 ? r.flops / (ms * 1e-3) * 1e-12 : 0.0, r.bytes * 1e-6, ms > 0 ? r.bytes / (ms * 1e-3) * 1e-9 : 0.0);
       auto it = agg.find(r.name);
       if (it == agg.end()) {
         ldiff_prof_row z;

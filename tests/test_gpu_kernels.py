@@ -285,6 +285,10 @@ GN_CASES = {
     "c32_cg1": (2, 32, 0, 1024, 32, 1e-6),
     "hw1": (2, 64, 0, 1, 32, 1e-5),
     "large_mean": (2, 64, 0, 4096, 32, 1e-5),
+    # one-launch small-map kernel (HW <= 1024, B * groups >= 64): groups of 20 / 60 channels cut through 16-byte chunks
+    "small_c640_cg20_hw1024": (4, 640, 0, 1024, 32, 1e-5),
+    "small_concat_1280_640_hw256": (8, 1280, 640, 256, 32, 1e-6),
+    "small_c2560_hw64": (8, 1280, 1280, 64, 32, 1e-5),
 }
 
 

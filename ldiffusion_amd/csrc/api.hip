@@ -431,7 +431,7 @@ int ldiff_op_conv(const ldiff_conv_args* a, void* stream) {
     p.w_par = wpar;
     if (p.stats) p.stats_R = conv_stats_blocks_per_image(p);
   }
-  if (!p.stats && !p.out_f32) p.splitk = conv3x3_eligible(p) ? conv3x3_splitk_plan(p) : igemm_splitk_plan(p);
+  if (!p.stats && !p.out_f32) p.splitk = conv3x3_eligible(p) ? conv3x3_splitk_plan(p) : gemm_dma_eligible(p) ? gemm_dma_splitk_plan(p) : igemm_splitk_plan(p);
   if (p.splitk > 1) p.splitk_ws = (float*)op_scratch(st, 1, (size_t)p.splitk * p.M * p.N * sizeof(float));
   launch_igemm(p, (hipStream_t)stream);
   API_END

@@ -83,6 +83,7 @@ struct ConvParams {
 void launch_igemm(const ConvParams& p, hipStream_t s);   // dispatches to the halo-tile 3x3 kernel when eligible
 bool conv3x3_eligible(const ConvParams& p);
 int conv3x3_splitk_plan(const ConvParams& p);
+int gemm_dma_splitk_plan(const ConvParams& p);           // ... and for the LDS-DMA GEMM (1x1 convs / linears with few tiles and a long K)
 int igemm_splitk_plan(const ConvParams& p);              // same contract for the register-staged implicit GEMM (stride-2 convs with few tiles)
 void launch_splitk_reduce(const ConvParams& p, hipStream_t s);   // sums p.splitk fp32 partials of splitk_ws and applies the epilogue
 // nearest-2x upsample + conv3x3 == four 2x2 convs on the source grid (one per output parity) with pre-summed taps:

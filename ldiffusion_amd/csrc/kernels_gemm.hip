@@ -124,8 +124,11 @@ __global__ __launch_bounds__(256, 2) void gemm_dma_kernel(const ConvParams p) {
   const unsigned wa = lds0 + W_OFF + (unsigned)(wrow * 128 + ((g ^ ((wrow >> 1) & 7)) << 4)), wa1 = wa ^ 64u;
   constexpr int NF = NT + MT;
 
-  const int nk = p.K / 64;
-  issue(0, std::integral_constant<int, 0>{});
+  // split-K (few tiles, long K: the concat shortcut convs of the 8x8 level): blockIdx.y owns a contiguous range of K-steps and writes raw
+  // fp32 partials; splitk_reduce_kernel sums them and applies the epilogue
+  const int nk_all = p.K / 64, S = p.splitk > 1 ? p.splitk : 1, ksplit = blockIdx.y;
+  const int kt0 = S > 1 ? ksplit * nk_all / S : 0, nk = S > 1 ? (ksplit + 1) * nk_all / S : nk_all;
+  issue(kt0, std::integral_constant<int, 0>{});
   __syncthreads();
   auto step = [&](int kt, auto bufc) {
     constexpr int buf = decltype(bufc)::value;
@@ -157,13 +160,26 @@ __global__ __launch_bounds__(256, 2) void gemm_dma_kernel(const ConvParams p) {
     });
     __syncthreads();   // drains the DMA issued in this step (vmcnt(0)) and protects the stage swap
   };
-  for (int kt = 0; kt < nk; kt += 2) {
+  for (int kt = kt0; kt < nk; kt += 2) {
     step(kt, std::integral_constant<int, 0>{});
     if (kt + 1 < nk) step(kt + 1, std::integral_constant<int, 1>{});
   }
 
   // ---- epilogue (all loads issued before any use) ----
   const int ncol = n0 + wave_n * (BN / 2) + g * 4;
+  if (S > 1) {
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      const int mm = m0 + wave_m * (BM / 2) + m * 16 + l15;
+      if (mm >= p.M) continue;
+#pragma unroll
+      for (int a = 0; a < NT; ++a) {
+        const int n = ncol + a * 16;
+        if (n < p.N) *reinterpret_cast<f32x4*>(p.splitk_ws + ((long long)ksplit * p.M + mm) * p.N + n) = acc[a][m];
+      }
+    }
+    return;
+  }
   f32x4 bb[NT];
 #pragma unroll
   for (int a = 0; a < NT; ++a) {
@@ -289,7 +305,10 @@ void launch_g(const ConvParams& p, hipStream_t s) {
   static const std::string pname = std::string("gemm_dma<") + std::to_string(BM) + "," + std::to_string(BN) + ">";
   const double bytes = (double)p.M * p.K * 2.0 + (double)p.N * p.K * 2.0 + (double)p.M * p.N * (p.out_f32 || p.y_lo ? 4.0 : 2.0) + (p.res ? (double)p.M * p.N * (p.res_lo ? 4.0 : 2.0) : 0.0);
   ProfScope prof(pname.c_str(), 2.0 * p.M * (double)p.N * p.K, bytes, s);
-  hipLaunchKernelGGL(kern, dim3(ntm * ntn), dim3(256), smem, s, p);
+  const int S = p.splitk > 1 ? p.splitk : 1;
+  LDIFF_CHECK(S == 1 || (p.splitk_ws && !p.stats && !p.geglu && !p.out_f32 && p.w_bstride == 0), LDIFF_ERR_INVALID, "gemm: split-K needs a workspace and a plain fp16 epilogue");
+  hipLaunchKernelGGL(kern, dim3(ntm * ntn, S), dim3(256), smem, s, p);
+  if (S > 1) { HIP_CHECK(hipGetLastError()); launch_splitk_reduce(p, s); }
   HIP_CHECK(hipGetLastError());
 }
 
@@ -304,11 +323,26 @@ bool gemm_dma_eligible(const ConvParams& p) {
          p.Hout == p.Hin && p.Wout == p.Win && p.M < (1 << 24) && pmax * 2 < (1 << 24) && (long long)p.M * pmax * 2 < (1LL << 31) && (long long)p.Nrows * p.K * 2 < (1LL << 31);
 }
 
+// Split-K for the LDS-DMA GEMM, same rule as igemm_splitk_plan: only where the tiles leave most workgroup slots empty and K is long
+// (1x1 shortcut convs over the concat input at the 8x8 level: M = 512, K = 2560 or 5120 on split operands)
+int gemm_dma_splitk_plan(const ConvParams& p) {
+  if (p.out_f32 || p.stats || p.geglu || p.w_bstride != 0 || p.M <= 0 || !gemm_dma_eligible(p)) return 1;
+  auto tiles = [&](int bm, int bn) { return (long long)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn); };
+  if (tiles(128, 64) >= 384) return 1;
+  const int nk = p.K / 64;
+  auto splits = [&](long long t) { int S = (int)(512 / t); S = S > nk / 16 ? nk / 16 : S; return S > 8 ? 8 : S; };
+  const int S128 = splits(tiles(128, 64));
+  if (S128 >= 2 && tiles(128, 64) * S128 >= 384) return S128;
+  const int S64 = splits(tiles(64, 64));
+  return S64 >= 2 ? S64 : 1;
+}
+
 void launch_gemm_dma(const ConvParams& p, hipStream_t s) {
+  const int S = p.splitk > 1 ? p.splitk : 1;   // split-K multiplies the workgroups of a tile shape
   auto tiles = [&](int bm, int bn) { return (long long)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn); };
   const bool n_small = p.N <= 64 || (p.N % 128 != 0 && p.N % 128 <= 64 && p.N < 512);
   const bool bm128_ok = p.w_bstride == 0 || (p.Hout * p.Wout) % 128 == 0;   // per-image weights: 128-row tiles only if they divide an image
-  if (!n_small && bm128_ok && tiles(128, 128) >= 384) launch_g<128, 128>(p, s);
-  else if (bm128_ok && tiles(128, 64) >= 384) launch_g<128, 64>(p, s);
+  if (!n_small && S == 1 && bm128_ok && tiles(128, 128) >= 384) launch_g<128, 128>(p, s);
+  else if (bm128_ok && tiles(128, 64) * S >= 384) launch_g<128, 64>(p, s);
   else launch_g<64, 64>(p, s);
 }

@@ -361,7 +361,7 @@ Act Exec::conv(const MatW& w, const Act& x, const Act* x2, const ConvOpts& o) {
     if (o.ups && conv3x3_eligible(p))   // nearest-2x upsample folded algebraically (4 parity convs with pre-summed taps)
       p.w_par = derived_par(w, wsrc, Cin_eff, o.split_in ? w.dup_par : w.par);
     // split-K launches write raw partials: the GroupNorm statistics of such a tensor come from the separate pass (Exec::gn)
-    p.splitk = conv3x3_eligible(p) ? conv3x3_splitk_plan(p) : igemm_splitk_plan(p);
+    p.splitk = conv3x3_eligible(p) ? conv3x3_splitk_plan(p) : gemm_dma_eligible(p) ? gemm_dma_splitk_plan(p) : igemm_splitk_plan(p);
     if (o.want_stats && C == p.N && p.N == w.N && p.splitk <= 1) {
       const int R = conv_stats_blocks_per_image(p);
       if (R > 0) {

@@ -134,6 +134,9 @@ CONV_CASES = {
     "3x3_stride2_splitk_512_16x16": (2, 512, 0, 16, 16, 256, 3, 2, 0, False, False, True),
     "3x3_stride2_splitk_concat_asym": (1, 256, 256, 16, 16, 192, 3, 2, 0, True, False, True),
     "3x3_stride2_splitk_gn": (2, 640, 0, 8, 8, 128, 3, 2, 0, False, True, True),
+    # ... and in the LDS-DMA GEMM (concat shortcut conv of the 8x8 level: M = 512, K = 2560)
+    "1x1_splitk_concat_2560": (8, 1280, 1280, 8, 8, 256, 1, 1, 0, False, False, True),
+    "1x1_splitk_4096_tailM": (1, 4096, 0, 1, 300, 192, 1, 1, 0, False, False, True),
     # wide-tile kernel (8x16 pixel tiles) on maps that are not multiples of the tile, with and without the 16-byte store path
     "3x3_wide_ragged_20x27_gn": (2, 64, 0, 20, 27, 96, 3, 1, 0, False, True, True),
     "3x3_wide_ragged_upsample_9x11": (2, 128, 0, 9, 11, 64, 3, 1, 1, False, False, True),
@@ -459,6 +462,7 @@ SPLIT_CASES = {
     "splitk3x3_hi_operand": (1, 1280, 0, 8, 8, 128, 3, 1, 0, False, True),
     "gemm_split_operand_shortcut_concat": (2, 128, 64, 16, 16, 128, 1, 1, 0, True, False),   # conv_shortcut over [x | skip], both split
     "gemm_split_operand_proj": (1, 320, 0, 1, 300, 320, 1, 1, 0, True, False),
+    "gemm_split_operand_shortcut_splitk": (8, 640, 640, 8, 8, 256, 1, 1, 0, True, False),    # K = 2 x 1280, 32 tiles -> split-K
     "igemm_stride2_split_operand": (2, 64, 0, 16, 16, 64, 3, 2, 0, True, False),       # downsampler on the split stream
     "igemm_stride2_split_operand_splitk": (2, 320, 0, 16, 16, 192, 3, 2, 0, True, False),   # ... deep level: few tiles, K = 2 x 2880 -> split-K
     "wide3x3_upsample_split_operand": (1, 64, 0, 16, 16, 64, 3, 1, 1, True, False),    # upsampler (parity folding on duplicated weights)

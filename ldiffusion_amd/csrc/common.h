@@ -91,6 +91,8 @@ void launch_splitk_reduce(const ConvParams& p, hipStream_t s);   // sums p.split
 void launch_make_parity_weights(const f16* w, f16* w_par, int Nrows, int Cin, hipStream_t s);                  // 1 = no split; >1 needs splitk_ws of splitk*M*N floats
 void launch_conv3x3(const ConvParams& p, hipStream_t s);       // kernels_conv3x3.hip
 // 16x16-tile ping-pong variant for the maps that fill the chip (kernels_conv3x3p.hip); launch_conv3x3 dispatches to it
+bool conv3x3n_selected(const ConvParams& p);   // narrow-output kernel (N == 4, plain epilogue, weights resident in LDS): kernels_conv3x3n.hip
+void launch_conv3x3n(const ConvParams& p, hipStream_t s);
 bool conv3x3p_selected(const ConvParams& p);
 int conv3x3p_stats_blocks(const ConvParams& p);
 void launch_conv3x3p(const ConvParams& p, hipStream_t s);

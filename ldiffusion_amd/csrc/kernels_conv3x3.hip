@@ -885,6 +885,7 @@ int conv3x3_splitk_plan(const ConvParams& p) {
 void launch_conv3x3(const ConvParams& p, hipStream_t s) {
   LDIFF_CHECK(p.splitk <= 1 || (p.splitk_ws && !p.stats), LDIFF_ERR_INVALID, "conv3x3: split-K needs a workspace and cannot emit fused statistics");
   LDIFF_CHECK(!p.w_par || (p.ups == 1 && p.splitk <= 1), LDIFF_ERR_INVALID, "conv3x3: parity weights need ups=1 and no split-K");
+  if (conv3x3n_selected(p)) { launch_conv3x3n(p, s); return; }
   if (conv3x3p_selected(p)) { launch_conv3x3p(p, s); return; }
   const bool wide = c3_tile_w(p) == 16;
   const int bn = (p.N % 128 != 0 && p.N % 160 == 0) ? 160 : (p.N <= 32 ? 32 : (p.N <= 64 ? 64 : 128));

@@ -126,6 +126,11 @@ CONV_CASES = {
     "3x3_cin32_general_path_gn": (2, 32, 0, 16, 16, 32, 3, 1, 0, False, True, True),
     "3x3_cout4_f32": (2, 320, 0, 16, 16, 4, 3, 1, 0, False, True, False),
     "3x3_cout3_f32": (1, 128, 0, 32, 32, 3, 3, 1, 0, False, True, False),
+    # narrow-output kernel (N == 4 stored columns, weights resident in LDS): ragged borders, several slabs, two sources, no GroupNorm
+    "3x3_cout3_f32_ragged_20x27": (2, 128, 0, 20, 27, 3, 3, 1, 0, False, True, False),
+    "3x3_cout4_f32_concat_320": (2, 192, 128, 24, 40, 4, 3, 1, 0, False, True, False),
+    "3x3_cout3_f32_plain_512": (1, 512, 0, 16, 48, 3, 3, 1, 0, False, False, False),
+    "3x3_cout4_f32_large": (8, 128, 0, 128, 128, 4, 3, 1, 0, False, True, False),
     "1x1_cin8_cout8": (2, 8, 0, 8, 8, 8, 1, 1, 0, False, False, False),
     "3x3_1x1_spatial": (3, 64, 0, 1, 1, 64, 3, 1, 0, False, False, False),
     "3x3_splitk_8x8_1280": (2, 1280, 0, 8, 8, 256, 3, 1, 0, False, True, True),

@@ -106,6 +106,9 @@ def main():
         if gn:
             a.gn_scale, a.gn_shift, a.silu_in = sc.data_ptr(), sh.data_ptr(), int(os.environ.get("LDIFF_BENCH_SILU", "1"))
         a.y, a.ldy = y.data_ptr(), Nst
+        if os.environ.get('LDIFF_BENCH_RES'):   # residual operand (conv2 of a resnet block)
+            res = torch.randn((B, Ho, Wo, Nst), device=DEV, dtype=torch.float16)
+            a.res, a.ld_res = res.data_ptr(), Nst
         if os.environ.get('LDIFF_BENCH_STATS'):
             R = lib.ldiff_op_conv_stats_blocks(C.byref(a))
             if R > 0:

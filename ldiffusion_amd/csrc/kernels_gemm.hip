@@ -331,6 +331,11 @@ int gemm_dma_splitk_plan(const ConvParams& p) {
   if (tiles(128, 64) >= 384) return 1;
   const int nk = p.K / 64;
   auto splits = [&](long long t) { int S = (int)(512 / t); S = S > nk / 16 ? nk / 16 : S; return S > 8 ? 8 : S; };
+  // the largest tile whose splits fill the chip (128x128: 0.0156 operand bytes per flop, 128x64: 0.023, 64x64: 0.031); launch_gemm_dma picks
+  // the tile by tiles x S with the same thresholds
+  const bool n_small = p.N <= 64 || (p.N % 128 != 0 && p.N % 128 <= 64 && p.N < 512);
+  const int S256 = n_small ? 1 : splits(tiles(128, 128));
+  if (S256 >= 2 && tiles(128, 128) * S256 >= 384) return S256;
   const int S128 = splits(tiles(128, 64));
   if (S128 >= 2 && tiles(128, 64) * S128 >= 384) return S128;
   const int S64 = splits(tiles(64, 64));
@@ -342,7 +347,7 @@ void launch_gemm_dma(const ConvParams& p, hipStream_t s) {
   auto tiles = [&](int bm, int bn) { return (long long)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn); };
   const bool n_small = p.N <= 64 || (p.N % 128 != 0 && p.N % 128 <= 64 && p.N < 512);
   const bool bm128_ok = p.w_bstride == 0 || (p.Hout * p.Wout) % 128 == 0;   // per-image weights: 128-row tiles only if they divide an image
-  if (!n_small && S == 1 && bm128_ok && tiles(128, 128) >= 384) launch_g<128, 128>(p, s);
+  if (!n_small && bm128_ok && tiles(128, 128) * S >= 384) launch_g<128, 128>(p, s);
   else if (bm128_ok && tiles(128, 64) * S >= 384) launch_g<128, 64>(p, s);
   else launch_g<64, 64>(p, s);
 }

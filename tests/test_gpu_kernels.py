@@ -142,6 +142,7 @@ CONV_CASES = {
     # ... and in the LDS-DMA GEMM (concat shortcut conv of the 8x8 level: M = 512, K = 2560)
     "1x1_splitk_concat_2560": (8, 1280, 1280, 8, 8, 256, 1, 1, 0, False, False, True),
     "1x1_splitk_4096_tailM": (1, 4096, 0, 1, 300, 192, 1, 1, 0, False, False, True),
+    "1x1_splitk_128x128_tiles": (1, 2560, 0, 1, 1000, 640, 1, 1, 0, False, False, True),   # 8 x 5 tiles of 128 x 128, 40 K-steps -> S = 2
     # wide-tile kernel (8x16 pixel tiles) on maps that are not multiples of the tile, with and without the 16-byte store path
     "3x3_wide_ragged_20x27_gn": (2, 64, 0, 20, 27, 96, 3, 1, 0, False, True, True),
     "3x3_wide_ragged_upsample_9x11": (2, 128, 0, 9, 11, 64, 3, 1, 1, False, False, True),

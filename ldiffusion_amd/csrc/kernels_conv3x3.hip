@@ -19,9 +19,54 @@
 namespace {
 
 __device__ __forceinline__ int swz8(int row, int chunk) { return chunk ^ ((row >> 1) & 7); }
-// x * sigmoid(x) with the two hardware transcendentals only (v_exp_f32, v_rcp_f32: 1 ulp); __frcp_rn would expand to a
-// 11-instruction IEEE division per element
-__device__ __forceinline__ float silu_f(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v * -1.4426950408889634f)); }
+
+// GroupNorm-apply (+SiLU) of TWO fp16 elements (one dword) -> one packed fp16 dword, six single-issue VALU instructions per element:
+//   y = fma(x, scale, shift)  (v_fma_mix_f32 reads the fp16 half directly: no v_cvt),  r = 1 / (1 + 2^(-y log2 e)),  out = f16(y * r)
+// (v_fma_mixlo/hi_f16: multiply and ONE rounding to fp16 in one instruction).  hipcc's own code for the same arithmetic packs the
+// fp32 multiplies / fmas of neighbouring elements into v_pk_fma_f32 / v_pk_mul_f32, which cost ~5x a plain VALU instruction beside
+// MFMAs (MI355X_MICROARCH.md, cycle constants: "an anti-lever beside MFMAs"; scripts/micro/conv_consumer.hip measures it: the same
+// transform next to a matrix stream costs 22 % of the matrix rate in the compiler's form and 3 % in this one).  The two elements'
+// chains are interleaved so that every transcendental result has one independent instruction before its first reader (gfx940+
+// trans-forwarding hazard: nothing pads it inside an asm statement).
+template <bool SILU>
+__device__ __forceinline__ unsigned gn_pair(unsigned xw, float s0, float t0, float s1, float t1) {
+  unsigned o;
+  if constexpr (SILU) {
+    float y0, y1, e0, e1;
+    asm("v_fma_mix_f32 %1, %5, %6, %7 op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mix_f32 %2, %5, %8, %9 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_mul_f32 %3, 0xbfb8aa3b, %1\n\t"
+        "v_mul_f32 %4, 0xbfb8aa3b, %2\n\t"
+        "v_exp_f32 %3, %3\n\t"
+        "v_exp_f32 %4, %4\n\t"
+        "v_add_f32 %3, 1.0, %3\n\t"
+        "v_add_f32 %4, 1.0, %4\n\t"
+        "v_rcp_f32 %3, %3\n\t"
+        "v_rcp_f32 %4, %4\n\t"
+        "v_fma_mixlo_f16 %0, %1, %3, 0\n\t"
+        "v_fma_mixhi_f16 %0, %2, %4, 0"
+        : "=&v"(o), "=&v"(y0), "=&v"(y1), "=&v"(e0), "=&v"(e1)
+        : "v"(xw), "v"(s0), "v"(t0), "v"(s1), "v"(t1));
+  } else {
+    float y0, y1;
+    asm("v_fma_mix_f32 %1, %3, %4, %5 op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mix_f32 %2, %3, %6, %7 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixlo_f16 %0, %1, 1.0, 0\n\t"
+        "v_fma_mixhi_f16 %0, %2, 1.0, 0"
+        : "=&v"(o), "=&v"(y0), "=&v"(y1)
+        : "v"(xw), "v"(s0), "v"(t0), "v"(s1), "v"(t1));
+  }
+  return o;
+}
+template <int K>
+__device__ __forceinline__ float comp8(const float4& a, const float4& b) {
+  if constexpr (K == 0) return a.x; else if constexpr (K == 1) return a.y; else if constexpr (K == 2) return a.z; else if constexpr (K == 3) return a.w;
+  else if constexpr (K == 4) return b.x; else if constexpr (K == 5) return b.y; else if constexpr (K == 6) return b.z; else return b.w;
+}
+template <int D>
+__device__ __forceinline__ unsigned dword4(const uint4& v) {
+  if constexpr (D == 0) return v.x; else if constexpr (D == 1) return v.y; else if constexpr (D == 2) return v.z; else return v.w;
+}
 
 typedef __attribute__((address_space(1))) const void gptr_t;
 typedef __attribute__((address_space(3))) void lptr_t;
@@ -107,15 +152,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const ConvParams p) {  
       if (hp >= HP) continue;
       uint4 v = ra[i];
       if (GN && a_off[i] >= 0) {   // zero padding applies to the normalised tensor: padding chunks stay exactly 0
-        f16x8 h = __builtin_bit_cast(f16x8, v), o;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          float f = (float)h[j] * sv[j] + tv[j];
-          const float fs = silu_f(f);
-          f = silu ? fs : f;   // select, not a branch per element
-          o[j] = (f16)f;
+        const uint4 r = v;
+        if (silu) {
+          v.x = gn_pair<true>(r.x, sv[0], tv[0], sv[1], tv[1]); v.y = gn_pair<true>(r.y, sv[2], tv[2], sv[3], tv[3]);
+          v.z = gn_pair<true>(r.z, sv[4], tv[4], sv[5], tv[5]); v.w = gn_pair<true>(r.w, sv[6], tv[6], sv[7], tv[7]);
+        } else {
+          v.x = gn_pair<false>(r.x, sv[0], tv[0], sv[1], tv[1]); v.y = gn_pair<false>(r.y, sv[2], tv[2], sv[3], tv[3]);
+          v.z = gn_pair<false>(r.z, sv[4], tv[4], sv[5], tv[5]); v.w = gn_pair<false>(r.w, sv[6], tv[6], sv[7], tv[7]);
         }
-        v = __builtin_bit_cast(uint4, o);
       }
       sA[buf * HP * 8 + hp * 8 + swz8(hp, kc)] = v;
     }
@@ -399,20 +443,13 @@ __global__ __launch_bounds__(256, BN > 128 ? 1 : 2) void conv3x3w_kernel(const C
     constexpr int i = decltype(ic)::value;
     uint4 v = ra[i];
     if (GN) {
-      const float sv[8] = {gs0.x, gs0.y, gs0.z, gs0.w, gs1.x, gs1.y, gs1.z, gs1.w};
-      const float tv[8] = {gt0.x, gt0.y, gt0.z, gt0.w, gt1.x, gt1.y, gt1.z, gt1.w};
-      const f16x8 h = __builtin_bit_cast(f16x8, v);
-      float f[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) f[j] = (float)h[j] * sv[j] + tv[j];
       if (silu) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) f[j] = silu_f(f[j]);
+        v.x = gn_pair<true>(ra[i].x, gs0.x, gt0.x, gs0.y, gt0.y); v.y = gn_pair<true>(ra[i].y, gs0.z, gt0.z, gs0.w, gt0.w);
+        v.z = gn_pair<true>(ra[i].z, gs1.x, gt1.x, gs1.y, gt1.y); v.w = gn_pair<true>(ra[i].w, gs1.z, gt1.z, gs1.w, gt1.w);
+      } else {
+        v.x = gn_pair<false>(ra[i].x, gs0.x, gt0.x, gs0.y, gt0.y); v.y = gn_pair<false>(ra[i].y, gs0.z, gt0.z, gs0.w, gt0.w);
+        v.z = gn_pair<false>(ra[i].z, gs1.x, gt1.x, gs1.y, gt1.y); v.w = gn_pair<false>(ra[i].w, gs1.z, gt1.z, gs1.w, gt1.w);
       }
-      f16x8 o;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) o[j] = (f16)f[j];
-      v = __builtin_bit_cast(uint4, o);
     }
     v.x &= a_msk[i]; v.y &= a_msk[i]; v.z &= a_msk[i]; v.w &= a_msk[i];
     *reinterpret_cast<uint4*>(smem_raw + bufoff + a_lds[i]) = v;
@@ -463,14 +500,9 @@ __global__ __launch_bounds__(256, BN > 128 ? 1 : 2) void conv3x3w_kernel(const C
   // GroupNorm(+SiLU) of ONE element of a staged chunk; issued between the MFMAs of the k-half-1 groups so that its
   // VALU/transcendental issue slots fall into the shadow of the matrix pipe (an MFMA holds the vector issue port for 8 of
   // its 16 cycles) and the k-half-0 fragments' registers are free for its temporaries
-  auto xform_elem = [&](auto ic, auto jc, auto siluc) -> float {
-    constexpr int i = decltype(ic)::value, j = decltype(jc)::value;
-    const float sv[8] = {gs0.x, gs0.y, gs0.z, gs0.w, gs1.x, gs1.y, gs1.z, gs1.w};
-    const float tv[8] = {gt0.x, gt0.y, gt0.z, gt0.w, gt1.x, gt1.y, gt1.z, gt1.w};
-    const f16x8 h = __builtin_bit_cast(f16x8, ra[i]);
-    float f = (float)h[j] * sv[j] + tv[j];
-    if constexpr (decltype(siluc)::value) f = silu_f(f);
-    return f;
+  auto xform_pair = [&](auto ic, auto dc, auto siluc) -> unsigned {   // dword d (elements 2d, 2d+1) of staged chunk i
+    constexpr int i = decltype(ic)::value, d = decltype(dc)::value;
+    return gn_pair<decltype(siluc)::value>(dword4<d>(ra[i]), comp8<2 * d>(gs0, gs1), comp8<2 * d>(gt0, gt1), comp8<2 * d + 1>(gs0, gs1), comp8<2 * d + 1>(gt0, gt1));
   };
   auto mask_store = [&](auto ic, uint4 v, unsigned bufoff) {
     constexpr int i = decltype(ic)::value;
@@ -498,9 +530,8 @@ __global__ __launch_bounds__(256, BN > 128 ? 1 : 2) void conv3x3w_kernel(const C
         constexpr bool LAST = T == NTAPS - 1;
         // chunks [C0, C1) of the NEXT slab are normalised during this tap
         constexpr int C0 = T >= 1 ? (T - 1) * CPT : A_IT, C1 = T >= 1 ? (T * CPT < A_IT ? T * CPT : A_IT) : A_IT;
-        constexpr int NE = GN && STAGE && C0 < C1 ? (C1 - C0) * 8 : 0, EPG = (NE + NT - 1) / NT;
-        float fx = 0.f;                       // even element waiting for its odd neighbour
-        unsigned pk[NE > 0 ? NE / 2 : 1];     // normalised elements, packed f16 pairs
+        constexpr int NE = GN && STAGE && C0 < C1 ? (C1 - C0) * 4 : 0, EPG = (NE + NT - 1) / NT;   // NE element PAIRS (dwords), EPG per MFMA group
+        unsigned pk[NE > 0 ? NE : 1];         // normalised elements, packed f16 pairs
         f16x8 wf[2][NT], xf[2][MT];
         // k-half 0 up front; the k-half-1 reads go out between the first MFMA groups (an LDS instruction issues while the matrix pipe
         // works: all sixteen in front of the first MFMA cost ~100 cycles of every step)
@@ -526,11 +557,7 @@ __global__ __launch_bounds__(256, BN > 128 ? 1 : 2) void conv3x3w_kernel(const C
           if constexpr (kk == 0 && a == WI) static_for<0, NT>([&](auto bc) { constexpr int b2 = decltype(bc)::value; lds_read128<b2 * 2048>(wf[1][b2], wc1[T & 1]); });
           static_for<(kk == 1 ? a * EPG : NE), (kk == 1 ? ((a + 1) * EPG < NE ? (a + 1) * EPG : NE) : NE)>([&](auto ec) {
             constexpr int e = decltype(ec)::value;
-            const float f = xform_elem(std::integral_constant<int, C0 + e / 8>{}, std::integral_constant<int, e % 8>{}, siluc);
-            if constexpr (e & 1) {
-              const f16x2 h2 = {(f16)fx, (f16)f};
-              pk[e / 2] = __builtin_bit_cast(unsigned, h2);
-            } else fx = f;
+            pk[e] = xform_pair(std::integral_constant<int, C0 + e / 4>{}, std::integral_constant<int, e % 4>{}, siluc);
           });
           __builtin_amdgcn_sched_barrier(0);
         });

@@ -1,0 +1,288 @@
+// Micro-benchmark (diagnostic, not part of the product library): what matrix rate does the CONSUMER side of a producer / consumer
+// 3x3 convolution reach on this device?  One 512-thread workgroup per CU: waves 0-3 ("consumers", one per SIMD) run the tap loop of a
+// 16x16-pixel x 128-channel tile (each wave 8 rows x 16 pixels x 64 channels = 8x4 accumulator tiles of v_mfma_f32_16x16x32_f16,
+// operands by ds_read_b128 from a swizzled halo image and a weight slot, one pixel-row pair prefetched ahead, every accumulator's two
+// k-halves back to back); waves 4-7 ("producers") optionally run the per-step work of the other role next to them: GroupNorm+SiLU
+// arithmetic on register data, ds_write_b128 of the result, and weight slices by LDS-DMA.  No synchronisation between the roles: this is
+// the ceiling of the loop shape, not a kernel.
+//   build: hipcc -O3 --offload-arch=gfx950 -std=c++17 -o scripts/micro/conv_consumer scripts/micro/conv_consumer.hip
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <type_traits>
+typedef _Float16 f16;
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void lptr_t;
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
+
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) { f(std::integral_constant<int, I>{}); static_for<I + 1, N>(f); }
+}
+template <int OFF>
+__device__ __forceinline__ void lds_read128(f16x8& d, unsigned addr) {
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF) : "memory");
+}
+template <int CNT>
+__device__ __forceinline__ void lds_wait2(f16x8& a, f16x8& b) { asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "n"(CNT)); }
+template <int CNT>
+__device__ __forceinline__ void lds_wait6(f16x8& a, f16x8& b, f16x8& c, f16x8& d, f16x8& e, f16x8& f) {
+  asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f) : "n"(CNT));
+}
+template <int CNT>
+__device__ __forceinline__ void lds_wait4(f16x8& a, f16x8& b, f16x8& c, f16x8& d) {
+  asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(CNT));
+}
+__device__ __forceinline__ int swzx(int hx) { return (0xcb5888 >> (3 * (hx >> 1))) & 7; }
+__device__ __forceinline__ float silu_f(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v * -1.4426950408889634f)); }
+
+constexpr int HWD = 18, HPX = 18 * 18, ROWB = HWD * 128, HB = HPX * 128;   // halo image: 18 x 18 pixels of 128 B
+constexpr int WSLOT = 128 * 128, NSLOT = 3;
+constexpr unsigned W_OFF = 2 * HB, DUMP = W_OFF + NSLOT * WSLOT, LDS_BYTES = DUMP + 4096 + 64, FLAG = DUMP + 4096;
+
+// PROD: 0 = consumers only (producer waves exit), 1 = producers run the transform arithmetic + ds_write, 2 = ... + weight slices by LDS-DMA
+// ORDER: 0 = dependent pairs (k-half 0 and 1 of an accumulator back to back), 1 = k-half 0 of the 8 accumulators of a channel tile pair, then k-half 1
+// PRIO: s_setprio level of the consumer waves; XF: 0 = compiler-scheduled GroupNorm+SiLU, 1 = v_fma_mix form (6 instructions per element),
+// 2 = same instruction count without transcendentals; PACE: producers follow the consumers' step counter (LDS word) instead of free-running
+template <int PROD, int ORDER, int PRIO, int XF, int PACE>
+__global__ __launch_bounds__(512, 2) void conv_consumer_kernel(int tiles, int nslab, const f16* wsrc, float* sink, unsigned long long* prod_done) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const unsigned lds0 = (unsigned)(size_t)(lptr_t*)smem;
+  // random-ish operands in LDS (both halo buffers, all weight slots)
+  for (unsigned i = tid; i < DUMP / 4; i += 512) {
+    const unsigned h = (i * 2654435761u) >> 12;
+    const f16 a = (f16)(((int)(h & 255) - 128) * (1.0f / 256.f)), b = (f16)(((int)((h >> 8) & 255) - 128) * (1.0f / 256.f));
+    reinterpret_cast<unsigned*>(smem)[i] = (unsigned)__builtin_bit_cast(unsigned short, a) | ((unsigned)__builtin_bit_cast(unsigned short, b) << 16);
+  }
+  if (tid == 0) *reinterpret_cast<volatile unsigned*>(smem + FLAG) = 0u;
+  __syncthreads();
+  const unsigned long long tstart = __builtin_readcyclecounter();
+  if (wave >= 4) {
+    if (PROD == 0) return;
+    // ---- producer stand-in: per consumer step (1024 matrix cycles) each producer wave transforms ~9 elements per lane; here per "round" one
+    // 16-byte chunk (8 elements) + one ds_write_b128, 10.25 rounds per slab of 9 steps; PROD 2 adds 4 LDS-DMA pieces per step ----
+    const int pw = wave - 4, ptid = tid - 256;
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)wsrc, 0, 128 * 1152 * 2, 0x00020000);
+    int w_voff[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = pw * 32 + i * 8 + (lane >> 3), pos = lane & 7;
+      w_voff[i] = (r * 1152 + (pos ^ ((r >> 1) & 7)) * 8) * 2 - i * 1024;
+    }
+    float sc[8], sh[8], sc2[8], sh2[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { sc[j] = 1.0f + 0.01f * ((lane + j) & 7); sh[j] = 0.02f * ((lane * 3 + j) & 15) - 0.1f; sc2[j] = sc[j] * -1.4426950408889634f; sh2[j] = sh[j] * -1.4426950408889634f; }
+    uint4 x = make_uint4(0x3c003800u + lane, 0xb8003c00u, 0x34003a00u + lane * 3, 0x3e00b400u);
+    const long long steps = (long long)tiles * nslab * 9;
+    for (long long s = 0; s < steps; ++s) {
+      if (PROD >= 2) {
+        unsigned char* dst = smem + W_OFF + (unsigned)(s % NSLOT) * WSLOT + pw * 4096;
+        const int soff = (int)((s % 9) * 128 + ((s / 9) % 2) * 64) * 2;
+        static_for<0, 4>([&](auto ic) {
+          constexpr int i = decltype(ic)::value;
+#if defined(__HIP_DEVICE_COMPILE__)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (lptr_t*)dst, 16, w_voff[i], soff, i * 1024, 0);
+#endif
+        });
+      }
+      const int rounds = (s % 9) < 5 ? 2 : ((s % 9) == 5 && pw == 0 ? 1 : 0);
+      if (PACE) {   // stay at most 2 steps ahead of consumer wave 0
+        for (;;) {
+          const unsigned cs = *reinterpret_cast<volatile unsigned*>(smem + FLAG);
+          if ((long long)__builtin_amdgcn_readfirstlane(cs) + 2 >= s) break;
+          __builtin_amdgcn_s_sleep(2);
+        }
+      }
+      for (int r = 0; r < rounds; ++r) {
+        if (XF == 0) {
+          const f16x8 h = __builtin_bit_cast(f16x8, x);
+          f16x8 o;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) o[j] = (f16)silu_f((float)h[j] * sc[j] + sh[j]);
+          x = __builtin_bit_cast(uint4, o);
+        } else {
+          unsigned xi[4] = {x.x, x.y, x.z, x.w}, xo[4];
+#pragma unroll
+          for (int d = 0; d < 4; ++d) {
+            float y0, y1, e0, e1;
+            asm volatile("v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(y0) : "v"(xi[d]), "v"(sc[2 * d]), "v"(sh[2 * d]));
+            asm volatile("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(y1) : "v"(xi[d]), "v"(sc[2 * d + 1]), "v"(sh[2 * d + 1]));
+            asm volatile("v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(e0) : "v"(xi[d]), "v"(sc2[2 * d]), "v"(sh2[2 * d]));
+            asm volatile("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(e1) : "v"(xi[d]), "v"(sc2[2 * d + 1]), "v"(sh2[2 * d + 1]));
+            if (XF == 1) { e0 = __builtin_amdgcn_exp2f(e0); e1 = __builtin_amdgcn_exp2f(e1); } else { e0 = e0 * 1.5f; e1 = e1 * 1.25f; }
+            e0 += 1.0f; e1 += 1.0f;
+            if (XF == 1) { e0 = __builtin_amdgcn_rcpf(e0); e1 = __builtin_amdgcn_rcpf(e1); } else { e0 = e0 * 0.75f; e1 = e1 * 0.875f; }
+            unsigned o = 0;
+            asm volatile("v_fma_mixlo_f16 %0, %1, %2, 0" : "+v"(o) : "v"(y0), "v"(e0));
+            asm volatile("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(o) : "v"(y1), "v"(e1));
+            xo[d] = o;
+          }
+          x = make_uint4(xo[0], xo[1], xo[2], xo[3]);
+        }
+        x.x ^= 0x00010001u * (unsigned)(s & 3);
+        asm volatile("ds_write_b128 %0, %1" :: "v"(lds0 + DUMP + (unsigned)(ptid & 255) * 16), "v"(__builtin_bit_cast(f32x4, x)) : "memory");
+      }
+      if (PROD >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (x.x == 0x12345u) sink[1] = 1.f;
+    if (lane == 0 && blockIdx.x == 0) prod_done[pw] = __builtin_readcyclecounter() - tstart;
+    return;
+  }
+  // ---- consumer ----
+  if (PRIO > 0) __builtin_amdgcn_s_setprio(PRIO);
+  const int wave_m = wave >> 1, wave_n = wave & 1;
+  const int g = lane >> 4, l15 = lane & 15;
+  unsigned xb[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const int hx = l15 + j;
+    xb[j] = lds0 + (unsigned)(((wave_m * 8) * HWD + hx) * 128 + ((g ^ swzx(hx)) << 4));
+  }
+  const int wrow = wave_n * 64 + l15;
+  const unsigned w_lane = lds0 + W_OFF + (unsigned)(wrow * 128 + ((g ^ ((wrow >> 1) & 7)) << 4));
+  f32x4 acc[4][8];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int m = 0; m < 8; ++m) acc[a][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  f16x8 W[2][4], X[2][2][2];   // W[k-half][channel tile]; X[buffer][row of the pair][k-half]
+  unsigned slot = 0;
+  // reads of a row pair: rows 2p, 2p+1, both k-halves, at tap (ky, kx) of halo buffer hb
+  auto issue_x = [&](auto pc, auto kyc, auto kxc, unsigned hb, f16x8 (&dst)[2][2]) {
+    constexpr int p = decltype(pc)::value, ky = decltype(kyc)::value, kx = decltype(kxc)::value;
+    const unsigned b0 = xb[kx] + hb, b1 = b0 ^ 64u;
+    lds_read128<(2 * p + ky) * ROWB>(dst[0][0], b0);
+    lds_read128<(2 * p + ky) * ROWB>(dst[0][1], b1);
+    lds_read128<(2 * p + 1 + ky) * ROWB>(dst[1][0], b0);
+    lds_read128<(2 * p + 1 + ky) * ROWB>(dst[1][1], b1);
+  };
+  auto issue_w = [&](auto ac, unsigned wc) {
+    constexpr int a = decltype(ac)::value;
+    lds_read128<a * 2048>(W[0][a], wc);
+    lds_read128<a * 2048>(W[1][a], wc ^ 64u);
+  };
+  auto mfma4 = [&](auto ac, auto pc, f16x8 (&x)[2][2]) {
+    constexpr int a = decltype(ac)::value, p = decltype(pc)::value;
+    if (ORDER == 0) {
+      acc[a][2 * p] = __builtin_amdgcn_mfma_f32_16x16x32_f16(W[0][a], x[0][0], acc[a][2 * p], 0, 0, 0);
+      acc[a][2 * p] = __builtin_amdgcn_mfma_f32_16x16x32_f16(W[1][a], x[0][1], acc[a][2 * p], 0, 0, 0);
+      acc[a][2 * p + 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(W[0][a], x[1][0], acc[a][2 * p + 1], 0, 0, 0);
+      acc[a][2 * p + 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(W[1][a], x[1][1], acc[a][2 * p + 1], 0, 0, 0);
+    } else {
+      acc[a][2 * p] = __builtin_amdgcn_mfma_f32_16x16x32_f16(W[0][a], x[0][0], acc[a][2 * p], 0, 0, 0);
+      acc[a][2 * p + 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(W[0][a], x[1][0], acc[a][2 * p + 1], 0, 0, 0);
+      acc[a][2 * p] = __builtin_amdgcn_mfma_f32_16x16x32_f16(W[1][a], x[0][1], acc[a][2 * p], 0, 0, 0);
+      acc[a][2 * p + 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(W[1][a], x[1][1], acc[a][2 * p + 1], 0, 0, 0);
+    }
+  };
+  // first step's operands
+  issue_x(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, 0u, X[0]);
+  static_for<0, 4>([&](auto ac) { issue_w(ac, w_lane); });
+  const int nsl = tiles * nslab;
+  for (int c = 0; c < nsl; ++c) {
+    const unsigned hb = (unsigned)(c & 1) * HB;
+    static_for<0, 9>([&](auto tc) {
+      constexpr int T = decltype(tc)::value, ky = T / 3, kx = T % 3;
+      constexpr int nky = (T + 1) % 9 / 3, nkx = (T + 1) % 3;
+      const unsigned nslot = slot + 1 == NSLOT ? 0 : slot + 1;
+      const unsigned wc_next = w_lane + nslot * WSLOT;
+      const unsigned hb_next = T == 8 ? HB - hb : hb;
+      // entry: outstanding = X pair 0 (4 reads), W (8 reads: a0 k0, a0 k1, a1 k0, ...)
+      lds_wait6<6>(X[0][0][0], X[0][0][1], X[0][1][0], X[0][1][1], W[0][0], W[1][0]);
+      mfma4(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, X[0]);
+      issue_x(std::integral_constant<int, 1>{}, std::integral_constant<int, ky>{}, std::integral_constant<int, kx>{}, hb, X[1]);
+      __builtin_amdgcn_sched_barrier(0);
+      lds_wait2<8>(W[0][1], W[1][1]);
+      mfma4(std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{}, X[0]);
+      __builtin_amdgcn_sched_barrier(0);
+      lds_wait2<6>(W[0][2], W[1][2]);
+      mfma4(std::integral_constant<int, 2>{}, std::integral_constant<int, 0>{}, X[0]);
+      __builtin_amdgcn_sched_barrier(0);
+      lds_wait2<4>(W[0][3], W[1][3]);
+      mfma4(std::integral_constant<int, 3>{}, std::integral_constant<int, 0>{}, X[0]);
+      __builtin_amdgcn_sched_barrier(0);
+      // pair 1
+      issue_x(std::integral_constant<int, 2>{}, std::integral_constant<int, ky>{}, std::integral_constant<int, kx>{}, hb, X[0]);
+      lds_wait4<4>(X[1][0][0], X[1][0][1], X[1][1][0], X[1][1][1]);
+      static_for<0, 4>([&](auto ac) { mfma4(ac, std::integral_constant<int, 1>{}, X[1]); __builtin_amdgcn_sched_barrier(0); });
+      // pair 2
+      issue_x(std::integral_constant<int, 3>{}, std::integral_constant<int, ky>{}, std::integral_constant<int, kx>{}, hb, X[1]);
+      lds_wait4<4>(X[0][0][0], X[0][0][1], X[0][1][0], X[0][1][1]);
+      static_for<0, 4>([&](auto ac) { mfma4(ac, std::integral_constant<int, 2>{}, X[0]); __builtin_amdgcn_sched_barrier(0); });
+      // pair 3: the next step's first row pair and weights go out between its MFMA groups
+      issue_x(std::integral_constant<int, 0>{}, std::integral_constant<int, nky>{}, std::integral_constant<int, nkx>{}, hb_next, X[0]);
+      lds_wait4<4>(X[1][0][0], X[1][0][1], X[1][1][0], X[1][1][1]);
+      static_for<0, 4>([&](auto ac) {
+        mfma4(ac, std::integral_constant<int, 3>{}, X[1]);
+        issue_w(ac, wc_next);
+        __builtin_amdgcn_sched_barrier(0);
+      });
+      slot = nslot;
+      if (PACE && wave == 0 && lane == 0) *reinterpret_cast<volatile unsigned*>(smem + FLAG) = (unsigned)(c * 9 + T + 1);
+    });
+  }
+  const unsigned long long t1 = __builtin_readcyclecounter();
+  const unsigned long long t0 = tstart;
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  float s = 0.f;
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int m = 0; m < 8; ++m) s += acc[a][m][0] + acc[a][m][1] + acc[a][m][2] + acc[a][m][3];
+  if (s == 12345.678f) sink[0] = s + (float)X[0][0][0][0] + (float)W[0][0][0];
+  if (lane == 0 && blockIdx.x == 0) prod_done[4 + wave] = t1 - t0;
+}
+
+template <int PROD, int ORDER, int PRIO = 0, int XF = 0, int PACE = 0>
+void run(int tiles, int nslab, const f16* w, float* sink, unsigned long long* pd, int cus) {
+  auto k = conv_consumer_kernel<PROD, ORDER, PRIO, XF, PACE>;
+  CK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  hipLaunchKernelGGL(k, dim3(cus), dim3(512), LDS_BYTES, 0, 2, nslab, w, sink, pd);
+  CK(hipDeviceSynchronize());
+  float best = 1e30f, sum = 0.f;
+  for (int rep = 0; rep < 5; ++rep) {
+    CK(hipEventRecord(e0));
+    hipLaunchKernelGGL(k, dim3(cus), dim3(512), LDS_BYTES, 0, tiles, nslab, w, sink, pd);
+    CK(hipEventRecord(e1));
+    CK(hipDeviceSynchronize());
+    float ms = 0.f;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    best = ms < best ? ms : best; sum += ms;
+  }
+  const double flops = (double)cus * tiles * 2.0 * 256 * 128 * (nslab * 64 * 9);
+  unsigned long long h[8];
+  CK(hipMemcpy(h, pd, sizeof(h), hipMemcpyDeviceToHost));
+  printf("PROD %d ORDER %d PRIO %d XF %d PACE %d: best %.3f ms mean %.3f ms  %7.1f TFLOP/s = %.3f of 2500;  wg0 ticks: producers %llu..%llu consumers %llu..%llu\n", PROD, ORDER, PRIO, XF, PACE, best, sum / 5,
+         flops / (best * 1e-3) * 1e-12, flops / (best * 1e-3) * 1e-12 / 2500.0, h[0] < h[3] ? h[0] : h[3], h[0] > h[3] ? h[0] : h[3], h[4] < h[7] ? h[4] : h[7], h[4] > h[7] ? h[4] : h[7]);
+  CK(hipEventDestroy(e0)); CK(hipEventDestroy(e1));
+}
+
+int main() {
+  int dev = 0, cus = 0;
+  CK(hipGetDevice(&dev));
+  CK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+  printf("device %d: %d CUs\n", dev, cus);
+  f16* w; float* sink; unsigned long long* pd;
+  CK(hipMalloc(&w, 128 * 1152 * 2)); CK(hipMemset(w, 0x11, 128 * 1152 * 2));
+  CK(hipMalloc(&sink, 64)); CK(hipMalloc(&pd, 128));
+  for (int rep = 0; rep < 2; ++rep) {
+    run<0, 0>(32, 2, w, sink, pd, cus);
+    run<0, 0, 2>(32, 2, w, sink, pd, cus);
+    run<1, 0, 0, 0, 0>(32, 2, w, sink, pd, cus);
+    run<1, 0, 0, 0, 1>(32, 2, w, sink, pd, cus);
+    run<1, 0, 2, 0, 1>(32, 2, w, sink, pd, cus);
+    run<1, 0, 0, 1, 1>(32, 2, w, sink, pd, cus);
+    run<1, 0, 2, 1, 1>(32, 2, w, sink, pd, cus);
+    run<1, 0, 0, 2, 1>(32, 2, w, sink, pd, cus);
+    run<2, 0, 0, 1, 1>(32, 2, w, sink, pd, cus);
+    run<2, 0, 2, 1, 1>(32, 2, w, sink, pd, cus);
+    run<2, 1, 2, 1, 1>(32, 2, w, sink, pd, cus);
+  }
+  return 0;
+}

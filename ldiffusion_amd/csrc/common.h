@@ -281,6 +281,43 @@ __device__ __forceinline__ unsigned gn_pair(unsigned xw, float s0, float t0, flo
   }
   return o;
 }
+// The same for FOUR elements (two dwords) with the four chains interleaved: one wave alone issues a dependent chain at its latency, not its
+// rate, and a producer wave of the dataflow conv kernel (kernels_conv3x3d.hip) has no second wave to fill the gaps.
+template <bool SILU>
+__device__ __forceinline__ void gn_quad(unsigned xa, unsigned xb, float s0, float t0, float s1, float t1, float s2, float t2, float s3, float t3, unsigned& oa, unsigned& ob) {
+  if constexpr (SILU) {
+    float y0, y1, y2, y3, e0, e1, e2, e3;
+    asm("v_fma_mix_f32 %2, %10, %12, %13 op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mix_f32 %3, %10, %14, %15 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mix_f32 %4, %11, %16, %17 op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mix_f32 %5, %11, %18, %19 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_mul_f32 %6, 0xbfb8aa3b, %2\n\t"
+        "v_mul_f32 %7, 0xbfb8aa3b, %3\n\t"
+        "v_mul_f32 %8, 0xbfb8aa3b, %4\n\t"
+        "v_mul_f32 %9, 0xbfb8aa3b, %5\n\t"
+        "v_exp_f32 %6, %6\n\t"
+        "v_exp_f32 %7, %7\n\t"
+        "v_exp_f32 %8, %8\n\t"
+        "v_exp_f32 %9, %9\n\t"
+        "v_add_f32 %6, 1.0, %6\n\t"
+        "v_add_f32 %7, 1.0, %7\n\t"
+        "v_add_f32 %8, 1.0, %8\n\t"
+        "v_add_f32 %9, 1.0, %9\n\t"
+        "v_rcp_f32 %6, %6\n\t"
+        "v_rcp_f32 %7, %7\n\t"
+        "v_rcp_f32 %8, %8\n\t"
+        "v_rcp_f32 %9, %9\n\t"
+        "v_fma_mixlo_f16 %0, %2, %6, 0\n\t"
+        "v_fma_mixhi_f16 %0, %3, %7, 0\n\t"
+        "v_fma_mixlo_f16 %1, %4, %8, 0\n\t"
+        "v_fma_mixhi_f16 %1, %5, %9, 0"
+        : "=&v"(oa), "=&v"(ob), "=&v"(y0), "=&v"(y1), "=&v"(y2), "=&v"(y3), "=&v"(e0), "=&v"(e1), "=&v"(e2), "=&v"(e3)
+        : "v"(xa), "v"(xb), "v"(s0), "v"(t0), "v"(s1), "v"(t1), "v"(s2), "v"(t2), "v"(s3), "v"(t3));
+  } else {
+    oa = gn_pair<false>(xa, s0, t0, s1, t1);
+    ob = gn_pair<false>(xb, s2, t2, s3, t3);
+  }
+}
 template <int K>
 __device__ __forceinline__ float comp8(const float4& a, const float4& b) {
   if constexpr (K == 0) return a.x; else if constexpr (K == 1) return a.y; else if constexpr (K == 2) return a.z; else if constexpr (K == 3) return a.w;

@@ -45,10 +45,12 @@ constexpr unsigned D_HB = 41 * 1024;                                   // one ha
 constexpr int D_NSLOT = 4;                                             // weight ring
 constexpr unsigned D_WSLOT = 128 * 128, D_WOFF = 2 * D_HB;
 constexpr unsigned D_FLAGS = D_WOFF + D_NSLOT * D_WSLOT;               // [producer progress x4][consumer progress x4] | per-wave dump rows
-constexpr unsigned D_DUMP = D_FLAGS + 64;                              // consumers: 4 x 256 B
-constexpr unsigned D_DMADUMP = D_DUMP + 4 * 256;                       // 4 KiB: target of the DMA instructions that exist only to keep the counted waits uniform
-constexpr unsigned D_AFF = D_DMADUMP + 4096;                           // [producer wave 4][table 2] x 1 KiB: scale (256 B) | shift (256 B) of a slab's 64 channels
-constexpr unsigned D_LDS = D_AFF + 8 * 1024;
+constexpr unsigned D_DUMP = D_FLAGS + 64;                              // 8 waves x 256 B: where the lanes other than 0 put their copy of a progress word
+constexpr unsigned D_DMADUMP = D_DUMP + 8 * 256;                       // 4 KiB: target of the DMA instructions that exist only to keep the counted waits uniform
+constexpr unsigned D_AFF = D_DMADUMP + 4096;                           // [producer wave 4][table 2] x 512 B: scale (256 B) | shift (256 B) of a slab's 64 channels
+constexpr unsigned D_BT = D_AFF + 8 * 512;                               // [unit parity 2] x (bias 128 floats | time embedding 128 floats) of a unit's channel tile
+constexpr unsigned D_LDS = D_BT + 2 * 1024;
+static_assert(D_LDS <= 160 * 1024, "LDS budget of one workgroup per CU");
 constexpr unsigned D_OOR = 0x80000000u;                                // beyond num_records of every eligible tensor: the load returns zeros
 constexpr int D_NROUND = 11;                                           // 324 pixels x 8 chunks = 2592 = 10 x 256 + 32 lane-chunks
 enum { D_RES = 1, D_STATS = 2 };
@@ -87,6 +89,22 @@ __device__ __forceinline__ float u2f(unsigned v) { return __builtin_bit_cast(flo
 
 struct UnitC { int b, oy0, ox0, n0; };
 
+#ifdef C3D_STAMPS   // diagnostic build only (scripts/conv_stamps_d.py): cycle sums / poll counts of waves 0 and 4 of workgroup 0
+__device__ unsigned long long c3d_dbg[48];
+__device__ __forceinline__ unsigned long long d_stamp() {
+  __builtin_amdgcn_sched_barrier(0);
+  unsigned long long t = __builtin_amdgcn_s_memtime();
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+  return t;
+}
+#define DSTAMP(v) const unsigned long long v = d_stamp()
+#define DACC(i, expr) dbg[i] += (expr)
+#else
+#define DSTAMP(v)
+#define DACC(i, expr)
+#endif
+
 template <int FLAGS>
 __global__ __launch_bounds__(512, 2) void conv3x3d_kernel(const ConvParams p, const int units) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -103,18 +121,25 @@ __global__ __launch_bounds__(512, 2) void conv3x3d_kernel(const ConvParams p, co
   const int u0 = (int)((long long)sw * units / G), u1 = (int)((long long)(sw + 1) * units / G);
   const int n_u = u1 - u0;
   const int S = n_u * nslab * 9, total_slabs = n_u * nslab;
-  auto decode = [&](int u) __attribute__((always_inline)) -> UnitC {
+  auto decode = [&](int u) __attribute__((always_inline)) -> UnitC {   // (readfirstlane: descriptors and LDS-DMA bases built from these must be provably uniform)
     UnitC c;
     int t = u / ntn;
-    c.n0 = (u - t * ntn) * 128;
+    c.n0 = __builtin_amdgcn_readfirstlane((u - t * ntn) * 128);
     const int t2 = t / tiles_x;
-    c.ox0 = (t - t2 * tiles_x) * 16;
+    c.ox0 = __builtin_amdgcn_readfirstlane((t - t2 * tiles_x) * 16);
     const int t3 = t2 / tiles_y;
-    c.oy0 = (t2 - t3 * tiles_y) * 16;
-    c.b = t3;
+    c.oy0 = __builtin_amdgcn_readfirstlane((t2 - t3 * tiles_y) * 16);
+    c.b = __builtin_amdgcn_readfirstlane(t3);
     return c;
   };
 
+  // Stagger: workgroups that start together stay in lock-step (equal work per unit), and then all 256 of them store their 64 KB output
+  // tiles in the same few microseconds: the epilogue, the one phase in which the matrix pipes idle, is stretched 4x by a chip-wide write
+  // burst (scripts/conv_stamps_d.py).  One sixteenth of a unit's duration per phase step spreads the epilogues evenly over time.
+  if (n_u >= 4) {
+    const int nsleep = ((id >> 3) & 15) * nslab;
+    for (int k = 0; k < nsleep; ++k) __builtin_amdgcn_s_sleep(10);
+  }
   if (tid < 8) *reinterpret_cast<volatile unsigned*>(smem_raw + D_FLAGS + tid * 4) = 0u;
   __syncthreads();
   if (n_u <= 0) return;
@@ -127,22 +152,27 @@ __global__ __launch_bounds__(512, 2) void conv3x3d_kernel(const ConvParams p, co
     // SOURCE address: lane l of a piece fetches channel chunk (l & 7) ^ swzx(hx)) and are normalised IN PLACE two iterations later:
     // ds_read own chunk + this wave's private scale / shift table (also by DMA) -> gn_pair -> mask -> ds_write, all inside one basic block.
     const int pw = wave - 4;
-    const bool silu = p.silu_in != 0;
     const int ld1 = p.ld1 ? p.ld1 : p.C1;
     const long long Kw = 9LL * Cin;
-    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)((long long)p.B * H * W * ld1 * 2), 0x00020000);
     const __amdgpu_buffer_rsrc_t scrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.gn_scale, 0, (int)((long long)p.B * Cin * 4), 0x00020000);
     const __amdgpu_buffer_rsrc_t shrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.gn_shift, 0, (int)((long long)p.B * Cin * 4), 0x00020000);
     const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, (int)((long long)p.Nrows * Kw * 2), 0x00020000);
     const unsigned pflag = lds0 + D_FLAGS + (unsigned)pw * 4u, cflags = lds0 + D_FLAGS + 16u;
 
-    // per-round constants of this lane: round r = piece pw + 4 r; halo pixel (hy, hx), channel chunk kc
-    unsigned rc[D_NROUND];   // hy << 16 | hx << 8 | kc, 0xffffffff: no such pixel
+    // per-round constants of this lane (round r = piece pw + 4 r, lane l -> halo pixel px = 8 (pw + 4 r) + l / 8):
+    //   DMA side: the lane fetches channel chunk (l & 7) ^ swzx(hx) into position l & 7 of the pixel's 128-byte row (LDS-DMA writes lane-linear);
+    //   transform side: the lane normalises channel chunk l & 7 -- a FIXED chunk, so its scale / shift live in registers for a whole slab --
+    //   which sits at position (l & 7) ^ swzx(hx) of the same row.
+    unsigned rc_yx[D_NROUND];   // hy << 8 | hx, 0xffff: no such pixel (piece 40's pad pixels; pieces that do not exist)
+    unsigned rc_rel[D_NROUND];  // DMA source offset relative to halo pixel (0, 0) of the unit: ((hy W + hx) pitch + 8 chunk) * 2 bytes
+    unsigned rc_lds[D_NROUND];  // transform address inside a halo image
 #pragma unroll
     for (int r = 0; r < D_NROUND; ++r) {
       const int px = (pw + 4 * r) * 8 + (lane >> 3);
-      const int hy = px / D_HWD, hx = px - hy * D_HWD;
-      rc[r] = px < D_HPX ? (unsigned)(hy << 16 | hx << 8 | ((lane & 7) ^ d_swzx(hx))) : 0xffffffffu;
+      const int hy = px / D_HWD, hx = px - hy * D_HWD, sz = d_swzx(hx);
+      rc_yx[r] = px < D_HPX ? (unsigned)(hy << 8 | hx) : 0xffffu;
+      rc_rel[r] = (unsigned)(((hy * W + hx) * ld1 + ((lane & 7) ^ sz) * 8) * 2);
+      rc_lds[r] = lds0 + (unsigned)(px * 128 + (((lane & 7) ^ sz) << 4));
     }
     // ---- cursors ----
     int w_step = 0, w_tap = 0, w_c = 0, w_u = u0;   // weights: next step whose slice is issued
@@ -155,45 +185,75 @@ __global__ __launch_bounds__(512, 2) void conv3x3d_kernel(const ConvParams p, co
       }
     };
     set_wvoff(decode(u0).n0);
-    auto issue_w = [&]() __attribute__((always_inline)) {   // slice of step w_step -> ring slot w_step % D_NSLOT, then advance
-      unsigned char* dst = smem_raw + D_WOFF + (unsigned)(w_step & (D_NSLOT - 1)) * D_WSLOT + pw * 4096;
-      const bool live = w_step < S;
-      const int soff = live ? (w_tap * Cin + w_c * 64) * 2 : 0;
-      if (!live) dst = smem_raw + D_DMADUMP;        // past the end: the same four instructions (the counted waits stay valid), data nobody reads
-      static_for<0, 4>([&](auto ic) {
-        constexpr int i = decltype(ic)::value;
+    // slice of step w_step -> ring slot w_step % D_NSLOT in four 1-KiB pieces (issued one by one between the transform's arithmetic: a wave
+    // that issues its vector-memory instructions back to back waits ~100 cycles on each), then advance
+    unsigned char* w_dst = nullptr; int w_soff = 0; bool w_live = false;
+    auto w_begin = [&]() __attribute__((always_inline)) {
+      w_live = w_step < S;
+      w_dst = w_live ? smem_raw + D_WOFF + (unsigned)(w_step & (D_NSLOT - 1)) * D_WSLOT + pw * 4096 : smem_raw + D_DMADUMP;   // past the end: the same
+      w_soff = w_live ? (w_tap * Cin + w_c * 64) * 2 : 0;                                                                      // instructions, data nobody reads
+    };
+    auto w_piece = [&](auto ic) __attribute__((always_inline)) {
+      constexpr int i = decltype(ic)::value;
 #if defined(__HIP_DEVICE_COMPILE__)   // the host pass rejects this builtin (target feature) and then silently drops the kernel stub
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (lptr_t*)dst, 16, live ? w_voff[i] : (int)D_OOR, soff, i * 1024, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (lptr_t*)w_dst, 16, w_live ? w_voff[i] : (int)D_OOR, w_soff, i * 1024, 0);
 #endif
-      });
-      if (live) {
+    };
+    // bias and time embedding of the unit the weight cursor enters -> LDS table (unit parity): the consumers start that unit's sums from it.
+    // Issued behind the iteration's other pieces by producer wave 0 only: the next counted wait then also covers some halo pieces (stricter, never weaker).
+    const __amdgpu_buffer_rsrc_t brsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(p.bias ? p.bias : p.gn_scale), 0, p.bias ? p.Nrows * 4 : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t trsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(p.temb ? p.temb : p.gn_scale), 0, p.temb ? (int)((long long)p.B * p.ld_temb * 4) : 0, 0x00020000);
+    auto dma_bt = [&](const UnitC& un, int parity) __attribute__((always_inline)) {
+      if (pw == 0 && lane < 32) {
+        unsigned char* dst = smem_raw + D_BT + (unsigned)parity * 1024u;
+#if defined(__HIP_DEVICE_COMPILE__)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(brsrc, (lptr_t*)dst, 16, (un.n0 + lane * 4) * 4, 0, 0, 0);            // no bias: zero records, the DMA writes zeros
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(trsrc, (lptr_t*)(dst + 512), 16, (un.b * p.ld_temb + un.n0 + lane * 4) * 4, 0, 0, 0);
+#endif
+      }
+    };
+    auto w_end = [&]() __attribute__((always_inline)) {
+      if (w_live) {
         ++w_step;
         if (++w_tap == 9) {
           w_tap = 0;
-          if (++w_c == nslab) { w_c = 0; ++w_u; if (w_u < u1) set_wvoff(decode(w_u).n0); }
+          if (++w_c == nslab) {
+            w_c = 0; ++w_u;
+            if (w_u < u1) { const UnitC un = decode(w_u); set_wvoff(un.n0); dma_bt(un, (w_u - u0) & 1); }
+          }
         }
       }
     };
+    auto issue_w = [&]() __attribute__((always_inline)) { w_begin(); static_for<0, 4>([&](auto ic) { w_piece(ic); }); w_end(); };
     // halo: the slab being built (global slab index l_k, unit coordinates l_un, slab of the unit l_c); l_k >= total_slabs: nothing to build
     int l_k = 0, l_c = 0, l_u = u0;
     UnitC l_un = decode(u0);
+    // per unit: which of this lane's halo pixels lie inside the image (bit r of vbits), and a descriptor whose base is halo pixel (0, 0) of
+    // the unit (it may lie in front of the tensor for border tiles: only lanes whose pixel is inside are ever given a real offset)
+    unsigned vbits = 0;
+    __amdgpu_buffer_rsrc_t xrsrc;
+    auto set_unit = [&]() __attribute__((always_inline)) {
+      vbits = 0;
+#pragma unroll
+      for (int r = 0; r < D_NROUND; ++r) {
+        const int hy = (int)(rc_yx[r] >> 8), hx = (int)(rc_yx[r] & 0xff);
+        const bool inb = rc_yx[r] != 0xffffu && (unsigned)(l_un.oy0 + hy - 1) < (unsigned)H && (unsigned)(l_un.ox0 + hx - 1) < (unsigned)W;
+        vbits |= inb ? 1u << r : 0u;
+      }
+      const long long org = ((long long)(l_un.b * H + l_un.oy0 - 1) * W + l_un.ox0 - 1) * ld1 * 2;
+      const unsigned long long xa = (unsigned long long)reinterpret_cast<const char*>(p.x) + (unsigned long long)org;
+      const unsigned xlo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)xa), xhi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(xa >> 32));
+      xrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)xhi << 32) | xlo), 0, 0x7fffffff, 0x00020000);
+    };
+    set_unit();
     auto next_slab = [&]() __attribute__((always_inline)) {
       ++l_k;
-      if (++l_c == nslab) { l_c = 0; ++l_u; if (l_u < u1) l_un = decode(l_u); }
-    };
-    auto lane_inb = [&](auto rc_, bool& inb, unsigned& pix) __attribute__((always_inline)) {
-      constexpr int r = decltype(rc_)::value;
-      const int hy = (int)(rc[r] >> 16), hx = (int)((rc[r] >> 8) & 0xff);
-      const int iy = l_un.oy0 + hy - 1, ix = l_un.ox0 + hx - 1;
-      inb = rc[r] != 0xffffffffu && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
-      pix = (unsigned)((l_un.b * H + iy) * W + ix);
+      if (++l_c == nslab) { l_c = 0; ++l_u; if (l_u < u1) { l_un = decode(l_u); set_unit(); } }
     };
     auto dma_round = [&](auto rc_, unsigned hbuf) __attribute__((always_inline)) {   // raw piece pw + 4 r of the slab at the cursor -> its place in image hbuf
       constexpr int r = decltype(rc_)::value;
-      bool inb; unsigned pix;
-      lane_inb(rc_, inb, pix);
       const bool live = l_k < total_slabs && (r < 10 || pw == 0);
-      const int voff = live && inb ? (int)((pix * (unsigned)ld1 + (rc[r] & 7u) * 8u) * 2u) : (int)D_OOR;
+      const int voff = live && ((vbits >> r) & 1u) ? (int)rc_rel[r] : (int)D_OOR;
       unsigned char* dst = live ? smem_raw + hbuf + (unsigned)(pw + 4 * r) * 1024u : smem_raw + D_DMADUMP;
 #if defined(__HIP_DEVICE_COMPILE__)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (lptr_t*)dst, 16, voff, l_c * 128, 0, 0);
@@ -202,90 +262,134 @@ __global__ __launch_bounds__(512, 2) void conv3x3d_kernel(const ConvParams p, co
     auto dma_affine = [&](int tab) __attribute__((always_inline)) {   // scale | shift of the slab's 64 channels -> this wave's table `tab` (512 B): lanes 0-15 | 16-31
       const bool live = l_k < total_slabs;
       const int voff = live && lane < 32 ? (l_un.b * Cin + l_c * 64) * 4 + (lane & 15) * 16 : (int)D_OOR;
-      unsigned char* dst = live ? smem_raw + D_AFF + (unsigned)(pw * 2 + tab) * 1024u : smem_raw + D_DMADUMP;
+      unsigned char* dst = live ? smem_raw + D_AFF + (unsigned)(pw * 2 + tab) * 512u : smem_raw + D_DMADUMP;
 #if defined(__HIP_DEVICE_COMPILE__)
       if (lane < 16) __builtin_amdgcn_raw_ptr_buffer_load_lds(scrsrc, (lptr_t*)dst, 16, voff, 0, 0, 0);
-      else __builtin_amdgcn_raw_ptr_buffer_load_lds(shrsrc, (lptr_t*)dst, 16, voff, 0, 0, 0);
+      else if (lane < 32) __builtin_amdgcn_raw_ptr_buffer_load_lds(shrsrc, (lptr_t*)dst, 16, voff, 0, 0, 0);
 #endif
     };
-    auto xform_round = [&](auto rc_, unsigned hbuf, int tab) __attribute__((always_inline)) {   // normalise + activate + mask chunk r in place
-      constexpr int r = decltype(rc_)::value;
-      bool inb; unsigned pix;
-      lane_inb(rc_, inb, pix);
-      const unsigned addr = lds0 + hbuf + (unsigned)(pw + 4 * r) * 1024u + (unsigned)lane * 16u;
-      const unsigned taddr = lds0 + D_AFF + (unsigned)(pw * 2 + tab) * 1024u + (rc[r] & 7u) * 32u;
-      u32x4 x, sc0, sc1, sh0, sh1;
-      asm volatile("ds_read_b128 %0, %5\n\tds_read_b128 %1, %6\n\tds_read_b128 %2, %6 offset:16\n\tds_read_b128 %3, %6 offset:256\n\tds_read_b128 %4, %6 offset:272\n\t"
-                   "s_waitcnt lgkmcnt(0)"
-                   : "=&v"(x), "=&v"(sc0), "=&v"(sc1), "=&v"(sh0), "=&v"(sh1) : "v"(addr), "v"(taddr) : "memory");
-      const float s0 = u2f(sc0[0]), s1 = u2f(sc0[1]), s2 = u2f(sc0[2]), s3 = u2f(sc0[3]), s4 = u2f(sc1[0]), s5 = u2f(sc1[1]), s6 = u2f(sc1[2]), s7 = u2f(sc1[3]);
-      const float t0 = u2f(sh0[0]), t1 = u2f(sh0[1]), t2 = u2f(sh0[2]), t3 = u2f(sh0[3]), t4 = u2f(sh1[0]), t5 = u2f(sh1[1]), t6 = u2f(sh1[2]), t7 = u2f(sh1[3]);
-      const unsigned x0 = x[0], x1 = x[1], x2 = x[2], x3 = x[3];
-      u32x4 v;
-      if (silu) {
-        v[0] = gn_pair<true>(x0, s0, t0, s1, t1); v[1] = gn_pair<true>(x1, s2, t2, s3, t3);
-        v[2] = gn_pair<true>(x2, s4, t4, s5, t5); v[3] = gn_pair<true>(x3, s6, t6, s7, t7);
-      } else {
-        v[0] = gn_pair<false>(x0, s0, t0, s1, t1); v[1] = gn_pair<false>(x1, s2, t2, s3, t3);
-        v[2] = gn_pair<false>(x2, s4, t4, s5, t5); v[3] = gn_pair<false>(x3, s6, t6, s7, t7);
-      }
-      const unsigned m = inb ? 0xffffffffu : 0u;   // zero padding applies to the NORMALISED tensor
-      v[0] &= m; v[1] &= m; v[2] &= m; v[3] &= m;
-      lds_write128(addr, v);
+    float gs[8], gt[8];   // scale / shift of channels [8 (l & 7), + 8) of the slab being normalised
+    auto read_affine = [&](int tab) __attribute__((always_inline)) {
+      const unsigned taddr = lds0 + D_AFF + (unsigned)(pw * 2 + tab) * 512u + (unsigned)(lane & 7) * 32u;
+      u32x4 sc0, sc1, sh0, sh1;
+      asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:16\n\tds_read_b128 %2, %4 offset:256\n\tds_read_b128 %3, %4 offset:272\n\ts_waitcnt lgkmcnt(0)"
+                   : "=&v"(sc0), "=&v"(sc1), "=&v"(sh0), "=&v"(sh1) : "v"(taddr) : "memory");
+      gs[0] = u2f(sc0[0]); gs[1] = u2f(sc0[1]); gs[2] = u2f(sc0[2]); gs[3] = u2f(sc0[3]); gs[4] = u2f(sc1[0]); gs[5] = u2f(sc1[1]); gs[6] = u2f(sc1[2]); gs[7] = u2f(sc1[3]);
+      gt[0] = u2f(sh0[0]); gt[1] = u2f(sh0[1]); gt[2] = u2f(sh0[2]); gt[3] = u2f(sh0[3]); gt[4] = u2f(sh1[0]); gt[5] = u2f(sh1[1]); gt[6] = u2f(sh1[2]); gt[7] = u2f(sh1[3]);
+    };
+    auto quad = [&](auto hc, const u32x4& x, u32x4& v) __attribute__((always_inline)) {   // elements 4h .. 4h+3 of a chunk
+      constexpr int h = decltype(hc)::value;
+      unsigned oa, ob;
+      gn_quad<true>(x[2 * h], x[2 * h + 1], gs[4 * h], gt[4 * h], gs[4 * h + 1], gt[4 * h + 1], gs[4 * h + 2], gt[4 * h + 2], gs[4 * h + 3], gt[4 * h + 3], oa, ob);   // SiLU always (conv3x3d_selected)
+      v[2 * h] = oa; v[2 * h + 1] = ob;
     };
     // group g of a slab = rounds 2g, 2g+1 (g < 5); group 5 = round 10 (piece 40: wave 4 only, its last four pixels are padding)
-    auto dma_group = [&](auto gc, unsigned hbuf, int tab) __attribute__((always_inline)) {
-      constexpr int g = decltype(gc)::value;
-      if constexpr (g == 0) dma_affine(tab);
-      dma_round(ic_t<2 * g>{}, hbuf);
-      if constexpr (g < 5) dma_round(ic_t<2 * g + 1>{}, hbuf);
-    };
-    auto xform_group = [&](auto gc, unsigned hbuf, int tab) __attribute__((always_inline)) {
-      constexpr int g = decltype(gc)::value;
-      if (l_k < total_slabs) {
-        if constexpr (g < 5) { xform_round(ic_t<2 * g>{}, hbuf, tab); xform_round(ic_t<2 * g + 1>{}, hbuf, tab); }
-        else if (pw == 0) xform_round(ic_t<10>{}, hbuf, tab);
+    // One producer iteration's work: the step's four weight pieces, the halo pieces of group GD (-1: none; with group 0 the scale / shift
+    // table), and the in-place transform of group GX (-1: none), with the DMA instructions spread between the transform's four quads.
+    auto iteration_work = [&](auto gdc, auto gxc, auto wc_, unsigned hbuf, int tab) __attribute__((always_inline)) {
+      constexpr int GD = decltype(gdc)::value, GX = decltype(gxc)::value;
+      constexpr bool WITH_W = decltype(wc_)::value != 0;   // 0: the prologue's transform of the first image (nothing to issue)
+      if constexpr (WITH_W) w_begin();
+      auto dma_slot = [&](auto kc) __attribute__((always_inline)) {   // slot k of 4.  ALL weight pieces before the halo pieces: the next iteration's
+        constexpr int k = decltype(kc)::value;                          // wait then retires the weights while the (HBM-latency) halo pieces fly on
+        if constexpr (WITH_W) { if constexpr (k == 0) { w_piece(ic_t<0>{}); w_piece(ic_t<1>{}); } if constexpr (k == 1) w_piece(ic_t<2>{}); if constexpr (k == 2) w_piece(ic_t<3>{}); }
+        if constexpr (GD >= 0) {
+          if constexpr (k == 3) {
+            if constexpr (GD == 0) dma_affine(tab);
+            dma_round(ic_t<2 * GD>{}, hbuf);
+            if constexpr (GD < 5) dma_round(ic_t<2 * GD + 1>{}, hbuf);
+          }
+        }
+      };
+      const bool xf = GX >= 0 && l_k < total_slabs && (GX < 5 || pw == 0);
+      if (xf) {
+        if constexpr (GX == 0) read_affine(tab);
+        if constexpr (GX >= 0 && GX < 5) {
+          const unsigned a0 = rc_lds[2 * (GX < 0 ? 0 : GX)] + hbuf, a1 = rc_lds[2 * (GX < 0 ? 0 : GX) + 1] + hbuf;
+          u32x4 x0, x1, v0, v1;
+          asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %3\n\ts_waitcnt lgkmcnt(0)" : "=&v"(x0), "=&v"(x1) : "v"(a0), "v"(a1) : "memory");
+          const unsigned k0 = (unsigned)__builtin_amdgcn_sbfe((int)vbits, 2 * (GX < 0 ? 0 : GX), 1), k1 = (unsigned)__builtin_amdgcn_sbfe((int)vbits, 2 * (GX < 0 ? 0 : GX) + 1, 1);
+          quad(ic_t<0>{}, x0, v0); dma_slot(ic_t<0>{});
+          quad(ic_t<1>{}, x0, v0); dma_slot(ic_t<1>{});
+          v0[0] &= k0; v0[1] &= k0; v0[2] &= k0; v0[3] &= k0;   // zero padding applies to the NORMALISED tensor
+          lds_write128(a0, v0);
+          quad(ic_t<0>{}, x1, v1); dma_slot(ic_t<2>{});
+          quad(ic_t<1>{}, x1, v1); dma_slot(ic_t<3>{});
+          v1[0] &= k1; v1[1] &= k1; v1[2] &= k1; v1[3] &= k1;
+          lds_write128(a1, v1);
+        } else if constexpr (GX == 5) {
+          const unsigned a0 = rc_lds[10] + hbuf;
+          u32x4 x0, v0;
+          asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(x0) : "v"(a0) : "memory");
+          const unsigned k0 = (unsigned)__builtin_amdgcn_sbfe((int)vbits, 10, 1);
+          quad(ic_t<0>{}, x0, v0); dma_slot(ic_t<0>{}); dma_slot(ic_t<1>{});
+          quad(ic_t<1>{}, x0, v0); dma_slot(ic_t<2>{}); dma_slot(ic_t<3>{});
+          v0[0] &= k0; v0[1] &= k0; v0[2] &= k0; v0[3] &= k0;
+          lds_write128(a0, v0);
+        }
+      } else {
+        static_for<0, 4>([&](auto kc) { dma_slot(kc); });
       }
+      if constexpr (WITH_W) w_end();
     };
+    // progress word by ONE unmasked ds_write_b32: lane 0 hits the word, the other lanes a dump row of their own
+    const unsigned pflag_addr = lane == 0 ? pflag : lds0 + D_DUMP + (unsigned)(4 + pw) * 256u + (unsigned)lane * 4u;
     auto publish = [&](unsigned v) __attribute__((always_inline)) {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      if (lane == 0) lds_write32(pflag, v);
+      lds_write32(pflag_addr, v);
     };
 
+#ifdef C3D_STAMPS
+    unsigned long long dbg[32] = {0};
+#endif
+    DSTAMP(p_t0);
     // ---- prologue: weight slices of steps 0..2, the whole first halo image ----
     issue_w(); issue_w(); issue_w();
-    static_for<0, 6>([&](auto gc) { dma_group(gc, 0u, 0); });
+    dma_affine(0);
+    static_for<0, D_NROUND>([&](auto rc_) { dma_round(rc_, 0u); });
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    static_for<0, 6>([&](auto gc) { xform_group(gc, 0u, 0); });
+    static_for<0, 6>([&](auto gc) { iteration_work(ic_t<-1>{}, gc, ic_t<0>{}, 0u, 0); });
     next_slab();
     publish(1u);
+    DSTAMP(p_t1);
+    DACC(0, p_t1 - p_t0);
 
     // ---- iterations: i = 9 blk + ph mirrors consumer step i; block blk builds the image of slab blk + 1 (cursor l_k) ----
     // ph:              0    1    2    3    4    5    6    7    8
     // DMA (group)      -    0    1    2    3    4    5    -    -      (+ the scale / shift table with group 0, + 4 weight pieces every phase)
     // transform        -    -    -    0    1    2    3    4    5      (two iterations behind its DMA)
     // The halo buffer is free from iteration 9 blk + 1 on (gate: every consumer past the first weights of step 9 blk).
-    // vmcnt before the transform of iteration i = everything issued after the halo pieces of iteration i - 2:
-    //   4 + halo pieces of iteration i - 1, 4 + halo pieces of iteration i          (halo pieces per phase: 0 4 2 2 2 2 1 0 0; the table is two instructions)
+    // The iteration opens with ONE counted wait that leaves only iteration i - 1's halo / table pieces in flight (0 4 2 2 2 2 1 0 0 by phase;
+    // they are issued behind its weight pieces): the halo pieces about to be normalised (iteration i - 2) and the weight slice of step
+    // i + 2 (iteration i - 1) have landed.  Progress i + 2 at the end of the iteration therefore means: weights up to step i + 2, halo groups
+    // up to this iteration's.
+    // Past the end of the unit list the same instructions are issued with out-of-range sources: the counts stay valid.
     const int nblk = n_u * nslab;
     for (int blk = 0; blk < nblk; ++blk) {
       const unsigned hbuf = (unsigned)((blk + 1) & 1) * D_HB;
       const int tab = (blk + 1) & 1;
       static_for<0, 9>([&](auto phc) {
         constexpr int ph = decltype(phc)::value;
-        constexpr int HP[10] = {0, 0, 4, 2, 2, 2, 2, 1, 0, 0};        // HP[ph + 1] = halo (+ table) pieces issued at phase ph; HP[0] = phase 8 of the previous block
-        constexpr int NWAIT = 8 + HP[ph] + HP[ph + 1];
+        constexpr int HP[9] = {0, 4, 2, 2, 2, 2, 1, 0, 0};
+        constexpr int NWAIT = HP[(ph + 8) % 9];
         const int i = blk * 9 + ph;
-        while (flags_min_now(cflags) < (unsigned)i) __builtin_amdgcn_s_sleep(1);
-        issue_w();
-        if constexpr (ph >= 1 && ph <= 6) dma_group(ic_t<ph - 1>{}, hbuf, tab);
+        DSTAMP(q0);
+        while (flags_min_now(cflags) < (unsigned)i) { __builtin_amdgcn_s_sleep(1); DACC(5, 1); }
+        DSTAMP(q1);
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NWAIT) : "memory");
-        if constexpr (ph >= 3) xform_group(ic_t<ph - 3>{}, hbuf, tab);
-        if constexpr (ph == 8) next_slab();
+        DSTAMP(q2);
+        iteration_work(ic_t<(ph >= 1 && ph <= 6) ? ph - 1 : -1>{}, ic_t<ph >= 3 ? ph - 3 : -1>{}, ic_t<1>{}, hbuf, tab);
+        DSTAMP(q3);
         publish((unsigned)i + 2u);
+        if constexpr (ph == 8) next_slab();   // (behind the publication: a unit change is ~250 instructions of tile arithmetic)
+        DSTAMP(q4);
+        DACC(1, q1 - q0); DACC(2, q2 - q1); DACC(3, q3 - q2); DACC(4, q4 - q3); DACC(6, 1); DACC(8 + ph, q3 - q2); DACC(17 + ph, q1 - q0);
       });
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef C3D_STAMPS
+    { DSTAMP(p_t2); dbg[7] = p_t2 - p_t0; if (blockIdx.x == 0 && pw == 0 && lane == 0) for (int i = 0; i < 32; ++i) c3d_dbg[16 + i] = dbg[i]; }
+#endif
     return;
   }
 
@@ -304,6 +408,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3d_kernel(const ConvParams p, co
   // progress word of this wave by ONE unmasked ds_write_b32: lane 0 hits the word, the other lanes a dump row of their own
   const unsigned cflag_addr = lane == 0 ? lds0 + D_FLAGS + 16u + (unsigned)wave * 4u : lds0 + D_DUMP + (unsigned)wave * 256u + (unsigned)lane * 4u;
 
+#ifdef C3D_STAMPS
+  unsigned long long dbg[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#endif
   f32x4 acc[4][8];
   f16x8 Wf[2][4], X[2][2][2];   // Wf[k-half][channel tile]; X[buffer][row of the pair][k-half]
   u32x4 fl;                     // producers' progress words, read in the shadow of pair 2
@@ -358,26 +465,26 @@ __global__ __launch_bounds__(512, 2) void conv3x3d_kernel(const ConvParams p, co
   // between the packed values of two rows P = 2pr, Q = 2pr + 1 leaves lanes with even g holding channels 4g .. 4g+7 of row P and lanes
   // with odd g channels 4(g-1) .. 4(g-1)+7 of row Q: 16-byte stores; the residual is read in the same shape and un-swapped the same way
   // (the swap is its own inverse).
-  auto epilogue = [&](const UnitC& u, const UnitC& nu, bool has_next) __attribute__((always_inline)) {
+  auto epilogue = [&](const UnitC& u, int next_parity, bool has_next) __attribute__((always_inline)) {
     const int mrow = wave_m * 8 + (g & 1);
     const unsigned pix = (unsigned)((u.b * H + u.oy0 + mrow) * W + u.ox0 + l15);
     const unsigned chb = (unsigned)(u.n0 + wave_n * 64 + (g & ~1) * 4);
     const unsigned yoff = (pix * (unsigned)p.ldy + chb) * 2u, ystep = (unsigned)(2 * W * p.ldy) * 2u;
     const unsigned roff = (pix * (unsigned)p.ld_res + chb) * 2u, rstep = (unsigned)(2 * W * p.ld_res) * 2u;
     constexpr bool RES = (FLAGS & D_RES) != 0, ST = (FLAGS & D_STATS) != 0;
-    if (has_next) load_bt(nu);
+    DSTAMP(ep0);
     u32x4 R[2][4];
     if constexpr (RES) {
 #pragma unroll
       for (int a = 0; a < 4; ++a) R[0][a] = __builtin_amdgcn_raw_buffer_load_b128(rrsrc, (int)(roff + a * 32), 0, 0);
     }
-    float sv[16], qv[16];
-    if constexpr (ST) {
-#pragma unroll
-      for (int j = 0; j < 16; ++j) { sv[j] = 0.f; qv[j] = 0.f; }
-    }
+    // fused GroupNorm statistics: per (channel tile, row pair) the 4 sums and 4 sums of squares of the lane's channels are reduced over the
+    // 16 pixel lanes at once (row16_reduce_spread<8>: lane keeps ONE of the eight totals, value index jv) and added up over the row pairs:
+    // four live registers instead of thirty-two (the epilogue shares the register file with 128 accumulators)
+    float tot[4] = {0.f, 0.f, 0.f, 0.f};
     static_for<0, 4>([&](auto pc) {
       constexpr int pr = decltype(pc)::value;
+      DSTAMP(ep1);
       if constexpr (RES && pr < 3) {
 #pragma unroll
         for (int a = 0; a < 4; ++a) R[(pr + 1) & 1][a] = __builtin_amdgcn_raw_buffer_load_b128(rrsrc, (int)(roff + (pr + 1) * rstep + a * 32), 0, 0);
@@ -393,33 +500,57 @@ __global__ __launch_bounds__(512, 2) void conv3x3d_kernel(const ConvParams p, co
           v1 += up4(__builtin_bit_cast(f16x4, make_uint2(s0[1], s1[1])));
         }
         const f16x4 o0 = cvt4(v0), o1 = cvt4(v1);
-        if constexpr (ST) {   // statistics of what the consumer will read: the fp16-rounded values
-          const f32x4 f0 = up4(o0), f1 = up4(o1);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) { sv[a * 4 + r] += f0[r] + f1[r]; qv[a * 4 + r] += f0[r] * f0[r] + f1[r] * f1[r]; }
-        }
         const uint2 q0 = __builtin_bit_cast(uint2, o0), q1 = __builtin_bit_cast(uint2, o1);
         auto r0 = __builtin_amdgcn_permlane16_swap(q0.x, q1.x, false, false);
         auto r1 = __builtin_amdgcn_permlane16_swap(q0.y, q1.y, false, false);
         __builtin_amdgcn_raw_buffer_store_b128((u32x4){r0[0], r1[0], r0[1], r1[1]}, yrsrc, (int)(yoff + pr * ystep + a * 32), 0, 0);
         asm volatile("s_nop 1" ::: "memory");   // the next VALU instruction may overwrite the store's data registers (profiles/r02_conv3x3_pingpong.md)
+        if constexpr (ST) {   // statistics of what the consumer of this tensor will read: the fp16-rounded values
+          const f32x4 f0 = up4(o0), f1 = up4(o1);
+          float x8[8];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { x8[r] = f0[r] + f1[r]; x8[4 + r] = f0[r] * f0[r] + f1[r] * f1[r]; }
+          tot[a] += row16_reduce_spread<8>(x8, l15);
+        }
       }
+      DSTAMP(ep2);
+      DACC(8 + pr, ep2 - ep1);
     });
-    if constexpr (ST) {   // one row block per consumer wave (8 x 16 pixels): totals over the 16 pixel lanes, spread over the lanes (common.h)
-      const float st_s = row16_reduce_spread<16>(sv, l15), st_q = row16_reduce_spread<16>(qv, l15);
-      const int jv = ((l15 >> 3) & 1) | ((l15 >> 1) & 2) | ((l15 << 1) & 4) | ((l15 << 3) & 8);
-      const int n = u.n0 + wave_n * 64 + g * 4 + (jv >> 2) * 16 + (jv & 3);
+    DSTAMP(ep3);
+    if constexpr (ST) {   // one row block per consumer wave (8 x 16 pixels); lanes l15 and l15 ^ 1 hold the same total: the even one stores it
+      const int jv = ((l15 >> 3) & 1) | ((l15 >> 1) & 2) | ((l15 << 1) & 4);   // bits 0-1: channel of the lane's four, bit 2: sum / sum of squares
       const long long rblk = ((long long)(u.oy0 >> 4) * tiles_x + (u.ox0 >> 4)) * 2 + wave_m;
-      *reinterpret_cast<float2*>(p.stats + (((long long)u.b * p.N + n) * p.stats_R + rblk) * 2) = make_float2(st_s, st_q);
+      if ((l15 & 1) == 0) {
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+          const int n = u.n0 + wave_n * 64 + a * 16 + g * 4 + (jv & 3);
+          p.stats[(((long long)u.b * p.N + n) * p.stats_R + rblk) * 2 + (jv >> 2)] = tot[a];
+        }
+      }
     }
-    if (has_next) init_acc();
+    if (has_next) {   // the next unit's sums start at bias + time embedding: table written by producer wave 0 when the weight cursor entered that unit
+      const unsigned taddr = lds0 + D_BT + (unsigned)next_parity * 1024u + (unsigned)(wave_n * 64 + g * 4) * 4u;
+      static_for<0, 4>([&](auto ac) {
+        constexpr int a = decltype(ac)::value;
+        f32x4 bb, tt;
+        asm volatile("ds_read_b128 %0, %2 offset:%3\n\tds_read_b128 %1, %2 offset:%4\n\ts_waitcnt lgkmcnt(0)" : "=&v"(bb), "=&v"(tt) : "v"(taddr), "n"(a * 64), "n"(512 + a * 64) : "memory");
+        const f32x4 b = bb + tt;
+#pragma unroll
+        for (int m = 0; m < 8; ++m) acc[a][m] = b;
+      });
+    }
+    DSTAMP(ep4);
+    DACC(12, ep4 - ep3); DACC(13, ep3 - ep0);
   };
 
+  DSTAMP(c_t0);
   // ---- prologue ----
   UnitC cur = decode(u0), nxt = cur;
   load_bt(cur);
   init_acc();
   wait_producers(1u);
+  DSTAMP(c_t1);
+  DACC(0, c_t1 - c_t0);
   issue_x(ic_t<0>{}, ic_t<0>{}, ic_t<0>{}, 0u, X[0]);
   static_for<0, 4>([&](auto ac) { issue_w1(ac, w_lane); });
 
@@ -462,14 +593,16 @@ __global__ __launch_bounds__(512, 2) void conv3x3d_kernel(const ConvParams p, co
         static_for<0, 4>([&](auto ac) { mfma4(ac, ic_t<2>{}, X[0]); __builtin_amdgcn_sched_barrier(0); });
         // pair 3
         lds_wait_flags(X[1][0][0], X[1][0][1], X[1][1][0], X[1][1][1], fl);
-        // step s + 1 needs producer iteration s complete (weights of step s + 1 landed, halo image of its slab written): progress >= s + 2.
+        // step s + 1 needs its weight slice (producer iteration s - 1 complete: progress >= s + 1) and, if it opens a slab, that slab's halo image
+        // (iteration s complete: progress >= s + 2).
         // At the last step of a unit the same reads go out unchecked and unused (one code path, no join for the register allocator: a
         // second variant of this pair made hipcc spill the weight fragments around every slab); the next unit's first operands are
         // issued again behind the epilogue, whose registers these are.
         if (!(T == 8 && last_slab)) {
-          const unsigned need = (unsigned)s + 2u;
+          const unsigned need = (unsigned)s + (T == 8 ? 2u : 1u);   // weights of step s + 1: iteration s - 1; a new slab's halo image: iteration s
           unsigned have = (unsigned)__builtin_amdgcn_readfirstlane((int)min(min(fl[0], fl[1]), min(fl[2], fl[3])));
-          while (have < need) have = flags_min_now(pflags);
+          while (have < need) { have = flags_min_now(pflags); DACC(1, 1); }
+          DACC(2, 1);
         }
         issue_x(ic_t<0>{}, ic_t<nky>{}, ic_t<nkx>{}, hb_next, X[0]);
         static_for<0, 4>([&](auto ac) {
@@ -481,9 +614,14 @@ __global__ __launch_bounds__(512, 2) void conv3x3d_kernel(const ConvParams p, co
       });
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the unused reads of the unit's last step
-    epilogue(cur, nxt, has_next);
+    DSTAMP(e0);
+    epilogue(cur, (u + 1 - u0) & 1, has_next);
+    DSTAMP(e1);
+    DACC(3, e1 - e0); DACC(4, 1);
     if (has_next) {
-      wait_producers((unsigned)s + 1u);   // step s (first of the next unit) needs producer iteration s - 1
+      wait_producers((unsigned)s + 1u);
+      DSTAMP(e2);
+      DACC(5, e2 - e1);   // step s (first of the next unit) needs producer iteration s - 1
       const unsigned hb0 = (unsigned)((s / 9) & 1) * D_HB;
       issue_x(ic_t<0>{}, ic_t<0>{}, ic_t<0>{}, hb0, X[0]);
       const unsigned wc0 = w_lane + (unsigned)(s & (D_NSLOT - 1)) * D_WSLOT;
@@ -491,6 +629,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3d_kernel(const ConvParams p, co
       cur = nxt;
     }
   }
+#ifdef C3D_STAMPS
+  { DSTAMP(c_t2); dbg[6] = c_t2 - c_t0; if (blockIdx.x == 0 && wave == 0 && lane == 0) for (int i = 0; i < 16; ++i) c3d_dbg[i] = dbg[i]; }
+#endif
 }
 
 int d_num_cus() {
@@ -525,7 +666,7 @@ bool conv3x3d_selected(const ConvParams& p) {
   static const int mode = [] { const char* e = getenv("LDIFF_CONV3X3_DATAFLOW"); return e ? atoi(e) : 1; }();
   if (mode == 0) return false;
   if (p.ks != 3 || p.stride != 1 || p.pad_t != 1 || p.pad_l != 1 || p.ups != 0 || p.w_par || p.splitk > 1) return false;
-  if (!p.gn_scale || p.x2 || p.C2 != 0 || p.C1 % 64 != 0 || p.N % 128 != 0 || p.Nrows < p.N) return false;
+  if (!p.gn_scale || !p.silu_in || p.x2 || p.C2 != 0 || p.C1 % 64 != 0 || p.N % 128 != 0 || p.Nrows < p.N) return false;
   if (p.Hout % 16 != 0 || p.Wout % 16 != 0 || p.Hin != p.Hout || p.Win != p.Wout) return false;
   if (p.out_f32 || p.y_lo || p.res_lo || (p.ldy & 7) || (p.res && (p.ld_res & 7))) return false;
   const long long px = (long long)p.B * p.Hin * p.Win;
@@ -538,6 +679,11 @@ bool conv3x3d_selected(const ConvParams& p) {
   return units >= cus && units * 100 >= rounds * cus * 88;   // the runs must split evenly over the CUs
 }
 int conv3x3d_stats_blocks(const ConvParams& p) { return (p.Hout >> 4) * (p.Wout >> 4) * 2; }   // one row block per consumer wave pair (8 x 16 pixels)
+#ifdef C3D_STAMPS
+extern "C" int ldiff_debug_c3d_stamps(unsigned long long* out) {   // diagnostic build only
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(c3d_dbg), sizeof(unsigned long long) * 48);
+}
+#endif
 void launch_conv3x3d(const ConvParams& p, hipStream_t s) {
   const int f = (p.res ? D_RES : 0) | (p.stats ? D_STATS : 0);
   if (f == 0) launch_c3d<0>(p, s);

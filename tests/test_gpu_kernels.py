@@ -566,6 +566,63 @@ def test_conv_on_split_tensors(lib, name):
         assert (gotn - refn).abs().max() <= 2e-4 * max(1.0, refn.abs().max())
 
 
+@pytest.mark.parametrize("shape", ["one_unit_one_slab", "three_units_two_slabs", "two_channel_tiles_four_slabs"])
+@pytest.mark.parametrize("res,stats,temb", [(0, 0, 0), (1, 0, 1), (0, 1, 0), (1, 1, 1)])
+def test_conv3x3_dataflow_kernel(lib, shape, res, stats, temb):
+    """The producer / consumer conv3x3 kernel (kernels_conv3x3d.hip: GroupNorm + SiLU prologue on maps that fill the chip): every epilogue
+    configuration (residual x fused statistics, with and without a time embedding) on unit lists with one unit per workgroup, several
+    units (tile switches, bias table hand-over) and several channel tiles / slabs.  Three launches each: producers and consumers meet only
+    through progress words in LDS, and a missing wait would show up as a now-and-then wrong tile.  The statistics are checked against the
+    sums of the kernel's own fp16 outputs (they are defined on the rounded values)."""
+    B, Cin, H, W, Cout = {"one_unit_one_slab": (1, 64, 256, 256, 128), "three_units_two_slabs": (3, 128, 256, 256, 128),
+                          "two_channel_tiles_four_slabs": (2, 256, 128, 128, 256)}[shape]
+    g = torch.Generator().manual_seed(res * 4 + stats * 2 + temb + len(shape))
+    x = torch.randn((B, H, W, Cin), generator=g).to(torch.float16)
+    w = (torch.randn((Cout, 3, 3, Cin), generator=g) / math.sqrt(9 * Cin)).to(torch.float16)
+    bias = torch.randn(Cout, generator=g) * 0.1
+    sc, sh = 1.0 + 0.2 * torch.randn((B, Cin), generator=g), 0.2 * torch.randn((B, Cin), generator=g)
+    a = F.silu(x.float() * sc[:, None, None, :] + sh[:, None, None, :]).to(torch.float16).float()   # the kernel rounds the normalised operand to fp16
+    ref = F.conv2d(a.permute(0, 3, 1, 2), w.float().permute(0, 3, 1, 2), bias, padding=1)
+    xd, wd, bd, scd, shd = x.to(DEV), w.reshape(Cout, -1).contiguous().to(DEV), bias.to(DEV), sc.to(DEV), sh.to(DEV)
+    a_ = _lib.ConvArgs()
+    a_.x, a_.C1, a_.B, a_.Hin, a_.Win, a_.Hout, a_.Wout = xd.data_ptr(), Cin, B, H, W, H, W
+    a_.ks, a_.stride, a_.pad_t, a_.pad_l = 3, 1, 1, 1
+    a_.w, a_.N, a_.Nrows, a_.bias = wd.data_ptr(), Cout, Cout, bd.data_ptr()
+    a_.gn_scale, a_.gn_shift, a_.silu_in = scd.data_ptr(), shd.data_ptr(), 1
+    y = torch.empty((B, H, W, Cout), dtype=torch.float16, device=DEV)
+    a_.y, a_.ldy = y.data_ptr(), Cout
+    if temb:
+        t = torch.randn((B, Cout), generator=g) * 0.3
+        td = t.to(DEV)
+        a_.temb, a_.ld_temb = td.data_ptr(), Cout
+        ref = ref + t[:, :, None, None]
+    if res:
+        r = (torch.randn((B, H, W, Cout), generator=g) * 2.0).to(torch.float16)
+        rd = r.to(DEV)
+        a_.res, a_.ld_res = rd.data_ptr(), Cout
+        ref = ref + r.float().permute(0, 3, 1, 2)
+    if stats:
+        R = lib.ldiff_op_conv_stats_blocks(C.byref(a_))
+        assert R > 0
+        st = torch.empty((B, Cout, R, 2), device=DEV)
+        a_.stats = st.data_ptr()
+    for it in range(3):
+        y.fill_(float("nan"))
+        if stats:
+            st.fill_(float("nan"))
+        _lib.check(lib.ldiff_op_conv(C.byref(a_), sp()))
+        torch.cuda.synchronize()
+        got = y.float().cpu().permute(0, 3, 1, 2)
+        assert_close(got, ref, f"{shape} launch {it}")
+        if stats:
+            sums = st.double().cpu().sum(dim=2)                       # [B, Cout, 2]
+            yd = y.double().cpu()
+            want = torch.stack([yd.sum(dim=(1, 2)), (yd * yd).sum(dim=(1, 2))], dim=-1)
+            assert torch.isfinite(sums).all(), f"launch {it}: statistics not written everywhere"
+            err = ((sums - want).abs() / (want.abs() + H * W * 1e-3)).max().item()
+            assert err <= 1e-4, f"launch {it}: fused statistics differ from the sums of the outputs by {err:.3e}"
+
+
 @pytest.mark.parametrize("shape", ["one_tile_per_workgroup", "two_tiles_per_workgroup"])
 @pytest.mark.parametrize("res,lo,stats", [(r, l, s_) for r in (0, 1) for l in (0, 1) for s_ in (0, 1)])
 def test_conv3x3_persistent_kernel_epilogue_configs(lib, shape, res, lo, stats):

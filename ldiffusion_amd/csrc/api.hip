@@ -431,6 +431,11 @@ int ldiff_op_conv(const ldiff_conv_args* a, void* stream) {
     p.w_par = wpar;
     if (p.stats) p.stats_R = conv_stats_blocks_per_image(p);
   }
+  if (conv3x3d_selected(p)) {   // dataflow kernel: fragment-packed weights (the executors cache them per layer; here per call)
+    f16* wf = (f16*)op_scratch(st, 3, conv3x3d_frag_bytes(p));
+    launch_pack_frag_weights(p.w, wf, p.N, p.C1, st);
+    p.w_frag = wf;
+  }
   if (!p.stats && !p.out_f32) p.splitk = conv3x3_eligible(p) ? conv3x3_splitk_plan(p) : gemm_dma_eligible(p) ? gemm_dma_splitk_plan(p) : igemm_splitk_plan(p);
   if (p.splitk > 1) p.splitk_ws = (float*)op_scratch(st, 1, (size_t)p.splitk * p.M * p.N * sizeof(float));
   launch_igemm(p, (hipStream_t)stream);

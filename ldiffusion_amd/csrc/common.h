@@ -79,6 +79,7 @@ struct ConvParams {
   float* splitk_ws;       // [splitk][M][N] fp32 workspace (then reduced + epilogue by splitk_reduce)
   const f16* w_par;       // conv3x3 with ups=1 only: parity weights [4][Nrows][4*Cin] (see kernels_conv3x3.hip); nullptr => 9-tap gather
   unsigned div_ntn, div_tx, div_ty;   // conv3x3 8x16 kernel only, set by its launcher: reciprocals of its tile decode (0 = divisor 1)
+  const f16* w_frag;      // conv3x3 dataflow kernel only (conv3x3d_selected): the weights fragment-packed by launch_pack_frag_weights
 };
 void launch_igemm(const ConvParams& p, hipStream_t s);   // dispatches to the halo-tile 3x3 kernel when eligible
 bool conv3x3_eligible(const ConvParams& p);
@@ -97,6 +98,8 @@ bool conv3x3p_selected(const ConvParams& p);
 // producer / consumer ("dataflow") kernel for GroupNorm-prologue convs on the large maps: kernels_conv3x3d.hip
 bool conv3x3d_selected(const ConvParams& p);
 int conv3x3d_stats_blocks(const ConvParams& p);
+size_t conv3x3d_frag_bytes(const ConvParams& p);
+void launch_pack_frag_weights(const f16* w, f16* wf, int N, int Cin, hipStream_t s);   // [N][9 Cin] K-major -> MFMA A fragments, one KiB each
 void launch_conv3x3d(const ConvParams& p, hipStream_t s);
 int conv3x3p_stats_blocks(const ConvParams& p);
 void launch_conv3x3p(const ConvParams& p, hipStream_t s);

@@ -41,6 +41,7 @@ struct MatW {   // [Nrows][K] fp16 K-major + fp32 bias
   mutable Derived par;            //   upsampler convs: parity weights [4][Nrows][4*Cin]
   mutable Derived dup;            //   split operand: [Nrows][taps][2*Cin] (same weights against the hi and the lo half); key = C1 of a concat
   mutable Derived dup_par;        //   parity weights of the duplicated matrix
+  mutable Derived frag;           //   MFMA-fragment-packed copy for the dataflow conv3x3 kernel (kernels_conv3x3d.hip)
 };
 struct NormW { float* g = nullptr; float* b = nullptr; int C = 0; };
 struct GNss { float* scale = nullptr; float* shift = nullptr; };
@@ -109,6 +110,7 @@ class Exec {
   Act new_act(int B, int H, int W, int C, bool split = false);
   const f16* derived_dup(const MatW& w, int C1_logical, int C2_logical);
   const f16* derived_par(const MatW& w, const f16* src, int Cin, Derived& d);
+  const f16* derived_frag(const MatW& w, const ConvParams& p);
   Act norm_apply(const Act& x, const Act* x2, const GNss& g, bool silu, bool split_out);
   void release(Act& a);
   template <typename T> T* tmp(size_t n) { return reinterpret_cast<T*>(arena.alloc(n * sizeof(T))); }

@@ -276,6 +276,20 @@ const f16* Exec::derived_dup(const MatW& w, int C1, int C2) {
   }
   return w.dup.p;
 }
+const f16* Exec::derived_frag(const MatW& w, const ConvParams& p) {
+  const int gen = weights_gen ? *weights_gen : 0;
+  if (!w.frag.p) {
+    void* q = nullptr;
+    HIP_CHECK(hipMalloc(&q, conv3x3d_frag_bytes(p)));
+    owned.push_back(q);
+    w.frag.p = (f16*)q;
+  }
+  if (w.frag.gen != gen) {   // first use, or the checkpoint was reloaded since
+    launch_pack_frag_weights(w.w, w.frag.p, p.N, p.C1, s);
+    w.frag.gen = gen;
+  }
+  return w.frag.p;
+}
 const f16* Exec::derived_par(const MatW& w, const f16* src, int Cin, Derived& d) {
   const int gen = weights_gen ? *weights_gen : 0;
   if (!d.p) {
@@ -374,6 +388,7 @@ Act Exec::conv(const MatW& w, const Act& x, const Act* x2, const ConvOpts& o) {
   }
   if (!o.out_f32 && p.splitk > 1) p.splitk_ws = tmp<float>((size_t)p.splitk * p.M * p.N);
   else p.splitk = 0;
+  if (!o.split_in && conv3x3_eligible(p) && conv3x3d_selected(p)) p.w_frag = derived_frag(w, p);   // dataflow kernel: MFMA-fragment-packed weights
   launch_igemm(p, s);
   if (p.splitk_ws) arena.free(p.splitk_ws);   // stream-ordered reuse: safe once the launches are enqueued
   if (wfold) { arena.free(bfold); arena.free(wfold); }

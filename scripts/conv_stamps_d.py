@@ -35,11 +35,8 @@ for (B, Cin, H, Cout, res, stats) in cases:
     assert raw.ldiff_debug_c3d_stamps(out) == 0
     c, p = [out[i] for i in range(16)], [out[16 + i] for i in range(32)]
     us = e0.elapsed_time(e1) * 1e3
-    units = max(c[4], 1); iters = max(p[6], 1)
+    units = max(c[4], 1); slabs = max(p[6], 1)
     print(f"B{B} Cin{Cin} H{H} Cout{Cout} res{res} stats{stats}: {us:.0f} us")
-    print(f"  consumer w0: total {c[6]} ticks; first-step wait {c[0]}; steps checked {c[2]}, slow-path polls {c[1]}; units {c[4]}: epilogue {c[3]/units:.0f} ticks each, post-epilogue wait {c[5]/units:.0f};"
+    print(f"  consumer w0: total {c[6]} ticks; first-slab wait {c[0]}; slab checks {c[2]}, polls while waiting {c[1]}; units {c[4]}: epilogue {c[3]/units:.0f} ticks each, hand-over to the next unit {c[5]/units:.0f};"
           f" loop share {(c[6]-c[0]-c[3]-c[5])/max(c[6],1):.3f}")
-    print("  epilogue by row pair:", [round(c[8 + k] / units) for k in range(4)], " stats+init:", round(c[12] / units), " loads+pairs:", round(c[13] / units))
-    nb = max(iters // 9, 1)
-    print("  producer work by phase:", [round(p[8 + k] / nb) for k in range(9)], " gate wait by phase:", [round(p[17 + k] / nb) for k in range(9)])
-    print(f"  producer w4: total {p[7]} ticks; prologue {p[0]}; per iteration ({iters}): gate {p[1]/iters:.0f} ({p[5]} sleeps)  vmcnt {p[2]/iters:.0f}  work {p[3]/iters:.0f}  publish {p[4]/iters:.0f}")
+    print(f"  producer w4: total {p[7]} ticks; per slab ({slabs}): gate + issue {p[1]/slabs:.0f} ({p[5]} sleeps)  wait for the pieces {p[2]/slabs:.0f}  transform + publish {p[3]/slabs:.0f}")

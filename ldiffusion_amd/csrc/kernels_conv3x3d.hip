@@ -68,7 +68,9 @@ __device__ __forceinline__ void lds_wait4(f16x8& a, f16x8& b, f16x8& c, f16x8& d
   asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(CNT));
 }
 template <int CNT>
-__device__ __forceinline__ void vm_wait2(f16x8& a, f16x8& b) { asm volatile("s_waitcnt vmcnt(%2)" : "+v"(a), "+v"(b) : "n"(CNT)); }
+__device__ __forceinline__ void vm_wait4(f16x8& a, f16x8& b, f16x8& c, f16x8& d) {
+  asm volatile("s_waitcnt vmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(CNT));
+}
 template <int OFF>
 __device__ __forceinline__ void glb_read128(f16x8& d, const char* addr) {
   asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(d) : "v"(addr), "n"(OFF) : "memory");
@@ -321,28 +323,32 @@ __global__ __launch_bounds__(512, 2) void conv3x3d_kernel(const ConvParams p, co
   unsigned long long dbg[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #endif
   f32x4 acc[4][8];
-  f16x8 Wf[2][4], X[2][2][2];   // Wf[k-half][channel tile]; X[buffer][row of the pair][k-half]
+  f16x8 Wf[2][4], X[2][4];   // Wf[k-half][channel tile]; X[buffer][row of the group of four]
 
-  auto issue_x = [&](auto pc, auto kyc, auto kxc, unsigned hb, f16x8 (&dst)[2][2]) __attribute__((always_inline)) {
-    constexpr int pr = decltype(pc)::value, ky = decltype(kyc)::value, kx = decltype(kxc)::value;
-    const unsigned b0 = xb[kx] + hb, b1 = b0 ^ 64u;   // chunk bit 2 = k-half: XOR commutes with the swizzle
-    lds_read128<(2 * pr + ky) * D_ROWB>(dst[0][0], b0);
-    lds_read128<(2 * pr + ky) * D_ROWB>(dst[0][1], b1);
-    lds_read128<(2 * pr + 1 + ky) * D_ROWB>(dst[1][0], b0);
-    lds_read128<(2 * pr + 1 + ky) * D_ROWB>(dst[1][1], b1);
+  // A step (tap of a slab) runs as two HALF-steps, one per k-half, each over two groups of four pixel rows.  The weights of a half-step are
+  // loaded one half-step ahead (its registers are the ones the half-step before it has just released: ~512 matrix cycles of lead for an L2
+  // round trip), the pixels of a group one group ahead (~256 cycles for an LDS round trip).
+  auto issue_x = [&](auto gc, auto kyc, auto kxc, auto khc, unsigned hb, f16x8 (&dst)[4]) __attribute__((always_inline)) {   // rows 4 gr .. 4 gr + 3 of k-half kh at tap (ky, kx)
+    constexpr int gr = decltype(gc)::value, ky = decltype(kyc)::value, kx = decltype(kxc)::value, kh = decltype(khc)::value;
+    const unsigned b0 = (xb[kx] + hb) ^ (kh ? 64u : 0u);   // chunk bit 2 = k-half: XOR commutes with the swizzle
+    lds_read128<(4 * gr + ky) * D_ROWB>(dst[0], b0);
+    lds_read128<(4 * gr + 1 + ky) * D_ROWB>(dst[1], b0);
+    lds_read128<(4 * gr + 2 + ky) * D_ROWB>(dst[2], b0);
+    lds_read128<(4 * gr + 3 + ky) * D_ROWB>(dst[3], b0);
   };
-  auto issue_w1 = [&](auto ac, const char* wq) __attribute__((always_inline)) {   // both k-halves of channel tile a of the step at wq
-    constexpr int a = decltype(ac)::value;   // (the instruction offset is 13 bits signed: channel tiles 2, 3 through a second base)
-    const char* q = a < 2 ? wq : wq + 4096;
-    glb_read128<(a & 1) * 2048>(Wf[0][a], q);
-    glb_read128<(a & 1) * 2048 + 1024>(Wf[1][a], q);
+  auto issue_w = [&](auto khc, const char* wq) __attribute__((always_inline)) {   // the four channel tiles of k-half kh of the step at wq
+    constexpr int kh = decltype(khc)::value;
+    glb_read128<kh * 1024>(Wf[kh][0], wq);          // (the instruction offset is 13 bits signed: channel tiles 2, 3 through a second base)
+    glb_read128<2048 + kh * 1024>(Wf[kh][1], wq);
+    glb_read128<kh * 1024>(Wf[kh][2], wq + 4096);
+    glb_read128<2048 + kh * 1024>(Wf[kh][3], wq + 4096);
   };
-  auto mfma4 = [&](auto ac, auto pc, f16x8 (&x)[2][2]) __attribute__((always_inline)) {
-    constexpr int a = decltype(ac)::value, pr = decltype(pc)::value;
-    acc[a][2 * pr] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Wf[0][a], x[0][0], acc[a][2 * pr], 0, 0, 0);
-    acc[a][2 * pr] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Wf[1][a], x[0][1], acc[a][2 * pr], 0, 0, 0);
-    acc[a][2 * pr + 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Wf[0][a], x[1][0], acc[a][2 * pr + 1], 0, 0, 0);
-    acc[a][2 * pr + 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Wf[1][a], x[1][1], acc[a][2 * pr + 1], 0, 0, 0);
+  auto mfma16 = [&](auto khc, auto gc, f16x8 (&x)[4]) __attribute__((always_inline)) {
+    constexpr int kh = decltype(khc)::value, gr = decltype(gc)::value;
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[a][4 * gr + r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Wf[kh][a], x[r], acc[a][4 * gr + r], 0, 0, 0);
   };
   auto wait_producers = [&](unsigned need) __attribute__((always_inline)) {
     while (flags_min_now(pflags) < need) { DACC(1, 1); }
@@ -447,8 +453,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3d_kernel(const ConvParams p, co
   wait_producers(1u);
   DSTAMP(c_t1);
   DACC(0, c_t1 - c_t0);
-  issue_x(ic_t<0>{}, ic_t<0>{}, ic_t<0>{}, 0u, X[0]);
-  static_for<0, 4>([&](auto ac) { issue_w1(ac, wq); });
+  issue_x(ic_t<0>{}, ic_t<0>{}, ic_t<0>{}, ic_t<0>{}, 0u, X[0]);
+  issue_w(ic_t<0>{}, wq);
 
   int k = 0;   // global slab of this workgroup
   for (int u = u0; u < u1; ++u) {
@@ -462,46 +468,39 @@ __global__ __launch_bounds__(512, 2) void conv3x3d_kernel(const ConvParams p, co
         constexpr int nky = ((T + 1) % 9) / 3, nkx = (T + 1) % 3;
         // weights of the next step: the next tap of this slab (a tap = nslab slab blocks), or tap 0 of the next slab
         const char* wn = T == 8 ? wq - (8 * nslab - 1) * w_step_bytes : wq + nslab * w_step_bytes;
-        // entry: X pair 0 (4 LDS reads) and the step's 8 weight fragments (global loads) are in flight
-        lds_wait4<0>(X[0][0][0], X[0][0][1], X[0][1][0], X[0][1][1]);
-        vm_wait2<6>(Wf[0][0], Wf[1][0]);
-        mfma4(ic_t<0>{}, ic_t<0>{}, X[0]);
-        issue_x(ic_t<1>{}, ic_t<ky>{}, ic_t<kx>{}, hb, X[1]);
+        // entry: in flight are group 0 of k-half 0 (4 LDS reads -> X[0]) and the weights of k-half 0 (4 global loads -> Wf[0])
+        // ---- k-half 0 ----
+        issue_w(ic_t<1>{}, wq);
+        issue_x(ic_t<1>{}, ic_t<ky>{}, ic_t<kx>{}, ic_t<0>{}, hb, X[1]);
+        lds_wait4<4>(X[0][0], X[0][1], X[0][2], X[0][3]);
+        vm_wait4<4>(Wf[0][0], Wf[0][1], Wf[0][2], Wf[0][3]);
+        mfma16(ic_t<0>{}, ic_t<0>{}, X[0]);
         __builtin_amdgcn_sched_barrier(0);
-        vm_wait2<4>(Wf[0][1], Wf[1][1]);
-        mfma4(ic_t<1>{}, ic_t<0>{}, X[0]);
+        issue_x(ic_t<0>{}, ic_t<ky>{}, ic_t<kx>{}, ic_t<1>{}, hb, X[0]);
+        lds_wait4<4>(X[1][0], X[1][1], X[1][2], X[1][3]);
+        mfma16(ic_t<0>{}, ic_t<1>{}, X[1]);
         __builtin_amdgcn_sched_barrier(0);
-        vm_wait2<2>(Wf[0][2], Wf[1][2]);
-        mfma4(ic_t<2>{}, ic_t<0>{}, X[0]);
+        // ---- k-half 1 ----
+        issue_w(ic_t<0>{}, wn);
+        issue_x(ic_t<1>{}, ic_t<ky>{}, ic_t<kx>{}, ic_t<1>{}, hb, X[1]);
+        lds_wait4<4>(X[0][0], X[0][1], X[0][2], X[0][3]);
+        vm_wait4<4>(Wf[1][0], Wf[1][1], Wf[1][2], Wf[1][3]);
+        mfma16(ic_t<1>{}, ic_t<0>{}, X[0]);
         __builtin_amdgcn_sched_barrier(0);
-        vm_wait2<0>(Wf[0][3], Wf[1][3]);
-        mfma4(ic_t<3>{}, ic_t<0>{}, X[0]);
-        __builtin_amdgcn_sched_barrier(0);
-        // pair 1
-        issue_x(ic_t<2>{}, ic_t<ky>{}, ic_t<kx>{}, hb, X[0]);
-        lds_wait4<4>(X[1][0][0], X[1][0][1], X[1][1][0], X[1][1][1]);
-        static_for<0, 4>([&](auto ac) { mfma4(ac, ic_t<1>{}, X[1]); __builtin_amdgcn_sched_barrier(0); });
-        // pair 2
-        issue_x(ic_t<3>{}, ic_t<ky>{}, ic_t<kx>{}, hb, X[1]);
-        lds_wait4<4>(X[0][0][0], X[0][0][1], X[0][1][0], X[0][1][1]);
-        static_for<0, 4>([&](auto ac) { mfma4(ac, ic_t<2>{}, X[0]); __builtin_amdgcn_sched_barrier(0); });
-        // pair 3: the next step's first row pair and weights go out between its MFMA groups
-        lds_wait4<0>(X[1][0][0], X[1][0][1], X[1][1][0], X[1][1][1]);
         if constexpr (T == 8) {
-          // every pixel of slab k is in registers: its image is free.  The next slab (if it is this unit's) must be complete before its first
-          // rows are read; at a unit's last step the same reads go out unchecked and unused (one code path, no join for the register
-          // allocator), and the next unit's first operands are issued again behind the epilogue, whose registers these are.
+          // every pixel of slab k is in registers once the last group has landed: its image is free.  The next slab (if it is this unit's)
+          // must be complete before its first rows are read; at a unit's last step the same reads go out unchecked and unused (one code
+          // path, no join for the register allocator), and the next unit's first operands are issued again behind the epilogue.
+          lds_wait4<0>(X[1][0], X[1][1], X[1][2], X[1][3]);
           lds_write32(cflag_addr, (unsigned)k + 1u);
           if (!last_slab) { DACC(2, 1); wait_producers((unsigned)k + 2u); }
-          issue_x(ic_t<0>{}, ic_t<0>{}, ic_t<0>{}, hbn, X[0]);
+          issue_x(ic_t<0>{}, ic_t<0>{}, ic_t<0>{}, ic_t<0>{}, hbn, X[0]);
         } else {
-          issue_x(ic_t<0>{}, ic_t<nky>{}, ic_t<nkx>{}, hb, X[0]);
+          issue_x(ic_t<0>{}, ic_t<nky>{}, ic_t<nkx>{}, ic_t<0>{}, hb, X[0]);
+          lds_wait4<4>(X[1][0], X[1][1], X[1][2], X[1][3]);
         }
-        static_for<0, 4>([&](auto ac) {
-          mfma4(ac, ic_t<3>{}, X[1]);
-          issue_w1(ac, wn);
-          __builtin_amdgcn_sched_barrier(0);
-        });
+        mfma16(ic_t<1>{}, ic_t<1>{}, X[1]);
+        __builtin_amdgcn_sched_barrier(0);
         wq = wn;
       });
     }
@@ -518,8 +517,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3d_kernel(const ConvParams p, co
       DSTAMP(e2);
       DACC(5, e2 - e1);
       wq = wfrag + (long long)(nxt.n0 >> 7) * 16384;
-      issue_x(ic_t<0>{}, ic_t<0>{}, ic_t<0>{}, (unsigned)(k % D_NBUF) * D_HB, X[0]);
-      static_for<0, 4>([&](auto ac) { issue_w1(ac, wq); });
+      issue_x(ic_t<0>{}, ic_t<0>{}, ic_t<0>{}, ic_t<0>{}, (unsigned)(k % D_NBUF) * D_HB, X[0]);
+      issue_w(ic_t<0>{}, wq);
       cur = nxt;
     }
   }

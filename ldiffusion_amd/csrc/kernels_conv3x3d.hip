@@ -151,6 +151,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3d_kernel(const ConvParams p, co
     const __amdgpu_buffer_rsrc_t shrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.gn_shift, 0, (int)((long long)p.B * Cin * 4), 0x00020000);
     const __amdgpu_buffer_rsrc_t brsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(p.bias ? p.bias : p.gn_scale), 0, p.bias ? p.Nrows * 4 : 0, 0x00020000);
     const __amdgpu_buffer_rsrc_t trsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(p.temb ? p.temb : p.gn_scale), 0, p.temb ? (int)((long long)p.B * p.ld_temb * 4) : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(p.res ? p.res : (const f16*)p.gn_scale), 0, p.res ? (int)((long long)p.M * p.ld_res * 2) : 0, 0x00020000);
     const unsigned cflags = lds0 + D_FLAGS + 16u;
     // progress word by ONE unmasked ds_write_b32: lane 0 hits the word, the other lanes a dump row of their own
     const unsigned pflag_addr = lane == 0 ? lds0 + D_FLAGS + (unsigned)pw * 4u : lds0 + D_DUMP + (unsigned)(4 + pw) * 256u + (unsigned)lane * 4u;
@@ -212,6 +213,18 @@ __global__ __launch_bounds__(512, 2) void conv3x3d_kernel(const ConvParams p, co
           __builtin_amdgcn_raw_ptr_buffer_load_lds(brsrc, (lptr_t*)dst, 16, (sc.un.n0 + lane * 4) * 4, 0, 0, 0);            // no bias: zero records, the DMA writes zeros
           __builtin_amdgcn_raw_ptr_buffer_load_lds(trsrc, (lptr_t*)(dst + 512), 16, (sc.un.b * p.ld_temb + sc.un.n0 + lane * 4) * 4, 0, 0, 0);
         }
+#endif
+        n += 2;
+      }
+      if (p.res && sc.c == nslab - 1) {   // the unit's last slab: touch the lines of its residual tile (256 pixels x 256 B = 512 lines; 128 per producer
+        // wave, one dword per lane and instruction into a dump row) so that the consumers' epilogue loads are L2 hits
+        const int px = pw * 64 + lane;                                   // this lane's pixel of the 16 x 16 tile
+        const unsigned rpix = (unsigned)((sc.un.b * H + sc.un.oy0 + (px >> 4)) * W + sc.un.ox0 + (px & 15));
+        const int voff = (int)((rpix * (unsigned)p.ld_res + (unsigned)sc.un.n0) * 2u);
+        unsigned char* dst = smem_raw + D_DUMP + (unsigned)(4 + pw) * 256u;
+#if defined(__HIP_DEVICE_COMPILE__)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrsrc, (lptr_t*)dst, 4, voff, 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrsrc, (lptr_t*)dst, 4, voff, 128, 0, 0);
 #endif
         n += 2;
       }
@@ -285,9 +298,11 @@ __global__ __launch_bounds__(512, 2) void conv3x3d_kernel(const ConvParams p, co
       }
       DSTAMP(q1);
       // slab k's pieces are older than everything just issued: leave exactly those in flight
-      if (n_next == 15) asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
-      else if (n_next == 13) asm volatile("s_waitcnt vmcnt(13)" ::: "memory");
-      else if (n_next == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+      if (n_next >= 17) asm volatile("s_waitcnt vmcnt(17)" ::: "memory");
+      else if (n_next >= 15) asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
+      else if (n_next >= 14) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
+      else if (n_next >= 13) asm volatile("s_waitcnt vmcnt(13)" ::: "memory");
+      else if (n_next >= 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       DSTAMP(q2);
       xform_slab(cur);
@@ -368,26 +383,27 @@ __global__ __launch_bounds__(512, 2) void conv3x3d_kernel(const ConvParams p, co
     const unsigned yoff = (pix * (unsigned)p.ldy + chb) * 2u, ystep = (unsigned)(2 * W * p.ldy) * 2u;
     const unsigned roff = (pix * (unsigned)p.ld_res + chb) * 2u, rstep = (unsigned)(2 * W * p.ld_res) * 2u;
     constexpr bool RES = (FLAGS & D_RES) != 0, ST = (FLAGS & D_STATS) != 0;
-    u32x4 R[2][4];
+    // the residual tile: all sixteen 16-byte loads go out at once (the operand registers of the tap loop are free here): ONE memory round
+    // trip in front of the first row pair instead of one per pair; the producers have touched its lines during the unit's last slab (L2)
+    u32x4 R[4][4];
     if constexpr (RES) {
 #pragma unroll
-      for (int a = 0; a < 4; ++a) R[0][a] = __builtin_amdgcn_raw_buffer_load_b128(rrsrc, (int)(roff + a * 32), 0, 0);
+      for (int pr = 0; pr < 4; ++pr)
+#pragma unroll
+        for (int a = 0; a < 4; ++a) R[pr][a] = __builtin_amdgcn_raw_buffer_load_b128(rrsrc, (int)(roff + pr * rstep + a * 32), 0, 0);
     }
-    // fused GroupNorm statistics: per (channel tile, row pair) the 4 sums and 4 sums of squares of the lane's channels are reduced over the
-    // 16 pixel lanes at once (row16_reduce_spread<8>: lane keeps ONE of the eight totals, value index jv) and added up over the row pairs:
-    // four live registers instead of thirty-two (the epilogue shares the register file with 128 accumulators)
+    // fused GroupNorm statistics: per channel tile the 4 sums and 4 sums of squares of the lane's channels over its 8 rows are reduced over
+    // the 16 pixel lanes at once (row16_reduce_spread<8>: lane keeps ONE of the eight totals, value index jv): eight live registers
+    // instead of thirty-two (the epilogue shares the register file with 128 accumulators)
     float tot[4] = {0.f, 0.f, 0.f, 0.f};
-    static_for<0, 4>([&](auto pc) {
-      constexpr int pr = decltype(pc)::value;
-      if constexpr (RES && pr < 3) {
+    static_for<0, 4>([&](auto ac) {   // channel tile outermost: the statistics of a tile are reduced over the pixel lanes once, not once per row pair
+      constexpr int a = decltype(ac)::value;
+      float x8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int a = 0; a < 4; ++a) R[(pr + 1) & 1][a] = __builtin_amdgcn_raw_buffer_load_b128(rrsrc, (int)(roff + (pr + 1) * rstep + a * 32), 0, 0);
-      }
-#pragma unroll
-      for (int a = 0; a < 4; ++a) {
+      for (int pr = 0; pr < 4; ++pr) {
         f32x4 v0 = acc[a][2 * pr], v1 = acc[a][2 * pr + 1];
         if constexpr (RES) {
-          const u32x4 r = R[pr & 1][a];
+          const u32x4 r = R[pr][a];
           auto s0 = __builtin_amdgcn_permlane16_swap(r[0], r[2], false, false);
           auto s1 = __builtin_amdgcn_permlane16_swap(r[1], r[3], false, false);
           v0 += up4(__builtin_bit_cast(f16x4, make_uint2(s0[0], s1[0])));
@@ -401,12 +417,11 @@ __global__ __launch_bounds__(512, 2) void conv3x3d_kernel(const ConvParams p, co
         asm volatile("s_nop 1" ::: "memory");   // the next VALU instruction may overwrite the store's data registers (profiles/r02_conv3x3_pingpong.md)
         if constexpr (ST) {   // statistics of what the consumer of this tensor will read: the fp16-rounded values
           const f32x4 f0 = up4(o0), f1 = up4(o1);
-          float x8[8];
 #pragma unroll
-          for (int r = 0; r < 4; ++r) { x8[r] = f0[r] + f1[r]; x8[4 + r] = f0[r] * f0[r] + f1[r] * f1[r]; }
-          tot[a] += row16_reduce_spread<8>(x8, l15);
+          for (int r = 0; r < 4; ++r) { x8[r] += f0[r] + f1[r]; x8[4 + r] += f0[r] * f0[r] + f1[r] * f1[r]; }
         }
       }
+      if constexpr (ST) tot[a] = row16_reduce_spread<8>(x8, l15);
     });
     if constexpr (ST) {   // one row block per consumer wave (8 x 16 pixels); lanes l15 and l15 ^ 1 hold the same total: the even one stores it
       const int jv = ((l15 >> 3) & 1) | ((l15 >> 1) & 2) | ((l15 << 1) & 4);   // bits 0-1: channel of the lane's four, bit 2: sum / sum of squares
@@ -423,14 +438,16 @@ __global__ __launch_bounds__(512, 2) void conv3x3d_kernel(const ConvParams p, co
   // a unit's sums start at bias + time embedding: from the table producer wave 0 wrote with the unit's first slab
   auto init_from_table = [&](int parity) __attribute__((always_inline)) {
     const unsigned taddr = lds0 + D_BT + (unsigned)parity * 1024u + (unsigned)(wave_n * 64 + g * 4) * 4u;
-    static_for<0, 4>([&](auto ac) {
-      constexpr int a = decltype(ac)::value;
-      f32x4 bb, tt;
-      asm volatile("ds_read_b128 %0, %2 offset:%3\n\tds_read_b128 %1, %2 offset:%4\n\ts_waitcnt lgkmcnt(0)" : "=&v"(bb), "=&v"(tt) : "v"(taddr), "n"(a * 64), "n"(512 + a * 64) : "memory");
-      const f32x4 b = bb + tt;
+    f32x4 bb[4], tt[4];
+    asm volatile("ds_read_b128 %0, %8\n\tds_read_b128 %1, %8 offset:64\n\tds_read_b128 %2, %8 offset:128\n\tds_read_b128 %3, %8 offset:192\n\t"
+                 "ds_read_b128 %4, %8 offset:512\n\tds_read_b128 %5, %8 offset:576\n\tds_read_b128 %6, %8 offset:640\n\tds_read_b128 %7, %8 offset:704\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(bb[0]), "=&v"(bb[1]), "=&v"(bb[2]), "=&v"(bb[3]), "=&v"(tt[0]), "=&v"(tt[1]), "=&v"(tt[2]), "=&v"(tt[3]) : "v"(taddr) : "memory");
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      const f32x4 b = bb[a] + tt[a];
 #pragma unroll
       for (int m = 0; m < 8; ++m) acc[a][m] = b;
-    });
+    }
   };
 
   DSTAMP(c_t0);

@@ -582,7 +582,13 @@ void launch_c3d(const ConvParams& p, hipStream_t s) {
   auto kern = conv3x3d_kernel<FLAGS>;
   ensure_dyn_smem(reinterpret_cast<const void*>(kern), (int)D_LDS);
   const int units = p.B * (p.Hout >> 4) * (p.Wout >> 4) * (p.N >> 7);
-  const int grid = units < d_num_cus() ? units : d_num_cus();
+  // Run length (units per workgroup): LDIFF_C3D_RUN, default 2; 0 = one workgroup per CU walking its whole share.  The kernel alone is
+  // fastest fully persistent (0.43 of the MFMA peak against 0.42), but the sampler decodes on a side stream beside the next UNet pass, and a
+  // workgroup that holds a CU for half a millisecond keeps that pass's kernels out: measured on the whole step (8 patches, 5 passes)
+  // 175.7 ms fully persistent, 175.1 / 174.7 / 171.6 ms at 8 / 4 / 2 units per workgroup, 178.2 ms with the 8x16 kernel.
+  static const int run_cap = [] { const char* e = getenv("LDIFF_C3D_RUN"); return e ? atoi(e) : 2; }();
+  int grid = units < d_num_cus() ? units : d_num_cus();
+  if (run_cap > 0 && units > grid * run_cap) grid = (units + run_cap - 1) / run_cap;
   const double bytes = (double)p.B * p.Hin * p.Win * p.C1 * 2.0 + (double)p.N * p.K * 2.0 + (double)p.M * p.N * 2.0 + (p.res ? (double)p.M * p.N * 2.0 : 0.0);
   ProfScope prof("conv3x3<16x16d,128,gn>", 2.0 * p.M * (double)p.N * p.K, bytes, s);
   hipLaunchKernelGGL(kern, dim3(grid), dim3(512), D_LDS, s, p, units);

@@ -273,10 +273,10 @@ def adamw_step(params, grads, state, lr, betas=(0.9, 0.999), eps=1e-8, weight_de
     moment buffers per parameter and the device tables of the launch (parameter / moment pointers and the chunk list are built once;
     only the gradient pointers change from step to step)."""
     lib = _lib.load()
-    state["step"] = state.get("step", 0) + 1
     live = [(i, p, g) for i, (p, g) in enumerate(zip(params, grads)) if g is not None]
     if not live:
-        return
+        return   # nothing to update: the bias-correction step count must not advance either
+    state["step"] = state.get("step", 0) + 1
     dev = live[0][1].device
     for i, p, g in live:
         if not (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous()):

@@ -128,6 +128,10 @@ __global__ __launch_bounds__(256, 2) void gemm_dma_kernel(const ConvParams p) {
   // fp32 partials; splitk_reduce_kernel sums them and applies the epilogue
   const int nk_all = p.K / 64, S = p.splitk > 1 ? p.splitk : 1, ksplit = blockIdx.y;
   const int kt0 = S > 1 ? ksplit * nk_all / S : 0, nk = S > 1 ? (ksplit + 1) * nk_all / S : nk_all;
+  if (kt0 > kt2) {   // a split that starts INSIDE the second concat source never passes the step at which the voffsets change pitch
+#pragma unroll
+    for (int i = 0; i < A_NP; ++i) a_voff[i] = a_row[i] * (pitch2 * 2) + a_sw[i];
+  }
   issue(kt0, std::integral_constant<int, 0>{});
   __syncthreads();
   auto step = [&](int kt, auto bufc) {

@@ -88,7 +88,7 @@ class LDiffusionModel:
         save_path = os.path.join(root, "LDiffusion", "train_save", "unet", current_date)
         checkpoint = 100
         n_sched = min(int(num_inference_steps / 5), len(self.pipeline.scheduler.alphas_cumprod))
-        state, step_count = {}, 0
+        state, noise_offset = {}, 0   # Philox counters consumed so far: every step draws fresh Laplace noise (the reference samples anew each time)
         for epoch in range(num_epochs):
             if hasattr(train_loader, "sampler") and hasattr(train_loader.sampler, "set_epoch"):
                 train_loader.sampler.set_epoch(epoch)
@@ -112,8 +112,8 @@ class LDiffusionModel:
                     return loss_obj.compute_content_loss(image, big) + contrastive
 
                 total += T.train_step(unet, dec, proj, latents, text_hidden, ts, self.pipeline.scheduler.alphas_cumprod, None, None, state, lr=1e-5,
-                                      weight_decay=0.01, loss_fn=loss_fn, max_grad_norm=1.0, seed=self.rank, offset=step_count * 65536)
-                step_count += 1
+                                      weight_decay=0.01, loss_fn=loss_fn, max_grad_norm=1.0, seed=self.rank, offset=noise_offset)
+                noise_offset += len(ts) * latents.numel()   # v5_features draws offset + i * numel for pass i
             current = self._reduce_mean(total / max(1, len(train_loader)))
             if self._is_main_process():
                 print(f"Epoch [{epoch + 1}/{num_epochs}], Loss: {current:.4f}, Elapsed Time: {time.time() - start}s")

@@ -245,8 +245,10 @@ class AutoencoderKL:
         weights.save_model_dir(path, self._cfg, self._host_sd)
 
     def set_precision(self, encoder: int = 2, decoder: int = 0):
-        """Storage policy of the encoder / decoder graphs (include/ldiff.h ldiff_vae_set_precision)."""
+        """Storage policy of the encoder / decoder graphs (include/ldiff.h ldiff_vae_set_precision).  The current pair is kept in
+        `precision` so that a caller that changes it for one call can put back what was there."""
         _lib.check(self._lib.ldiff_vae_set_precision(self._h, int(encoder), int(decoder)))
+        self.precision = (int(encoder), int(decoder))
         return self
 
     def eval(self):

@@ -188,11 +188,12 @@ def laplace_features(pipeline: StableDiffusionImg2ImgPipeline, images: torch.Ten
     Here the decoder's FLOAT output is the feature (no uint8 quantisation behind it as in the sampler), so the decodes run with the
     split residual stream (`decoder_precision`, ldiff_vae_set_precision) instead of the sampler's all-fp16 decoder default."""
     vae, unet, sch = pipeline.vae, pipeline.unet, pipeline.scheduler
-    vae.set_precision(2, decoder_precision)
+    saved = getattr(vae, "precision", (2, 0))   # the caller's setting (the library's defaults if it was never changed)
+    vae.set_precision(saved[0], decoder_precision)
     try:
         return _laplace_features(pipeline, images, text_embeddings, num_inference_steps, u_list, seed, out_hw)
     finally:
-        vae.set_precision(2, 0)
+        vae.set_precision(*saved)
 
 
 def _laplace_features(pipeline, images, text_embeddings, num_inference_steps, u_list, seed, out_hw):

@@ -117,10 +117,17 @@ def test_gather_masks_world_size_2_gloo(tmp_path):
     script = tmp_path / "worker.py"
     script.write_text(_WORKER.format(root=ROOT, out=str(tmp_path)))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-           "--master-port", "29541", str(script)]
+           "--master-port", str(_free_port()), str(script)]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=240, env=dict(os.environ, OMP_NUM_THREADS="1"))
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert (tmp_path / "rank0.ok").exists() and (tmp_path / "rank1.ok").exists(), r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
 
 
 _GRAD_WORKER = r"""
@@ -135,20 +142,64 @@ for i, p in enumerate(ps[:2]):
 train.allreduce_gradients(ps)
 for i, p in enumerate(ps[:2]):
     assert torch.equal(p.grad, torch.full(p.shape, (1 + 2) / 2 + i)), (rank, i, p.grad)
-assert ps[2].grad is None
+assert torch.equal(ps[2].grad, torch.zeros(1))                 # shape-stable bucket: zeros, averaged, written back
+# one rank without ANY gradient (a batch that yields no sample triples): the collective must still match up, not hang
+qs = [torch.nn.Parameter(torch.zeros(s)) for s in ((4,), (2, 3))]
+if rank == 0:
+    for q in qs:
+        q.grad = torch.full(q.shape, 6.0)
+train.allreduce_gradients(qs)
+for q in qs:
+    assert torch.equal(q.grad, torch.full(q.shape, 3.0)), (rank, q.grad)
+
+# ZeRO-style path: reduce-scatter + AdamW on this rank's slice (moments sharded) + all-gather, against the replicated all-reduce path,
+# bit for bit in float32 over three steps (same elementwise update injected into both; the HIP kernel is the product's)
+def adamw(p, g, m, v, step, lr, betas, eps, wd):
+    b1, b2 = betas
+    p.mul_(1 - lr * wd)
+    m.mul_(b1).add_(g, alpha=1 - b1)
+    v.mul_(b2).addcmul_(g, g, value=1 - b2)
+    p.addcdiv_(m / (1 - b1 ** step), (v / (1 - b2 ** step)).sqrt_().add_(eps), value=-lr)
+gen = torch.Generator().manual_seed(5)
+shapes = ((7,), (3, 5), (2, 2, 3), (1,))
+init = [torch.randn(s, generator=gen) for s in shapes]
+pa = [torch.nn.Parameter(t.clone()) for t in init]
+pb = [torch.nn.Parameter(t.clone()) for t in init]
+opt = train.ShardedAdamW(pb, lr=1e-2, update=adamw)
+assert opt.m.numel() == (sum(t.numel() for t in init) + 1) // 2          # the moments cover half of the parameters per rank
+ma, va = [torch.zeros_like(t) for t in init], [torch.zeros_like(t) for t in init]
+for step in range(1, 4):
+    gr = torch.Generator().manual_seed(100 * step + rank)                 # every rank its own gradients
+    for i, (a, b) in enumerate(zip(pa, pb)):
+        g = torch.randn(a.shape, generator=gr)
+        if i == 3 and rank == 1:
+            a.grad = b.grad = None                                         # ... and one of them missing on one rank
+        else:
+            a.grad, b.grad = g.clone(), g.clone()
+    train.allreduce_gradients(pa)
+    for a, m, v in zip(pa, ma, va):
+        adamw(a.data, a.grad, m, v, step, 1e-2, (0.9, 0.999), 1e-8, 0.01)
+    opt.step()
+    for a, b in zip(pa, pb):
+        assert torch.equal(a.data, b.data), (rank, step, (a.data - b.data).abs().max())
+# with clipping the two paths differ only by the rounding of the norm
+for a, b in zip(pa, pb):
+    a.grad, b.grad = torch.ones_like(a) * (rank + 1), torch.ones_like(b) * (rank + 1)
+n = opt.step(max_grad_norm=1.0)
+assert abs(n - 1.5 * sum(t.numel() for t in init) ** 0.5) < 1e-4, n
 dist.barrier()
 dist.destroy_process_group()
 open(os.path.join({out!r}, "grad%d.ok" % rank), "w").write("ok")
 """
 
 
-def test_gradient_allreduce_world_size_2_gloo(tmp_path):
-    """The training step's one collective (ldiffusion_amd.train.allreduce_gradients: one flattened all-reduce of the float32 gradients,
-    RCCL on the GPUs) on gloo with two ranks."""
+def test_gradient_exchange_world_size_2_gloo(tmp_path):
+    """The training step's collectives on gloo with two ranks: the flattened all-reduce of replicated parameters (shape-stable when a rank
+    has no gradient at all), and the reduce-scatter + sharded AdamW + all-gather path, which must reproduce the all-reduce path bit for bit."""
     script = tmp_path / "gworker.py"
     script.write_text(_GRAD_WORKER.format(root=ROOT, out=str(tmp_path)))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-           "--master-port", "29547", str(script)]
+           "--master-port", str(_free_port()), str(script)]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=240, env=dict(os.environ, OMP_NUM_THREADS="1"))
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert (tmp_path / "grad0.ok").exists() and (tmp_path / "grad1.ok").exists()

@@ -143,6 +143,10 @@ CONV_CASES = {
     "1x1_splitk_concat_2560": (8, 1280, 1280, 8, 8, 256, 1, 1, 0, False, False, True),
     "1x1_splitk_4096_tailM": (1, 4096, 0, 1, 300, 192, 1, 1, 0, False, False, True),
     "1x1_splitk_128x128_tiles": (1, 2560, 0, 1, 1000, 640, 1, 1, 0, False, False, True),   # 8 x 5 tiles of 128 x 128, 40 K-steps -> S = 2
+    # two concat sources of UNEQUAL width, so that a K split starts strictly inside the second source (its row pitch differs from the first's)
+    "1x1_splitk_concat_1024_2048": (8, 1024, 2048, 8, 8, 256, 1, 1, 0, False, False, True),
+    "1x1_splitk_concat_1280_960": (8, 1280, 960, 8, 8, 256, 1, 1, 0, False, False, True),
+    "1x1_splitk_concat_1536_768": (8, 1536, 768, 8, 8, 192, 1, 1, 0, False, False, False),
     # wide-tile kernel (8x16 pixel tiles) on maps that are not multiples of the tile, with and without the 16-byte store path
     "3x3_wide_ragged_20x27_gn": (2, 64, 0, 20, 27, 96, 3, 1, 0, False, True, True),
     "3x3_wide_ragged_upsample_9x11": (2, 128, 0, 9, 11, 64, 3, 1, 1, False, False, True),

@@ -16,6 +16,7 @@ import os
 import numpy as np
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
 
 from .models import UNet2DConditionModel
 from .pipeline import PROMPT, LaplaceSampler, StableDiffusionImg2ImgPipeline, argmax_mask
@@ -119,6 +120,45 @@ class Segmentor:
         from PIL import Image  # other sizes: the reference's PIL bilinear Resize, on the host
         ims = [np.asarray(Image.fromarray(a).resize((1024, 1024), Image.BILINEAR), np.float32) / 255.0 for a in rgb.cpu().numpy()]
         return torch.from_numpy(np.stack(ims)).permute(0, 3, 1, 2).contiguous().to(self.device)
+
+    @torch.no_grad()
+    def ldiffusion_augment_for_multimodal(self, rgb, dtm, pipeline, unet, vae, controlnet, batch_size, device, u=None, seed=0):
+        """segmentor.py:301-386 (sampler variant V7: RGB + depth, ControlNet residuals), per sample as there:
+            rgb, dtm -> bilinear 256 x 256;  z = vae.encode(rgb).latent_dist.sample() * 0.18215          (:339)
+            depth = bilinear 32 x 32 of dtm, repeated over the 4 latent channels                          (:340-341)
+            z_noisy = z + Laplace(0, 1) * depth                                                           (:344-345)
+            ctx = proj(text_encoder("A remote sense image", padded to 77))                                (:348-352)
+            residuals = controlnet(z_noisy, t, ctx, controlnet_cond = depth x 3)  at set_timesteps(1)     (:355-363)
+            eps = unet(z_noisy, t, ctx, down_block_additional_residuals, mid_block_additional_residual)   (:366-372)
+            recon = vae.decode((z_noisy - eps * depth) / 0.18215).sample                                  (:375-379)
+        Returns the list of [256, 256, 3] float arrays the reference returns (:381-386).  The ControlNet is the caller's module (the reference
+        trains none and ships no weights for one: SURVEY 8f); the UNet, the VAE and the Laplace transform run on the HIP kernels.
+        `u` (optional, [B, 4, 32, 32] uniform draws in (-1, 1)) fixes the Laplace noise (parity is defined given u)."""
+        from .pipeline import laplace_noise
+        dev = self.device
+        proj = self._ensure_ldiffusion_proj(pipeline, unet)
+        rgb = F.interpolate(rgb.to(dev, torch.float32), size=(256, 256), mode="bilinear", align_corners=False)
+        dtm = F.interpolate(dtm.to(dev, torch.float32), size=(256, 256), mode="bilinear", align_corners=False)
+        ids = pipeline.tokenizer(["A remote sense image"], padding="max_length", max_length=77, return_tensors="pt")
+        ids = torch.as_tensor(ids["input_ids"] if isinstance(ids, dict) else ids.input_ids, dtype=torch.long, device=dev)
+        ctx = proj(pipeline.text_encoder(ids)["last_hidden_state"].to(device=dev, dtype=torch.float32)).to(dtype=torch.float32)
+        recon = []
+        for i in range(dtm.shape[0]):
+            dtm_i, rgb_i = dtm[i], rgb[i].unsqueeze(0)
+            depth_condition = dtm_i.unsqueeze(0).repeat(1, 3, 1, 1)
+            latents = vae.encode(rgb_i).latent_dist.sample().to(torch.float32) * 0.18215
+            depth = F.interpolate(dtm_i.unsqueeze(0), size=(32, 32), mode="bilinear", align_corners=False).repeat(1, latents.shape[1], 1, 1)
+            # z + Laplace(0, 1) * depth: the device transform with unit scale gives z + n, so noise = that minus z
+            noise = laplace_noise(torch.zeros_like(latents), 1.0, u=None if u is None else u[i:i + 1].to(dev), seed=seed, offset=i * latents.numel())
+            noisy = latents + noise * depth
+            pipeline.scheduler.set_timesteps(1, device=dev)
+            for t in pipeline.scheduler.timesteps:
+                down, mid = controlnet(sample=noisy, timestep=t, encoder_hidden_states=ctx, controlnet_cond=depth_condition, return_dict=False)
+                eps = unet(noisy, t, encoder_hidden_states=ctx, down_block_additional_residuals=down, mid_block_additional_residual=mid).sample
+            den = noisy - eps * depth
+            img = vae.decode(den / 0.18215).sample
+            recon.append(img.squeeze(0).permute(1, 2, 0).cpu().numpy())
+        return recon
 
     @torch.no_grad()
     def inference_cell_model(self, image_path, diffusion_path, ldiffusion_weight, segmentor_weight, head=None, text_embeddings=None):

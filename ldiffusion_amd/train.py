@@ -351,8 +351,12 @@ def clip_grad_norm(params, max_norm):
     return total
 
 
+LOSS_SCALE = 1024.0   # static loss scale of the backward pass: activation gradients are stored in float16 (the reference trains in fp32,
+                      # ldiffusion.py:172 `fp16.enabled: False`); unscaled, 0.5 % of the non-negligible parameter-gradient entries underflow to zero
+
+
 def train_step(unet, vae_dec, proj, z0, text_hidden, timesteps, abar, u_list, pairs, opt_state, lr=1e-5, weight_decay=0.01, loss_fn=None,
-               max_grad_norm=None, seed=0, offset=0):
+               max_grad_norm=None, seed=0, offset=0, loss_scale=LOSS_SCALE):
     """One fine-tuning step (ldiffusion.py:209-255): text projection -> V5 features -> loss -> backward through the VAE decoder and the
     UNet -> gradient all-reduce -> (clipping) -> AdamW on the UNet and projection parameters.
     `proj` = (weight [D, 768], bias [D]) float32 CUDA parameters of the text projection.  `loss_fn(features, last_rgb)` defaults to the
@@ -363,7 +367,9 @@ def train_step(unet, vae_dec, proj, z0, text_hidden, timesteps, abar, u_list, pa
     ctx = F.linear(text_hidden, proj[0], proj[1])
     feats, rgb = v5_features(unet, vae_dec, z0, ctx, timesteps, abar, u_list, seed=seed, offset=offset)
     loss = contrastive_loss(feats, pairs) if loss_fn is None else loss_fn(feats, rgb)
-    loss.backward()
+    (loss * loss_scale).backward()
+    if loss_scale != 1.0:   # the parameter gradients are float32: unscale before the exchange, the clipping and AdamW
+        torch._foreach_mul_([p.grad for p in params if p.grad is not None], 1.0 / loss_scale)
     allreduce_gradients(params)
     if max_grad_norm is not None:
         clip_grad_norm(params, max_grad_norm)

@@ -108,6 +108,31 @@ def test_one_pass_sampler_restatement_equals_reference_loop():
     assert np.array_equal(torch.nn.functional.avg_pool2d(out, 64).numpy(), z["pooled"])
 
 
+def test_v4_restatement_equals_reference_copy_or_convert_image():
+    """utils.copy_or_convert_image (reference code, utils.py:176-208; sampler variant V4) was run on the oracle's objects to make the
+    fixture (scripts/gen_golden_v4.py), with the text-alignment wrapper of its call site around the UNet.  Pinned: the wrapper is handed
+    embeddings of width 1280 (the function's own nn.Linear(768, 1280)), falls back to its cached embeddings (F12), ONE UNet pass at t = 1 on
+    a 128 x 128 latent of the image resized to 1024 x 1024 and ImageNet-normalised, and the PNG holds decode_latents -> numpy_to_pil of the
+    stepped latents.  The oracle's restatement of that loop must reproduce the PNG bit for bit."""
+    from PIL import Image
+    z = gold("reference_v4.npz")
+    assert z["calls_t"].tolist() == [1] and z["calls_fallback"].tolist() == [True] and z["calls_given_dim"].tolist() == [1280]
+    assert z["calls_sample_shape"].tolist() == [[1, 4, 128, 128]] and z["base_unet_calls"].tolist() == [1] and bool(z["plain_copy"])
+    ucfg, vcfg = configs.TINY_UNET, configs.TINY_VAE
+    usd = weights.synthetic_state_dict(weights.unet_param_shapes(ucfg), 42)
+    vsd = weights.synthetic_state_dict(weights.vae_param_shapes(vcfg), 43)
+    pipe = op.OraclePipeline(op.OracleUNet(usd, ucfg), op.OracleVAE(vsd, vcfg))
+    h, w = z["image_hw"].tolist()
+    img = Image.fromarray((torch.rand((h, w, 3), generator=torch.Generator().manual_seed(int(z["image_seed"]))) * 255).to(torch.uint8).numpy(), "RGB")
+    cached = torch.randn((1, 5, ucfg["cross_attention_dim"]), generator=torch.Generator().manual_seed(int(z["cached_seed"]))) * 0.5
+    x = torch.from_numpy(np.asarray(img.resize((1024, 1024), Image.BILINEAR), np.float32) / 255.0).permute(2, 0, 1)[None]
+    x = (x - torch.tensor([0.485, 0.456, 0.406]).view(1, 3, 1, 1)) / torch.tensor([0.229, 0.224, 0.225]).view(1, 3, 1, 1)
+    out = op.sample_one_pass(pipe, x, cached)["rgb_u8"][0]
+    assert list(out.shape) == z["out_shape"].tolist() and pipe.unet.calls == [1]
+    assert np.array_equal(out[480:544, 480:544], z["crop"])
+    assert np.array_equal(torch.nn.functional.avg_pool2d(torch.from_numpy(out.copy()).permute(2, 0, 1).float()[None], 64)[0].numpy(), z["pooled"])
+
+
 # ---------------------------------------------------------------- restated diffusers semantics (regression fixtures)
 def test_pndm_schedule_and_trajectory():
     z = gold("pndm.npz")

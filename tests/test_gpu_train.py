@@ -69,7 +69,10 @@ def _compare_step(sd15, tol_feat, tol_loss, tol_grad, min_cos):
     ctx = F.linear(hidden.to(DEV), pw, pb)
     feats, _ = train.v5_features(unet, dec, z0.to(DEV), ctx, ts, sch.alphas_cumprod, [u.to(DEV) for u in u_list])
     loss = train.contrastive_loss(feats, pairs)
-    loss.backward()
+    (loss * train.LOSS_SCALE).backward()                       # as train_step does: float16 activation gradients behind a static loss scale
+    for p_ in list(unet.p.values()) + [pw, pb]:
+        if p_.grad is not None:
+            p_.grad.mul_(1.0 / train.LOSS_SCALE)
     e_f = ((feats.detach().cpu() - rfeats).abs().max() / rfeats.abs().max()).item()
     e_l = abs(loss.item() - rloss.item()) / abs(rloss.item())
     worst, dots, n1, n2 = (0.0, ""), 0.0, 0.0, 0.0

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define LDIFF_VERSION 120 /* 0.1.2: + ldiff_op_adamw_multi, ldiff_op_pack_weight, ldiff_op_unpack_wgrad */
+#define LDIFF_VERSION 130 /* 0.1.3: + ldiff_op_infonce; dataflow conv3x3 kernel behind ldiff_op_conv */
 #define LDIFF_MAX_BLOCKS 8
 
 typedef enum { LDIFF_OK = 0, LDIFF_ERR_INVALID = -1, LDIFF_ERR_RUNTIME = -2, LDIFF_ERR_STATE = -3 } ldiff_status;
@@ -250,6 +250,12 @@ int ldiff_op_attention_bwd(const void* q, int ldq, const void* k, int ldk, const
 /* one AdamW update of n f32 parameters (torch.optim.AdamW semantics; step counts from 1) */
 int ldiff_op_adamw(void* p, const void* g, void* m, void* v, int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay, int step,
                    void* stream);
+/* Contrastive (InfoNCE) feature loss of the fine-tuning step for GIVEN sample triples, forward and gradient in one launch
+ * (/root/reference/model/loss.py:89-109; the random draws of :62-87 stay on the host, ldiffusion_amd/loss.py sample_triples):
+ *   features f32 [B, n, HW] (n <= 32 planes);  triple t = image bi[t], anchor pixel ai[t], positive pi[t], negatives ni[t*K .. t*K+K) (int32, device)
+ *   loss[0] = mean_t CE([a.p | a.n_k] / temperature, target 0);  dfeatures [B, n, HW] = d loss / d features.  Both are overwritten. */
+int ldiff_op_infonce(const void* features, int B, int n, int64_t HW, const void* bi, const void* ai, const void* pi, const void* ni, int T, int K,
+                     float temperature, void* loss, void* dfeatures, void* stream);
 /* Weight layouts of the training step (the float32 master [Cout, Cin, k, k] of torch / diffusers -> what ldiff_op_conv reads):
  *   mode 0, forward: dst[n][ky][kx][c] = w[n][c][ky][kx]           rows >= Cout, Cpad >= Cin, the rest zero
  *   mode 1, dgrad:   dst[c][ky][kx][n] = w[n][c][k-1-ky][k-1-kx]   rows >= Cin,  Cpad >= Cout, the rest zero

@@ -264,6 +264,30 @@ class AttentionFn(torch.autograd.Function):
         return dq, dk, dv, None
 
 
+class InfoNceFn(torch.autograd.Function):
+    """Contrastive feature loss for given sample triples (/root/reference/model/loss.py:89-109): forward value and d loss / d features from
+    ONE launch of ldiff_op_infonce; backward only scales the stored gradient.  features f32 [B, n, H, W]; bi/ai/pi int32 [T], ni int32 [T, K]."""
+
+    @staticmethod
+    def forward(ctx, features, bi, ai, pi, ni, temperature):
+        if not (features.is_cuda and features.dtype == torch.float32):
+            raise ValueError("InfoNceFn: features must be a float32 CUDA tensor")
+        f = features.contiguous()
+        B, n, H, W = f.shape
+        T, K = ni.shape
+        loss = torch.empty(1, dtype=torch.float32, device=f.device)
+        df = torch.empty_like(f)
+        _lib.check(_lib.load().ldiff_op_infonce(f.data_ptr(), B, n, H * W, bi.data_ptr(), ai.data_ptr(), pi.data_ptr(), ni.data_ptr(), T, K,
+                                                float(temperature), loss.data_ptr(), df.data_ptr(), _sp()))
+        ctx.save_for_backward(df)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        (df,) = ctx.saved_tensors
+        return g * df, None, None, None, None, None
+
+
 ADAMW_CHUNK = 16384   # elements per workgroup of ldiff_op_adamw_multi (csrc/common.h)
 
 

@@ -561,6 +561,14 @@ int ldiff_op_adamw(void* p, const void* g, void* m, void* v, int64_t n, float lr
   launch_adamw((float*)p, (const float*)g, (float*)m, (float*)v, n, lr, beta1, beta2, eps, weight_decay, step, (hipStream_t)stream);
   API_END
 }
+int ldiff_op_infonce(const void* features, int B, int n, int64_t HW, const void* bi, const void* ai, const void* pi, const void* ni, int T, int K,
+                     float temperature, void* loss, void* dfeatures, void* stream) {
+  API_BEGIN
+  LDIFF_CHECK(features && loss && dfeatures && B >= 1 && HW >= 1 && T >= 0 && (T == 0 || (bi && ai && pi && ni)), LDIFF_ERR_INVALID, "op_infonce: bad arguments");
+  launch_infonce((const float*)features, B, n, HW, (const int*)bi, (const int*)ai, (const int*)pi, (const int*)ni, T, K, temperature, (float*)loss,
+                 (float*)dfeatures, (hipStream_t)stream);
+  API_END
+}
 int ldiff_op_pack_weight(const void* w_f32, void* dst_f16, int Cout, int Cin, int k, int rows, int Cpad, int mode, void* stream) {
   API_BEGIN
   LDIFF_CHECK(w_f32 && dst_f16 && Cout >= 1 && Cin >= 1 && (k == 1 || k == 3) && (mode == 0 || mode == 1) && rows >= (mode ? Cin : Cout) &&

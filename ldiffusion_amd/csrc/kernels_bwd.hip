@@ -381,3 +381,77 @@ void launch_adamw(float* p, const float* g, float* m, float* v, long long n, flo
   hipLaunchKernelGGL(adamw_kernel, dim3(nblk(n)), dim3(256), 0, s, p, g, m, v, n, lr, b1, b2, eps, wd, bc1, bc2);
   HIP_CHECK(hipGetLastError());
 }
+
+
+// ---- contrastive (InfoNCE) feature loss of the fine-tuning step, forward AND gradient in one launch ----------------------------------
+// /root/reference/model/loss.py:89-109 for GIVEN sample triples (the draws stay on the host: they consume the torch random stream in the
+// reference's order, ldiffusion_amd/loss.py sample_triples):  feat[b, pixel, :] = features[b, :, pixel] (n planes, one per V5 pass);
+//   logits_t = [a.p | a.n_1 .. a.n_K] / temperature,   loss = mean_t (logsumexp(logits_t) - logits_t[0]).
+// One workgroup per triple: the K + 1 dot products (n <= 32 strided loads each; K = 1024 in the reference) into LDS, a block max / sum,
+// then dL/dlogits = (softmax - onehot) / (T temperature) scattered back into dfeatures with float atomics (pixels repeat across triples;
+// ~T (K + 2) n adds per step: thousands, nowhere near the atomic rate).  loss and dfeatures are zeroed by the launcher.
+__global__ __launch_bounds__(256) void infonce_kernel(const float* __restrict__ feat, int n, long long HW, const int* __restrict__ bi, const int* __restrict__ ai,
+                                                      const int* __restrict__ pi, const int* __restrict__ ni, int T, int K, float inv_temp,
+                                                      float* __restrict__ loss, float* __restrict__ dfeat) {
+  extern __shared__ float lg[];   // K + 1 logits, then 2 x 4 reduction slots, then the anchor (n)
+  const int t = blockIdx.x, tid = threadIdx.x;
+  const long long base = (long long)bi[t] * n * HW;
+  float* red = lg + K + 1;
+  float* av = red + 8;
+  const int a = ai[t];
+  for (int j = tid; j < n; j += 256) av[j] = feat[base + j * HW + a];
+  __syncthreads();
+  float mx = -3.0e38f;
+  for (int k = tid; k <= K; k += 256) {
+    const int px = k == 0 ? pi[t] : ni[(long long)t * K + k - 1];
+    float d = 0.f;
+    for (int j = 0; j < n; ++j) d += av[j] * feat[base + j * HW + px];
+    d *= inv_temp;
+    lg[k] = d;
+    mx = fmaxf(mx, d);
+  }
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+  if ((tid & 63) == 0) red[tid >> 6] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  float se = 0.f;
+  for (int k = tid; k <= K; k += 256) se += expf(lg[k] - mx);
+  for (int o = 32; o > 0; o >>= 1) se += __shfl_xor(se, o);
+  if ((tid & 63) == 0) red[4 + (tid >> 6)] = se;
+  __syncthreads();
+  se = red[4] + red[5] + red[6] + red[7];
+  const float invT = 1.0f / (float)T;
+  if (tid == 0) atomicAdd(loss, (logf(se) + mx - lg[0]) * invT);
+  // gradient: dl_k = (softmax_k - [k == 0]) / (T temperature);  d anchor += sum_k dl_k x_k,  d x_k += dl_k anchor
+  float da[32];
+#pragma unroll
+  for (int j = 0; j < 32; ++j) da[j] = 0.f;
+  const float gs = invT * inv_temp / se;
+  for (int k = tid; k <= K; k += 256) {
+    const int px = k == 0 ? pi[t] : ni[(long long)t * K + k - 1];
+    const float dl = expf(lg[k] - mx) * gs - (k == 0 ? invT * inv_temp : 0.f);
+#pragma unroll
+    for (int j = 0; j < 32; ++j)
+      if (j < n) {
+        da[j] += dl * feat[base + j * HW + px];
+        atomicAdd(dfeat + base + j * HW + px, dl * av[j]);
+      }
+  }
+#pragma unroll
+  for (int j = 0; j < 32; ++j)
+    if (j < n) {
+      float v = da[j];
+      for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+      if ((tid & 63) == 0) atomicAdd(dfeat + base + j * HW + a, v);
+    }
+}
+void launch_infonce(const float* feat, int B, int n, long long HW, const int* bi, const int* ai, const int* pi, const int* ni, int T, int K, float temperature,
+                    float* loss, float* dfeat, hipStream_t s) {
+  LDIFF_CHECK(n >= 1 && n <= 32 && K >= 1 && K <= 8192 && temperature > 0.f, LDIFF_ERR_INVALID, "infonce: 1..32 feature planes, 1..8192 negatives");
+  HIP_CHECK(hipMemsetAsync(loss, 0, sizeof(float), s));
+  HIP_CHECK(hipMemsetAsync(dfeat, 0, (size_t)B * n * HW * sizeof(float), s));
+  if (T == 0) return;
+  const size_t smem = (size_t)(K + 1 + 8 + n) * sizeof(float);
+  hipLaunchKernelGGL(infonce_kernel, dim3(T), dim3(256), smem, s, feat, n, HW, bi, ai, pi, ni, T, K, 1.0f / temperature, loss, dfeat);
+  HIP_CHECK(hipGetLastError());
+}

@@ -63,6 +63,13 @@ class InfoNceLoss:
         B, n, H, W = features.shape
         feat = features.view(B, n, -1).permute(0, 2, 1)
         triples = self.sample_triples(labels.to("cpu") if triples is None and labels.is_cuda else labels) if triples is None else triples
+        if features.is_cuda:
+            # GPU features: value and gradient from the one-launch HIP kernel (ldiff_op_infonce); the loop below is the host statement of
+            # the same arithmetic that tests/test_cpu_oracle.py pins to the reference's function
+            from .train import contrastive_loss
+            if not any(triples):
+                return torch.tensor(0.0, requires_grad=True, device=features.device)
+            return contrastive_loss(features, triples, self.temperature)
         total, count = 0.0, 0
         for b in range(B):
             for anchor, positive, negatives in triples[b]:

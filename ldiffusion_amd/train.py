@@ -214,15 +214,14 @@ def contrastive_loss(features, pairs, temperature=0.5):
     if K > 0 and all(len(tr[2]) == K for tr in triples):
         # every triple has the same number of negatives (the reference's sampler, model/loss.py:60-93): one gather + one cross-entropy
         dev = features.device
-        bi = torch.tensor([b for b in range(B) for _ in pairs[b]], device=dev)
-        ai = torch.tensor([tr[0] for tr in triples], device=dev)
-        pi = torch.tensor([tr[1] for tr in triples], device=dev)
-        ni = torch.tensor([tr[2] for tr in triples], device=dev)
-        anchor = feat[bi, ai]                                              # [T, n]
-        pos = (anchor * feat[bi, pi]).sum(-1, keepdim=True)                # [T, 1]
-        neg = torch.einsum("tn,tkn->tk", anchor, feat[bi[:, None], ni])    # [T, K]
-        logits = torch.cat([pos, neg], -1) / temperature
-        return F.cross_entropy(logits, torch.zeros(len(triples), dtype=torch.long, device=dev))
+        i32 = dict(dtype=torch.int32, device=dev)
+        bi = torch.tensor([b for b in range(B) for _ in pairs[b]], **i32)
+        ai = torch.tensor([tr[0] for tr in triples], **i32)
+        pi = torch.tensor([tr[1] for tr in triples], **i32)
+        ni = torch.tensor([tr[2] for tr in triples], **i32)
+        if not features.is_cuda:
+            raise RuntimeError("contrastive_loss: the loss and its gradient run in ldiff_op_infonce; features must be on the GPU")
+        return ag.InfoNceFn.apply(features.float(), bi, ai, pi, ni, temperature)
     total, count = features.new_zeros(()), 0
     for b in range(B):
         for a, p, negs in pairs[b]:

@@ -24,7 +24,7 @@ def test_library_exports_every_symbol_declared_in_header(lib):
     assert declared == set(_lib.SIGNATURES), f"header vs ctypes table differ: {declared ^ set(_lib.SIGNATURES)}"
     for name in declared:
         assert hasattr(lib, name), f"{name} not exported by libldiff_hip.so"
-    assert lib.ldiff_version() == 120
+    assert lib.ldiff_version() == 130
 
 
 def test_host_only_entry_points_match_oracle(lib):

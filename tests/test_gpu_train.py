@@ -12,10 +12,34 @@ import torch
 import torch.nn.functional as F
 
 from ldiffusion_amd import configs, train, weights
+from ldiffusion_amd.loss import InfoNceLoss
 from oracle import noise_post, schedule, unet as ounet, vae as ovae
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
+
+
+@pytest.mark.parametrize("B,n,hw,K,per", [(2, 5, 64, 1024, 12), (1, 1, 16, 7, 3), (3, 32, 32, 300, 5)])
+def test_contrastive_loss_kernel_value_and_gradient(B, n, hw, K, per):
+    """ldiff_op_infonce (one launch: loss + d loss / d features) against the host statement of model/loss.py:89-109 in float64 for the
+    same triples: the reference's shape (5 V5 planes, 1024 negatives), the smallest one, and the plane limit.  <= 1e-5 relative."""
+    g = torch.Generator().manual_seed(5)
+    feats = torch.rand((B, n, hw, hw), generator=g) * 2 - 0.5
+    pairs = [[(int(torch.randint(0, hw * hw, (1,), generator=g)), int(torch.randint(0, hw * hw, (1,), generator=g)),
+               torch.randperm(hw * hw, generator=g)[:K].tolist()) for _ in range(per)] for _ in range(B)]
+    pairs[-1] = pairs[-1][:1]                                   # images contribute different numbers of triples
+    ref_in = feats.double().requires_grad_(True)
+    ref = InfoNceLoss().compute_contrastive_loss(ref_in, None, triples=pairs)
+    ref.backward()
+    x = feats.to(DEV).requires_grad_(True)
+    loss = train.contrastive_loss(x, pairs)
+    (loss * 3.0).backward()
+    e_l = abs(loss.item() - ref.item()) / abs(ref.item())
+    e_g = ((x.grad.cpu().double() / 3.0 - ref_in.grad).abs().max() / ref_in.grad.abs().max()).item()
+    print(f"\n[infonce B={B} n={n} {hw}x{hw} K={K}] loss {loss.item():.6f} (ref {ref.item():.6f}, rel {e_l:.1e}); gradient max err / max {e_g:.1e}")
+    assert e_l <= 1e-5 and e_g <= 1e-5
+    again = train.contrastive_loss(feats.to(DEV), pairs)        # the outputs are overwritten, not accumulated
+    assert abs(again.item() - loss.item()) <= 1e-6 * abs(loss.item())
 
 
 def _setup(sd15=False):
@@ -54,7 +78,7 @@ def _oracle_loss_and_grads(ucfg, vcfg, usd, vsd, z0, hidden, proj_w, proj_b, sch
         rgb = F.interpolate(ovae.vae_decode(vsd, vcfg, den), size=(64, 64), mode="bilinear", align_corners=False)
         grays.append((rgb * torch.tensor(train.LUMA).view(1, 3, 1, 1)).sum(1, keepdim=True))
     feats = torch.cat(grays, 1)
-    loss = train.contrastive_loss(feats, pairs)
+    loss = InfoNceLoss().compute_contrastive_loss(feats, None, triples=pairs)   # CPU statement, pinned to model/loss.py by tests/test_cpu_oracle.py
     loss.backward()
     return loss.detach(), feats.detach(), {k: v.grad for k, v in sd.items()}, pw.grad, pb.grad
 
@@ -79,6 +103,7 @@ def _compare_step(sd15, tol_feat, tol_loss, tol_grad, min_cos):
     gmax = max(float(v.abs().max()) for v in rgrads.values())
     missing = [k for k, p in unet.p.items() if p.grad is None]
     assert not missing, f"no gradient reached {missing[:5]}"
+    lost_where = []
     lost, nonzero = 0, 0   # float16 activation gradients without loss scaling: entries that came out exactly 0 where the reference's are not small
     for k, p in list(unet.p.items()) + [("proj.weight", pw), ("proj.bias", pb)]:
         ref = rgrads[k] if k in rgrads else (rpw if k == "proj.weight" else rpb)
@@ -86,12 +111,16 @@ def _compare_step(sd15, tol_feat, tol_loss, tol_grad, min_cos):
         e = ((got - ref).abs().max() / ref.abs().max().clamp_min(1e-3 * gmax)).item()
         if e > worst[0]:
             worst = (e, k)
-        big = ref.abs() > 1e-3 * ref.abs().max().clamp_min(1e-30)
-        lost += int(((got == 0) & big).sum()); nonzero += int(big.sum())
+        big = ref.abs() > 1e-3 * ref.abs().max().clamp_min(1e-3 * gmax)   # (tensors whose gradient is mathematically 0 hold only rounding noise)
+        nl = int(((got == 0) & big).sum())
+        lost += nl; nonzero += int(big.sum())
+        if nl:
+            lost_where.append((nl, k, tuple(ref.shape)))
         dots += (got.double() * ref.double()).sum().item(); n1 += got.double().pow(2).sum().item(); n2 += ref.double().pow(2).sum().item()
     cos = dots / (n1 ** 0.5 * n2 ** 0.5)
     print(f"training step ({'SD-v1.5' if sd15 else 'tiny'} width, 8x8 latents, {len(ts)} V5 pass(es)): features {e_f:.2e}, loss {loss.item():.5f} vs {rloss.item():.5f} ({e_l:.2e}); "
           f"{len(unet.p) + 2} parameter gradients: worst {worst[0]:.2e} ({worst[1]}), cosine {cos:.6f}; entries lost to fp16 underflow {lost} of {nonzero} ({lost / max(nonzero, 1):.2e})")
+    print("  exact zeros by tensor:", sorted(lost_where, reverse=True)[:8])
     assert e_f <= tol_feat and e_l <= tol_loss and worst[0] <= tol_grad and cos >= min_cos
     assert lost <= 1e-4 * nonzero, "float16 activation gradients underflow: a loss scale is needed at this width"
     assert all(not p.requires_grad and p.grad is None for p in dec.p.values())            # the VAE is frozen: no parameter gradients

@@ -135,7 +135,7 @@ def test_training_step_gradients_match_autograd_over_the_oracle():
 def test_training_step_at_sd15_width_matches_autograd_over_the_oracle():
     """BASELINE.json configs[4] at SD-v1.5 width (fp16 operands, one rank): B = 2, 8 x 8 latents, one V5 pass, 860 M parameter gradients
     against torch.autograd over the fp32 CPU oracle."""
-    _compare_step(True, 1e-2, 2e-3, 5e-2, 0.9995)
+    _compare_step(True, 1e-2, 2e-3, 4e-2, 0.9995)        # measured: features 5.5e-3, loss 7e-5, worst gradient 2.2e-2, cosine 0.99993
 
 
 def test_train_step_runs_and_updates_parameters():

@@ -46,11 +46,16 @@ template <int V> using ic_t = std::integral_constant<int, V>;
 constexpr int D_HWD = 18, D_HPX = 18 * 18, D_ROWB = D_HWD * 128;       // halo image of a 16x16 tile: 18 x 18 pixels of 128 B (64 channels)
 constexpr unsigned D_HB = 41 * 1024;                                   // one halo image = 41 DMA pieces of 8 pixels (324 pixels + 4 pad)
 constexpr int D_NBUF = 3;                                              // halo images: one being read, two being built
-constexpr unsigned D_FLAGS = D_NBUF * D_HB;                            // [producer progress x4][consumer progress x4]
+constexpr unsigned D_FLAGS = D_NBUF * D_HB;                            // [producer slabs x4][consumer slabs x4][consumer tiles staged x4][producer tiles stored x4]
 constexpr unsigned D_DUMP = D_FLAGS + 64;                              // 8 waves x 256 B: where the lanes other than 0 put their copy of a progress word
 constexpr unsigned D_AFF = D_DUMP + 8 * 256;                           // [producer wave 4][image 3] x 512 B: scale (256 B) | shift (256 B) of a slab's 64 channels
 constexpr unsigned D_BT = D_AFF + 12 * 512;                            // [unit parity 2] x (bias 128 floats | time embedding 128 floats) of a unit's channel tile
-constexpr unsigned D_LDS = D_BT + 2 * 1024;
+// Output staging: a unit's fp16 tile (16 chunks of 4 KiB: [channel tile a][consumer wave w][row pair][lane][16 B]) goes from the consumers
+// to the producers through LDS: chunks 0-5 live here, chunks 6-15 in the halo image the unit's last slab has just released.
+constexpr unsigned D_STG = D_BT + 2 * 1024;
+constexpr int D_STG_CHUNKS = 6;
+constexpr unsigned D_LDS = D_STG + D_STG_CHUNKS * 4096;
+static_assert((16 - D_STG_CHUNKS) * 4096 <= D_HB, "the rest of a staged tile must fit one halo image");
 static_assert(D_LDS <= 160 * 1024, "LDS budget of one workgroup per CU");
 constexpr unsigned D_OOR = 0x80000000u;                                // beyond num_records of every descriptor used here: the load returns zeros
 constexpr int D_NROUND = 11;                                           // pieces per producer wave and slab: 41 = 4 x 10 + 1
@@ -139,7 +144,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3d_kernel(const ConvParams p, co
     const int nsleep = ((id >> 3) & 15) * nslab;
     for (int k = 0; k < nsleep; ++k) __builtin_amdgcn_s_sleep(10);
   }
-  if (tid < 8) *reinterpret_cast<volatile unsigned*>(smem_raw + D_FLAGS + tid * 4) = 0u;
+  if (tid < 16) *reinterpret_cast<volatile unsigned*>(smem_raw + D_FLAGS + tid * 4) = 0u;
   __syncthreads();
   if (n_u <= 0) return;
 
@@ -151,8 +156,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3d_kernel(const ConvParams p, co
     const __amdgpu_buffer_rsrc_t shrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.gn_shift, 0, (int)((long long)p.B * Cin * 4), 0x00020000);
     const __amdgpu_buffer_rsrc_t brsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(p.bias ? p.bias : p.gn_scale), 0, p.bias ? p.Nrows * 4 : 0, 0x00020000);
     const __amdgpu_buffer_rsrc_t trsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(p.temb ? p.temb : p.gn_scale), 0, p.temb ? (int)((long long)p.B * p.ld_temb * 4) : 0, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(p.res ? p.res : (const f16*)p.gn_scale), 0, p.res ? (int)((long long)p.M * p.ld_res * 2) : 0, 0x00020000);
-    const unsigned cflags = lds0 + D_FLAGS + 16u;
+    const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, (int)((long long)p.M * p.ldy * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(p.res ? p.res : (const f16*)p.y), 0, (int)((long long)p.M * (p.res ? p.ld_res : p.ldy) * 2), 0x00020000);
+    const unsigned cflags = lds0 + D_FLAGS + 16u, eflags = lds0 + D_FLAGS + 32u, dflags = lds0 + D_FLAGS + 48u;
+    const unsigned dflag_addr = lane == 0 ? lds0 + D_FLAGS + 48u + (unsigned)pw * 4u : lds0 + D_DUMP + (unsigned)(4 + pw) * 256u + (unsigned)lane * 4u;
     // progress word by ONE unmasked ds_write_b32: lane 0 hits the word, the other lanes a dump row of their own
     const unsigned pflag_addr = lane == 0 ? lds0 + D_FLAGS + (unsigned)pw * 4u : lds0 + D_DUMP + (unsigned)(4 + pw) * 256u + (unsigned)lane * 4u;
 
@@ -216,18 +223,6 @@ __global__ __launch_bounds__(512, 2) void conv3x3d_kernel(const ConvParams p, co
 #endif
         n += 2;
       }
-      if (p.res && sc.c == nslab - 1) {   // the unit's last slab: touch the lines of its residual tile (256 pixels x 256 B = 512 lines; 128 per producer
-        // wave, one dword per lane and instruction into a dump row) so that the consumers' epilogue loads are L2 hits
-        const int px = pw * 64 + lane;                                   // this lane's pixel of the 16 x 16 tile
-        const unsigned rpix = (unsigned)((sc.un.b * H + sc.un.oy0 + (px >> 4)) * W + sc.un.ox0 + (px & 15));
-        const int voff = (int)((rpix * (unsigned)p.ld_res + (unsigned)sc.un.n0) * 2u);
-        unsigned char* dst = smem_raw + D_DUMP + (unsigned)(4 + pw) * 256u;
-#if defined(__HIP_DEVICE_COMPILE__)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrsrc, (lptr_t*)dst, 4, voff, 0, 0, 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrsrc, (lptr_t*)dst, 4, voff, 128, 0, 0);
-#endif
-        n += 2;
-      }
       static_for<0, D_NROUND>([&](auto rc_) {
         constexpr int r = decltype(rc_)::value;
         if (r < 10 || pw == 0) {
@@ -281,37 +276,154 @@ __global__ __launch_bounds__(512, 2) void conv3x3d_kernel(const ConvParams p, co
 #ifdef C3D_STAMPS
     unsigned long long dbg[32] = {0};
 #endif
+    // Epilogue of local unit i, from the tile the consumers staged (D_STG + the halo image `hb_last` of the unit's last slab): producer wave
+    // pw stores the 8 rows x 16 columns x 64 channels consumer wave pw computed, in FULL 128-byte lines: a staged 16-byte item = 8
+    // consecutive channels ("octet" o = 2 a + gh of the wave's 64) of one pixel, and lane (px = lane >> 3, o = lane & 7) of store j takes
+    // octet o of pixel (row j >> 1, column 8 (j & 1) + px): eight lanes = one line, one instruction = eight lines.  (Storing the items
+    // in the accumulator shape -- 32 bytes per pixel and instruction -- costs 6 % of the layer: the memory pipe works in lines.)
+    // The consumers rotate an item's 16-byte slot inside its 256-byte staging row by 2 o, so that the sixteen lanes of a read phase
+    // (2 pixels x 8 octets) hit sixteen different slots.  Residual: read in the same shape, added in fp16 (v_pk_add_f16 = the exactly
+    // rounded sum of the two fp16 values).  Fused GroupNorm statistics of the stored values: a lane's octet is the same in all sixteen
+    // stores, so 8 sums + 8 sums of squares accumulate per lane and are reduced over the eight pixel lanes in three halving steps
+    // (row_ror:8, v_permlane16_swap, v_permlane32_swap): every lane ends with (sum, sum of squares) of ONE channel: one 8-byte store.
+    const int e_wm = pw >> 1, e_wn = pw & 1, e_px = lane >> 3, e_o = lane & 7;
+    auto store_unit = [&](int i, unsigned hb_last) __attribute__((always_inline)) {
+      constexpr bool RES = (FLAGS & D_RES) != 0, ST = (FLAGS & D_STATS) != 0;
+      const UnitC un = decode(u0 + i);
+      const unsigned pix0 = (unsigned)((un.b * H + un.oy0 + e_wm * 8) * W + un.ox0);   // first pixel of the wave's 8 x 16 block
+      const unsigned ch0 = (unsigned)(un.n0 + e_wn * 64);
+      const int ylane = (e_px * p.ldy + e_o * 8) * 2, rlane = (e_px * p.ld_res + e_o * 8) * 2;
+      const unsigned ybase = (pix0 * (unsigned)p.ldy + ch0) * 2u, rbase = (pix0 * (unsigned)p.ld_res + ch0) * 2u;
+      u32x4 R[16];
+      if constexpr (RES) {   // (nothing of this wave's is in flight here: the compiler's own waits for these loads are exact)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) R[j] = __builtin_amdgcn_raw_buffer_load_b128(rrsrc, rlane + (int)(rbase + (unsigned)(((j >> 1) * W + (j & 1) * 8) * p.ld_res) * 2u), 0, 0);
+      }
+      while ((int)flags_min_now(eflags) < i + 1) { __builtin_amdgcn_s_sleep(2); DACC(8, 1); }
+      u32x4 U[16];
+      {
+        const int idx = (e_o >> 1) * 4 + pw;   // chunk of this lane's channel tile
+        const unsigned cb = (idx < D_STG_CHUNKS ? lds0 + D_STG + (unsigned)idx * 4096u : lds0 + hb_last + (unsigned)(idx - D_STG_CHUNKS) * 4096u) + (unsigned)(e_o & 1) * 512u;
+        const unsigned a0 = cb + (unsigned)((e_px + 2 * e_o) & 15) * 16u, a8 = cb + (unsigned)((8 + e_px + 2 * e_o) & 15) * 16u;
+        // row rr = j >> 1 of the wave's eight = row pair rr >> 1 (1 KiB), row of the pair rr & 1 (256 B)
+        asm volatile("ds_read_b128 %0, %8\n\tds_read_b128 %1, %9\n\tds_read_b128 %2, %8 offset:256\n\tds_read_b128 %3, %9 offset:256\n\t"
+                     "ds_read_b128 %4, %8 offset:1024\n\tds_read_b128 %5, %9 offset:1024\n\tds_read_b128 %6, %8 offset:1280\n\tds_read_b128 %7, %9 offset:1280"
+                     : "=&v"(U[0]), "=&v"(U[1]), "=&v"(U[2]), "=&v"(U[3]), "=&v"(U[4]), "=&v"(U[5]), "=&v"(U[6]), "=&v"(U[7]) : "v"(a0), "v"(a8) : "memory");
+        asm volatile("ds_read_b128 %0, %8 offset:2048\n\tds_read_b128 %1, %9 offset:2048\n\tds_read_b128 %2, %8 offset:2304\n\tds_read_b128 %3, %9 offset:2304\n\t"
+                     "ds_read_b128 %4, %8 offset:3072\n\tds_read_b128 %5, %9 offset:3072\n\tds_read_b128 %6, %8 offset:3328\n\tds_read_b128 %7, %9 offset:3328"
+                     : "=&v"(U[8]), "=&v"(U[9]), "=&v"(U[10]), "=&v"(U[11]), "=&v"(U[12]), "=&v"(U[13]), "=&v"(U[14]), "=&v"(U[15]) : "v"(a0), "v"(a8) : "memory");
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(U[0]), "+v"(U[1]), "+v"(U[2]), "+v"(U[3]), "+v"(U[4]), "+v"(U[5]), "+v"(U[6]), "+v"(U[7]),
+                                            "+v"(U[8]), "+v"(U[9]), "+v"(U[10]), "+v"(U[11]), "+v"(U[12]), "+v"(U[13]), "+v"(U[14]), "+v"(U[15]));
+      lds_write32(dflag_addr, (unsigned)i + 1u);   // the staged tile is in registers: its LDS is free (the halo image once all four producers say so)
+      float x16[16];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) x16[j] = 0.f;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        u32x4 o = U[j];
+        if constexpr (RES) {
+#pragma unroll
+          for (int d = 0; d < 4; ++d) {
+            const unsigned ud = o[d], rd = R[j][d];
+            const f16x2 sum = __builtin_bit_cast(f16x2, ud) + __builtin_bit_cast(f16x2, rd);
+            o[d] = __builtin_bit_cast(unsigned, sum);
+          }
+        }
+        // (offset in the VGPR and a wait state behind the store: with an SGPR soffset a VALU write of the data registers right after a
+        // 16-byte store is seen by the store -- profiles/r02_conv3x3_pingpong.md)
+        __builtin_amdgcn_raw_buffer_store_b128(o, yrsrc, ylane + (int)(ybase + (unsigned)(((j >> 1) * W + (j & 1) * 8) * p.ldy) * 2u), 0, 0);
+        asm volatile("s_nop 1" ::: "memory");
+        if constexpr (ST) {
+#pragma unroll
+          for (int d = 0; d < 4; ++d) {
+            const unsigned od = o[d];
+            const f16x2 h = __builtin_bit_cast(f16x2, od);
+            const float f0 = (float)h[0], f1 = (float)h[1];
+            x16[2 * d] += f0; x16[2 * d + 1] += f1;
+            x16[8 + 2 * d] += f0 * f0; x16[8 + 2 * d + 1] += f1 * f1;
+          }
+        }
+      }
+      if constexpr (ST) {
+        // halving steps over the pixel lanes (lane bits 3, 4, 5); value index bit b is decided at step b, bit 3 (sum / sum of squares) stays
+        const bool b0 = (lane & 8) != 0;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const float keep = b0 ? x16[2 * q + 1] : x16[2 * q], send = b0 ? x16[2 * q] : x16[2 * q + 1];
+          x16[q] = keep + dpp_f<0x128>(send);   // row_ror:8 = lane ^ 8
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {   // swap(odd, even): rows 0, 2 end with both copies of the ODD value, rows 1, 3 with both of the EVEN one
+          auto sw = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, x16[2 * q + 1]), __builtin_bit_cast(unsigned, x16[2 * q]), false, false);
+          x16[q] = u2f(sw[0]) + u2f(sw[1]);
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {   // the same between the wave's halves
+          auto sw = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, x16[2 * q + 1]), __builtin_bit_cast(unsigned, x16[2 * q]), false, false);
+          x16[q] = u2f(sw[0]) + u2f(sw[1]);
+        }
+        const int chn = ((lane >> 3) & 1) | ((((lane >> 4) & 1) ^ 1) << 1) | ((((lane >> 5) & 1) ^ 1) << 2);
+        const long long rblk = ((long long)(un.oy0 >> 4) * tiles_x + (un.ox0 >> 4)) * 2 + e_wm;
+        const int n = (int)ch0 + e_o * 8 + chn;
+        *reinterpret_cast<float2*>(p.stats + (((long long)un.b * p.N + n) * p.stats_R + rblk) * 2) = make_float2(x16[0], x16[1]);
+      }
+    };
+
     DSTAMP(p_t0);
-    // Software pipeline over the run's slabs: the pieces of slab k + 1 are in flight while slab k is normalised.
+    // Software pipeline over the run's slabs: the pieces of slab k + 1 are in flight while slab k is normalised.  Iteration k is also where
+    // the tile of the unit whose LAST slab was k - 2 is stored (nslab >= 2: at most every other iteration): its staged rows occupy image
+    // (k + 1) % 3, the one slab k + 1 goes to, so that slab's pieces are issued behind the stores instead of in front of the transform --
+    // the consumers are a whole slab (nine steps) away from needing it.
     SlabC cur, nxt;
     cur.k = 0; cur.c = 0; cur.u = u0; set_unit(cur);
     issue_slab(cur);
     nxt = cur;
+    int stored = 0;   // units whose tile has been stored
     for (int k = 0; k < total_slabs; ++k) {
       advance(nxt);
+      const bool store_here = k >= 2 && (k - 1) % nslab == 0;
       int n_next = 0;
       DSTAMP(q0);
-      if (nxt.k < total_slabs) {
+      if (!store_here && nxt.k < total_slabs) {
         // image (k + 1) % 3 held slab k - 2: free once every consumer has all of that slab's pixels in registers
         while ((int)flags_min_now(cflags) < k - 1) { __builtin_amdgcn_s_sleep(2); DACC(5, 1); }
         n_next = issue_slab(nxt);
       }
       DSTAMP(q1);
       // slab k's pieces are older than everything just issued: leave exactly those in flight
-      if (n_next >= 17) asm volatile("s_waitcnt vmcnt(17)" ::: "memory");
-      else if (n_next >= 15) asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
+      if (n_next >= 15) asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
       else if (n_next >= 14) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
       else if (n_next >= 13) asm volatile("s_waitcnt vmcnt(13)" ::: "memory");
       else if (n_next >= 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       DSTAMP(q2);
+#ifndef C3D_ABL_NOXF
       xform_slab(cur);
+#endif
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       lds_write32(pflag_addr, (unsigned)k + 1u);
       DSTAMP(q3);
-      DACC(1, q1 - q0); DACC(2, q2 - q1); DACC(3, q3 - q2); DACC(6, 1);
+      if (store_here) {
+        const int i = (k - 1) / nslab - 1;
+#ifndef C3D_ABL_NOSTORE
+        store_unit(i, (unsigned)((k + 1) % D_NBUF) * D_HB);
+#else
+        lds_write32(dflag_addr, (unsigned)i + 1u);
+#endif
+        stored = i + 1;
+        if (nxt.k < total_slabs) {
+          while ((int)flags_min_now(dflags) < i + 1) { __builtin_amdgcn_s_sleep(1); DACC(9, 1); }   // every producer has its part of the staged tile in registers
+          issue_slab(nxt);
+        }
+      }
+      DSTAMP(q4);
+      DACC(1, q1 - q0); DACC(2, q2 - q1); DACC(3, q3 - q2); DACC(4, q4 - q3); DACC(6, 1);
       cur = nxt;
     }
+#ifndef C3D_ABL_NOSTORE
+    for (int i = stored; i < n_u; ++i) store_unit(i, (unsigned)(((i + 1) * nslab - 1) % D_NBUF) * D_HB);   // the last unit (one-slab units: the last two)
+#endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #ifdef C3D_STAMPS
     { DSTAMP(p_t2); dbg[7] = p_t2 - p_t0; if (blockIdx.x == 0 && pw == 0 && lane == 0) for (int i = 0; i < 32; ++i) c3d_dbg[16 + i] = dbg[i]; }
@@ -369,71 +481,37 @@ __global__ __launch_bounds__(512, 2) void conv3x3d_kernel(const ConvParams p, co
     while (flags_min_now(pflags) < need) { DACC(1, 1); }
   };
 
-  const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, (int)((long long)p.M * p.ldy * 2), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(p.res ? p.res : (const f16*)p.y), 0, (int)((long long)p.M * (p.res ? p.ld_res : p.ldy) * 2), 0x00020000);
-
-  // Epilogue of a unit.  Lane holds y[pixel = (row m, column l15)][channels 4g .. 4g+3 of channel tile a].  One v_permlane16_swap per dword
-  // between the packed values of two rows P = 2pr, Q = 2pr + 1 leaves lanes with even g holding channels 4g .. 4g+7 of row P and lanes
-  // with odd g channels 4(g-1) .. 4(g-1)+7 of row Q: 16-byte stores; the residual is read in the same shape and un-swapped the same way
-  // (the swap is its own inverse).
-  auto epilogue = [&](const UnitC& u) __attribute__((always_inline)) {
-    const int mrow = wave_m * 8 + (g & 1);
-    const unsigned pix = (unsigned)((u.b * H + u.oy0 + mrow) * W + u.ox0 + l15);
-    const unsigned chb = (unsigned)(u.n0 + wave_n * 64 + (g & ~1) * 4);
-    const unsigned yoff = (pix * (unsigned)p.ldy + chb) * 2u, ystep = (unsigned)(2 * W * p.ldy) * 2u;
-    const unsigned roff = (pix * (unsigned)p.ld_res + chb) * 2u, rstep = (unsigned)(2 * W * p.ld_res) * 2u;
-    constexpr bool RES = (FLAGS & D_RES) != 0, ST = (FLAGS & D_STATS) != 0;
-    // the residual tile: all sixteen 16-byte loads go out at once (the operand registers of the tap loop are free here): ONE memory round
-    // trip in front of the first row pair instead of one per pair; the producers have touched its lines during the unit's last slab (L2)
-    u32x4 R[4][4];
-    if constexpr (RES) {
-#pragma unroll
-      for (int pr = 0; pr < 4; ++pr)
-#pragma unroll
-        for (int a = 0; a < 4; ++a) R[pr][a] = __builtin_amdgcn_raw_buffer_load_b128(rrsrc, (int)(roff + pr * rstep + a * 32), 0, 0);
-    }
-    // fused GroupNorm statistics: per channel tile the 4 sums and 4 sums of squares of the lane's channels over its 8 rows are reduced over
-    // the 16 pixel lanes at once (row16_reduce_spread<8>: lane keeps ONE of the eight totals, value index jv): eight live registers
-    // instead of thirty-two (the epilogue shares the register file with 128 accumulators)
-    float tot[4] = {0.f, 0.f, 0.f, 0.f};
-    static_for<0, 4>([&](auto ac) {   // channel tile outermost: the statistics of a tile are reduced over the pixel lanes once, not once per row pair
+  // End of a unit: the consumer only ROUNDS its sums to fp16 and hands them to the producers through LDS (store_unit above) -- 16 ds_write_b128
+  // per lane instead of a residual read, the statistics and 64 KB of stores in front of the next unit's first MFMA.  Lane holds
+  // y[pixel = (row m, column l15)][channels 4g .. 4g+3 of channel tile a]; one v_permlane16_swap per dword between the packed values of two
+  // rows P = 2pr, Q = 2pr + 1 leaves lanes with even g holding channels 4g .. 4g+7 of row P and lanes with odd g channels 4(g-1) .. 4(g-1)+7
+  // of row Q: the 16-byte items the producers store as they are.  Chunk a * 4 + wave: the first D_STG_CHUNKS in the staging area (free once
+  // the producers hold the previous tile in registers), the rest in the halo image of the unit's last slab (free once every consumer has
+  // read its last pixels).
+  const unsigned cflags_all = lds0 + D_FLAGS + 16u, dflags = lds0 + D_FLAGS + 48u;
+  const unsigned eflag_addr = lane == 0 ? lds0 + D_FLAGS + 32u + (unsigned)wave * 4u : lds0 + D_DUMP + (unsigned)wave * 256u + (unsigned)lane * 4u;
+  auto stage_ready = [&](int i, unsigned slabs_done) __attribute__((always_inline)) {
+    while ((int)flags_min_now(dflags) < i) { DACC(7, 1); }
+    while (flags_min_now(cflags_all) < slabs_done) { DACC(8, 1); }
+  };
+  auto stage_tile = [&](int i, unsigned hb_last) __attribute__((always_inline)) {   // straight-line: the next unit's weights are in flight across it
+    static_for<0, 4>([&](auto ac) {
       constexpr int a = decltype(ac)::value;
-      float x8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      const int idx = a * 4 + wave;
+      // 256-byte row g of the row pair; the item's slot in it rotated by twice its octet (store_unit reads two pixels x eight octets at a time)
+      const unsigned base = (idx < D_STG_CHUNKS ? lds0 + D_STG + (unsigned)idx * 4096u : lds0 + hb_last + (unsigned)(idx - D_STG_CHUNKS) * 4096u) +
+                            (unsigned)g * 256u + (unsigned)((l15 + 4 * a + 2 * (g >> 1)) & 15) * 16u;
 #pragma unroll
       for (int pr = 0; pr < 4; ++pr) {
-        f32x4 v0 = acc[a][2 * pr], v1 = acc[a][2 * pr + 1];
-        if constexpr (RES) {
-          const u32x4 r = R[pr][a];
-          auto s0 = __builtin_amdgcn_permlane16_swap(r[0], r[2], false, false);
-          auto s1 = __builtin_amdgcn_permlane16_swap(r[1], r[3], false, false);
-          v0 += up4(__builtin_bit_cast(f16x4, make_uint2(s0[0], s1[0])));
-          v1 += up4(__builtin_bit_cast(f16x4, make_uint2(s0[1], s1[1])));
-        }
-        const f16x4 o0 = cvt4(v0), o1 = cvt4(v1);
+        const f16x4 o0 = cvt4(acc[a][2 * pr]), o1 = cvt4(acc[a][2 * pr + 1]);
         const uint2 q0 = __builtin_bit_cast(uint2, o0), q1 = __builtin_bit_cast(uint2, o1);
         auto r0 = __builtin_amdgcn_permlane16_swap(q0.x, q1.x, false, false);
         auto r1 = __builtin_amdgcn_permlane16_swap(q0.y, q1.y, false, false);
-        __builtin_amdgcn_raw_buffer_store_b128((u32x4){r0[0], r1[0], r0[1], r1[1]}, yrsrc, (int)(yoff + pr * ystep + a * 32), 0, 0);
-        asm volatile("s_nop 1" ::: "memory");   // the next VALU instruction may overwrite the store's data registers (profiles/r02_conv3x3_pingpong.md)
-        if constexpr (ST) {   // statistics of what the consumer of this tensor will read: the fp16-rounded values
-          const f32x4 f0 = up4(o0), f1 = up4(o1);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) { x8[r] += f0[r] + f1[r]; x8[4 + r] += f0[r] * f0[r] + f1[r] * f1[r]; }
-        }
+        lds_write128(base + (unsigned)pr * 1024u, (u32x4){r0[0], r1[0], r0[1], r1[1]});
       }
-      if constexpr (ST) tot[a] = row16_reduce_spread<8>(x8, l15);
     });
-    if constexpr (ST) {   // one row block per consumer wave (8 x 16 pixels); lanes l15 and l15 ^ 1 hold the same total: the even one stores it
-      const int jv = ((l15 >> 3) & 1) | ((l15 >> 1) & 2) | ((l15 << 1) & 4);   // bits 0-1: channel of the lane's four, bit 2: sum / sum of squares
-      const long long rblk = ((long long)(u.oy0 >> 4) * tiles_x + (u.ox0 >> 4)) * 2 + wave_m;
-      if ((l15 & 1) == 0) {
-#pragma unroll
-        for (int a = 0; a < 4; ++a) {
-          const int n = u.n0 + wave_n * 64 + a * 16 + g * 4 + (jv & 3);
-          p.stats[(((long long)u.b * p.N + n) * p.stats_R + rblk) * 2 + (jv >> 2)] = tot[a];
-        }
-      }
-    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    lds_write32(eflag_addr, (unsigned)i + 1u);
   };
   // a unit's sums start at bias + time embedding: from the table producer wave 0 wrote with the unit's first slab
   auto init_from_table = [&](int parity) __attribute__((always_inline)) {
@@ -523,19 +601,25 @@ __global__ __launch_bounds__(512, 2) void conv3x3d_kernel(const ConvParams p, co
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // the unused operands of the unit's last step
     DSTAMP(e0);
-    epilogue(cur);
+    UnitC nxt = cur;
+    if (has_next) nxt = decode(u + 1);
+    wq = wfrag + (long long)(nxt.n0 >> 7) * 16384;
+    stage_ready(u - u0, (unsigned)k);
+    issue_w(ic_t<0>{}, wq);   // the next unit's first weights travel while the tile is staged (after the last unit: loaded again, unused)
+#ifndef C3D_ABL_NOSTAGE
+    stage_tile(u - u0, (unsigned)((k - 1) % D_NBUF) * D_HB);
+#else
+    lds_write32(eflag_addr, (unsigned)(u - u0) + 1u);
+#endif
+    vm_wait4<0>(Wf[0][0], Wf[0][1], Wf[0][2], Wf[0][3]);   // landed long ago; nothing asynchronous is live across the polls below
     DSTAMP(e1);
     DACC(3, e1 - e0); DACC(4, 1);
     if (has_next) {
-      const UnitC nxt = decode(u + 1);
       wait_producers((unsigned)k + 1u);                 // the next unit's first slab (and with it the bias table producer wave 0 issued in front of it)
       init_from_table((u + 1 - u0) & 1);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the epilogue's stores and loads: nothing of the compiler's may be younger than the loads below
       DSTAMP(e2);
       DACC(5, e2 - e1);
-      wq = wfrag + (long long)(nxt.n0 >> 7) * 16384;
       issue_x(ic_t<0>{}, ic_t<0>{}, ic_t<0>{}, ic_t<0>{}, (unsigned)(k % D_NBUF) * D_HB, X[0]);
-      issue_w(ic_t<0>{}, wq);
       cur = nxt;
     }
   }

@@ -39,4 +39,6 @@ for (B, Cin, H, Cout, res, stats) in cases:
     print(f"B{B} Cin{Cin} H{H} Cout{Cout} res{res} stats{stats}: {us:.0f} us")
     print(f"  consumer w0: total {c[6]} ticks; first-slab wait {c[0]}; slab checks {c[2]}, polls while waiting {c[1]}; units {c[4]}: epilogue {c[3]/units:.0f} ticks each, hand-over to the next unit {c[5]/units:.0f};"
           f" loop share {(c[6]-c[0]-c[3]-c[5])/max(c[6],1):.3f}")
-    print(f"  producer w4: total {p[7]} ticks; per slab ({slabs}): gate + issue {p[1]/slabs:.0f} ({p[5]} sleeps)  wait for the pieces {p[2]/slabs:.0f}  transform + publish {p[3]/slabs:.0f}")
+    print(f"    staging polls: producers' registers {c[7]}, consumers' last reads {c[8]}")
+    print(f"  producer w4: total {p[7]} ticks; per slab ({slabs}): gate + issue {p[1]/slabs:.0f} ({p[5]} sleeps)  wait for the pieces {p[2]/slabs:.0f}  transform + publish {p[3]/slabs:.0f}"
+          f"  store a tile + issue behind it {p[4]/slabs:.0f} (polls: staged {p[8]}, all producers read {p[9]})")

@@ -570,7 +570,7 @@ def test_conv_on_split_tensors(lib, name):
         assert (gotn - refn).abs().max() <= 2e-4 * max(1.0, refn.abs().max())
 
 
-@pytest.mark.parametrize("shape", ["one_unit_one_slab", "three_units_two_slabs", "two_channel_tiles_four_slabs"])
+@pytest.mark.parametrize("shape", ["one_unit_one_slab", "two_units_one_slab", "three_units_two_slabs", "two_channel_tiles_four_slabs"])
 @pytest.mark.parametrize("res,stats,temb", [(0, 0, 0), (1, 0, 1), (0, 1, 0), (1, 1, 1)])
 def test_conv3x3_dataflow_kernel(lib, shape, res, stats, temb):
     """The producer / consumer conv3x3 kernel (kernels_conv3x3d.hip: GroupNorm + SiLU prologue on maps that fill the chip): every epilogue
@@ -578,7 +578,7 @@ def test_conv3x3_dataflow_kernel(lib, shape, res, stats, temb):
     units (tile switches, bias table hand-over) and several channel tiles / slabs.  Three launches each: producers and consumers meet only
     through progress words in LDS, and a missing wait would show up as a now-and-then wrong tile.  The statistics are checked against the
     sums of the kernel's own fp16 outputs (they are defined on the rounded values)."""
-    B, Cin, H, W, Cout = {"one_unit_one_slab": (1, 64, 256, 256, 128), "three_units_two_slabs": (3, 128, 256, 256, 128),
+    B, Cin, H, W, Cout = {"one_unit_one_slab": (1, 64, 256, 256, 128), "two_units_one_slab": (3, 64, 256, 256, 128), "three_units_two_slabs": (3, 128, 256, 256, 128),
                           "two_channel_tiles_four_slabs": (2, 256, 128, 128, 256)}[shape]
     g = torch.Generator().manual_seed(res * 4 + stats * 2 + temb + len(shape))
     x = torch.randn((B, H, W, Cin), generator=g).to(torch.float16)

@@ -475,7 +475,14 @@ __global__ __launch_bounds__(512, 2) void conv3x3d_kernel(const ConvParams p, co
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) acc[a][4 * gr + r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Wf[kh][a], x[r], acc[a][4 * gr + r], 0, 0, 0);
+      for (int r = 0; r < 4; ++r) {
+        acc[a][4 * gr + r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Wf[kh][a], x[r], acc[a][4 * gr + r], 0, 0, 0);
+#ifdef C3D_MFMA_GAP   // experiment: issue slots between matrix instructions (profiles/r02_mfma_peak.md)
+        __builtin_amdgcn_sched_barrier(0);
+        for (int q = 0; q < C3D_MFMA_GAP; ++q) asm volatile("s_nop 0");
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+      }
   };
   auto wait_producers = [&](unsigned need) __attribute__((always_inline)) {
     while (flags_min_now(pflags) < need) { DACC(1, 1); }

@@ -1,3 +1,12 @@
-mkdir -p gpurun_out/r3o
-timeout 300 python -m pytest tests/test_gpu_kernels.py -x -q -m gpu -k "dataflow" 2>&1 | tail -15 > gpurun_out/r3o/test.txt; cat gpurun_out/r3o/test.txt
-LDIFF_C3D_RUN=0 bash scripts/ab_c3d.sh r3o abl_nostore c3d_v3 | grep -E "==|vae512|vae256|vae128"
+mkdir -p gpurun_out/r3s; O=gpurun_out/r3s
+for rep in 1 2; do
+for v in product c3d_v3; do
+  if [ $v = product ]; then L=ldiffusion_amd/libldiff_hip.so; else L=build/$v/libldiff_hip.so; fi
+  timeout 400 python scripts/bench_variant.py $L --steps 6 --warmup 2 --no-cpu-baseline > $O/${v}_$rep.json 2> $O/${v}_$rep.err
+  python3 -c "
+import json,sys
+d=json.loads(open('$O/${v}_$rep.json').read().strip().splitlines()[-1])
+print('$v', round(d['value'],2), round(d['ms_per_step'],2), d['roofline']['frac'], d['roofline']['serial']['frac'], d['roofline']['serial']['avg_launch_us'])
+for k in d['kernels'][:6]: print('   ', k['name'], k['launches'], k['ms'])
+"
+done; done

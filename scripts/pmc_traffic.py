@@ -19,6 +19,7 @@ def load(d, counter):
 def bench_name(k):
     m = re.search(r"conv3x3w_kernel<(\d+), (true|false)>", k)
     if m: return f"conv3x3<8x16,{m.group(1)}{',gn' if m.group(2) == 'true' else ''}>"
+    if re.search(r"conv3x3d_kernel<\d+>", k): return "conv3x3<16x16d,128,gn>"   # producer / consumer kernel: every epilogue configuration
     m = re.search(r"conv3x3p_kernel<(\d+), (true|false), (\d+)>", k)   # persistent 16x16 kernel: every epilogue configuration / parity mode of a tile width
     if m: return f"conv3x3<16x16,{m.group(1)}>"
     m = re.search(r"conv3x3_kernel<(\d+), (\d+), (\d+), (true|false)>", k)

@@ -253,9 +253,11 @@ int ldiff_op_adamw(void* p, const void* g, void* m, void* v, int64_t n, float lr
 /* Contrastive (InfoNCE) feature loss of the fine-tuning step for GIVEN sample triples, forward and gradient in one launch
  * (/root/reference/model/loss.py:89-109; the random draws of :62-87 stay on the host, ldiffusion_amd/loss.py sample_triples):
  *   features f32 [B, n, HW] (n <= 32 planes);  triple t = image bi[t], anchor pixel ai[t], positive pi[t], negatives ni[t*K .. t*K+K) (int32, device)
- *   loss[0] = mean_t CE([a.p | a.n_k] / temperature, target 0);  dfeatures [B, n, HW] = d loss / d features.  Both are overwritten. */
-int ldiff_op_infonce(const void* features, int B, int n, int64_t HW, const void* bi, const void* ai, const void* pi, const void* ni, int T, int K,
-                     float temperature, void* loss, void* dfeatures, void* stream);
+ *   loss[0] = mean_t CE([a.p | a.n_k] / temperature, target 0);  dfeatures [B, n, HW] = d loss / d features.  Both are overwritten.
+ *   T_dev (may be NULL): device int32 holding the actual number of triples (<= T, which is then the capacity of the index arrays and the
+ *   launch size), read at execution time -- the launch is shape-stable, e.g. inside a captured graph whose batches yield varying counts. */
+int ldiff_op_infonce(const void* features, int B, int n, int64_t HW, const void* bi, const void* ai, const void* pi, const void* ni, int T, const void* T_dev,
+                     int K, float temperature, void* loss, void* dfeatures, void* stream);
 /* Weight layouts of the training step (the float32 master [Cout, Cin, k, k] of torch / diffusers -> what ldiff_op_conv reads):
  *   mode 0, forward: dst[n][ky][kx][c] = w[n][c][ky][kx]           rows >= Cout, Cpad >= Cin, the rest zero
  *   mode 1, dgrad:   dst[c][ky][kx][n] = w[n][c][k-1-ky][k-1-kx]   rows >= Cin,  Cpad >= Cout, the rest zero

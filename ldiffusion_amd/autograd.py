@@ -269,7 +269,8 @@ class InfoNceFn(torch.autograd.Function):
     ONE launch of ldiff_op_infonce; backward only scales the stored gradient.  features f32 [B, n, H, W]; bi/ai/pi int32 [T], ni int32 [T, K]."""
 
     @staticmethod
-    def forward(ctx, features, bi, ai, pi, ni, temperature):
+    def forward(ctx, features, bi, ai, pi, ni, temperature, count=None):
+        """count: optional device int32 scalar = the number of valid triples (the index tensors are then capacity-sized: shape-stable launch)."""
         if not (features.is_cuda and features.dtype == torch.float32):
             raise ValueError("InfoNceFn: features must be a float32 CUDA tensor")
         f = features.contiguous()
@@ -277,15 +278,15 @@ class InfoNceFn(torch.autograd.Function):
         T, K = ni.shape
         loss = torch.empty(1, dtype=torch.float32, device=f.device)
         df = torch.empty_like(f)
-        _lib.check(_lib.load().ldiff_op_infonce(f.data_ptr(), B, n, H * W, bi.data_ptr(), ai.data_ptr(), pi.data_ptr(), ni.data_ptr(), T, K,
-                                                float(temperature), loss.data_ptr(), df.data_ptr(), _sp()))
+        _lib.check(_lib.load().ldiff_op_infonce(f.data_ptr(), B, n, H * W, bi.data_ptr(), ai.data_ptr(), pi.data_ptr(), ni.data_ptr(), T,
+                                                None if count is None else count.data_ptr(), K, float(temperature), loss.data_ptr(), df.data_ptr(), _sp()))
         ctx.save_for_backward(df)
         return loss[0]
 
     @staticmethod
     def backward(ctx, g):
         (df,) = ctx.saved_tensors
-        return g * df, None, None, None, None, None
+        return g * df, None, None, None, None, None, None
 
 
 ADAMW_CHUNK = 16384   # elements per workgroup of ldiff_op_adamw_multi (csrc/common.h)

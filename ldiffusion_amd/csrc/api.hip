@@ -561,11 +561,11 @@ int ldiff_op_adamw(void* p, const void* g, void* m, void* v, int64_t n, float lr
   launch_adamw((float*)p, (const float*)g, (float*)m, (float*)v, n, lr, beta1, beta2, eps, weight_decay, step, (hipStream_t)stream);
   API_END
 }
-int ldiff_op_infonce(const void* features, int B, int n, int64_t HW, const void* bi, const void* ai, const void* pi, const void* ni, int T, int K,
-                     float temperature, void* loss, void* dfeatures, void* stream) {
+int ldiff_op_infonce(const void* features, int B, int n, int64_t HW, const void* bi, const void* ai, const void* pi, const void* ni, int T, const void* T_dev,
+                     int K, float temperature, void* loss, void* dfeatures, void* stream) {
   API_BEGIN
   LDIFF_CHECK(features && loss && dfeatures && B >= 1 && HW >= 1 && T >= 0 && (T == 0 || (bi && ai && pi && ni)), LDIFF_ERR_INVALID, "op_infonce: bad arguments");
-  launch_infonce((const float*)features, B, n, HW, (const int*)bi, (const int*)ai, (const int*)pi, (const int*)ni, T, K, temperature, (float*)loss,
+  launch_infonce((const float*)features, B, n, HW, (const int*)bi, (const int*)ai, (const int*)pi, (const int*)ni, T, (const int*)T_dev, K, temperature, (float*)loss,
                  (float*)dfeatures, (hipStream_t)stream);
   API_END
 }

@@ -183,8 +183,8 @@ struct AdamTensor { float* p; float* m; float* v; long long n; };
 struct AdamChunk { int tensor; int pad; long long first; };
 void launch_adamw_multi(const AdamTensor* tensors, const float* const* grads, const AdamChunk* chunks, long long nchunks, float lr, float b1, float b2, float eps,
                         float wd, int step, hipStream_t s);
-void launch_infonce(const float* feat, int B, int n, long long HW, const int* bi, const int* ai, const int* pi, const int* ni, int T, int K, float temperature,
-                    float* loss, float* dfeat, hipStream_t s);   // contrastive loss over given sample triples + its gradient (kernels_bwd.hip)
+void launch_infonce(const float* feat, int B, int n, long long HW, const int* bi, const int* ai, const int* pi, const int* ni, int T, const int* t_dev, int K,
+                    float temperature, float* loss, float* dfeat, hipStream_t s);   // contrastive loss over given sample triples + its gradient (kernels_bwd.hip)
 void launch_adamw(float* p, const float* g, float* m, float* v, long long n, float lr, float b1, float b2, float eps, float wd, int step, hipStream_t s);
 
 // ---- device arena: bump/free-list allocator over one hipMalloc'd slab ------------------------

@@ -391,10 +391,12 @@ void launch_adamw(float* p, const float* g, float* m, float* v, long long n, flo
 // then dL/dlogits = (softmax - onehot) / (T temperature) scattered back into dfeatures with float atomics (pixels repeat across triples;
 // ~T (K + 2) n adds per step: thousands, nowhere near the atomic rate).  loss and dfeatures are zeroed by the launcher.
 __global__ __launch_bounds__(256) void infonce_kernel(const float* __restrict__ feat, int n, long long HW, const int* __restrict__ bi, const int* __restrict__ ai,
-                                                      const int* __restrict__ pi, const int* __restrict__ ni, int T, int K, float inv_temp,
+                                                      const int* __restrict__ pi, const int* __restrict__ ni, int T_arg, const int* __restrict__ t_dev, int K, float inv_temp,
                                                       float* __restrict__ loss, float* __restrict__ dfeat) {
   extern __shared__ float lg[];   // K + 1 logits, then 2 x 4 reduction slots, then the anchor (n)
   const int t = blockIdx.x, tid = threadIdx.x;
+  const int T = t_dev ? *t_dev : T_arg;   // count from device memory: the launch (grid = capacity) is shape-stable, e.g. inside a captured graph
+  if (t >= T) return;
   const long long base = (long long)bi[t] * n * HW;
   float* red = lg + K + 1;
   float* av = red + 8;
@@ -445,13 +447,13 @@ __global__ __launch_bounds__(256) void infonce_kernel(const float* __restrict__ 
       if ((tid & 63) == 0) atomicAdd(dfeat + base + j * HW + a, v);
     }
 }
-void launch_infonce(const float* feat, int B, int n, long long HW, const int* bi, const int* ai, const int* pi, const int* ni, int T, int K, float temperature,
-                    float* loss, float* dfeat, hipStream_t s) {
+void launch_infonce(const float* feat, int B, int n, long long HW, const int* bi, const int* ai, const int* pi, const int* ni, int T, const int* t_dev, int K,
+                    float temperature, float* loss, float* dfeat, hipStream_t s) {
   LDIFF_CHECK(n >= 1 && n <= 32 && K >= 1 && K <= 8192 && temperature > 0.f, LDIFF_ERR_INVALID, "infonce: 1..32 feature planes, 1..8192 negatives");
   HIP_CHECK(hipMemsetAsync(loss, 0, sizeof(float), s));
   HIP_CHECK(hipMemsetAsync(dfeat, 0, (size_t)B * n * HW * sizeof(float), s));
   if (T == 0) return;
   const size_t smem = (size_t)(K + 1 + 8 + n) * sizeof(float);
-  hipLaunchKernelGGL(infonce_kernel, dim3(T), dim3(256), smem, s, feat, n, HW, bi, ai, pi, ni, T, K, 1.0f / temperature, loss, dfeat);
+  hipLaunchKernelGGL(infonce_kernel, dim3(T), dim3(256), smem, s, feat, n, HW, bi, ai, pi, ni, T, t_dev, K, 1.0f / temperature, loss, dfeat);
   HIP_CHECK(hipGetLastError());
 }

@@ -114,7 +114,7 @@ class TrainableUNet(_Graph):
         ctx16 = ctx.to(torch.float16).contiguous()
         half = boc[0] // 2
         freq = torch.exp(-math.log(10000.0) * torch.arange(half, dtype=torch.float32, device=self.device) / (half - cfg["freq_shift"]))
-        arg = torch.as_tensor(float(timestep), dtype=torch.float32, device=self.device) * freq
+        arg = torch.full((), float(timestep), dtype=torch.float32, device=self.device) * freq   # (a fill, not a host copy: capturable)
         emb = torch.cat([torch.sin(arg), torch.cos(arg)])
         if cfg["flip_sin_to_cos"]:
             emb = torch.cat([emb[half:], emb[:half]])
@@ -186,18 +186,37 @@ def _nhwc16_grad(z):
     return zp.to(torch.float16).contiguous()
 
 
-def v5_features(unet, vae_dec, z0, text_embeddings, timesteps, abar, u_list=None, out_hw=64, seed=0, offset=0):
-    """The V5 loop (ldiffusion.py:231-247): returns (features [B, n, out_hw, out_hw] float32, last rgb).  The Laplace noise comes from the
+_LUMA_T = {}
+
+
+def _luma_weights(device):
+    key = str(device)
+    if key not in _LUMA_T:
+        _LUMA_T[key] = torch.tensor(LUMA, dtype=torch.float32).view(1, 3, 1, 1).to(device)
+    return _LUMA_T[key]
+
+
+def v5_noisy(z0, timesteps, abar, u_list=None, seed=0, offset=0):
+    """The noisy latents of the V5 loop (ldiffusion.py:234-237), one per timestep: z0 + Laplace(0, sqrt(1 - abar_t)).  The noise comes from the
     given uniform draws `u_list[i]` (parity is defined given u) or from the device Philox stream (seed, offset + i * numel)."""
     from .pipeline import laplace_noise
-    grays, rgb = [], None
+    out = []
     for i, t in enumerate(timesteps):
         scale = float(torch.sqrt(1 - abar[int(t)]))
-        noisy = laplace_noise(z0, scale, u=None if u_list is None else u_list[i], seed=seed, offset=offset + i * z0.numel())
-        den = unet(noisy, t, text_embeddings)
+        out.append(laplace_noise(z0, scale, u=None if u_list is None else u_list[i], seed=seed, offset=offset + i * z0.numel()))
+    return out
+
+
+def v5_features(unet, vae_dec, z0, text_embeddings, timesteps, abar, u_list=None, out_hw=64, seed=0, offset=0, noisy_list=None):
+    """The V5 loop (ldiffusion.py:231-247): returns (features [B, n, out_hw, out_hw] float32, last rgb).  `noisy_list`: the noisy latents
+    when the caller has drawn them already (GraphedStep: the draw is outside the captured graph)."""
+    if noisy_list is None:
+        noisy_list = v5_noisy(z0, timesteps, abar, u_list, seed, offset)
+    grays, rgb = [], None
+    for i, t in enumerate(timesteps):
+        den = unet(noisy_list[i], t, text_embeddings)
         rgb = F.interpolate(vae_dec(den), size=(out_hw, out_hw), mode="bilinear", align_corners=False)
-        w = torch.tensor(LUMA, device=rgb.device, dtype=torch.float32).view(1, 3, 1, 1)
-        grays.append((rgb * w).sum(1, keepdim=True))
+        grays.append((rgb * _luma_weights(rgb.device)).sum(1, keepdim=True))
     return torch.cat(grays, 1), rgb
 
 
@@ -374,3 +393,94 @@ def train_step(unet, vae_dec, proj, z0, text_hidden, timesteps, abar, u_list, pa
         clip_grad_norm(params, max_grad_norm)
     ag.adamw_step(params, [p.grad for p in params], opt_state, lr=lr, weight_decay=weight_decay)
     return float(loss.detach())
+
+
+class GraphedStep:
+    """Forward, contrastive loss and backward of one fine-tuning step (ldiffusion.py:227-254) captured ONCE as a HIP graph
+    (torch.cuda.CUDAGraph: the ~3,000 launches of the two passes -- libldiff_hip.so kernels and torch's tensor plumbing alike -- become one
+    graph launch) and replayed per step.  The step driven from Python leaves the device idle 39-44 % of the time.
+    What stays outside the graph: the Laplace draw (its Philox offset advances per step), the copy of the batch into the static input
+    buffers, the gradient exchange, clipping and AdamW (its bias correction takes the step count as a launch argument).
+    The sample triples vary in number from batch to batch: the loss launch is capacity-sized (`max_triples`) and reads the count from
+    device memory (ldiff_op_infonce, T_dev)."""
+
+    def __init__(self, unet, vae_dec, proj, batch, timesteps, abar, latent_hw=8, text_len=6, text_dim=768, out_hw=64, max_triples=1024,
+                 num_negatives=1024, temperature=0.5, loss_scale=LOSS_SCALE):
+        dev = unet.device
+        self.unet, self.vae_dec, self.proj = unet, vae_dec, proj
+        self.timesteps, self.abar = [int(t) for t in timesteps], abar.detach().cpu()
+        self.out_hw, self.temperature, self.loss_scale = out_hw, temperature, loss_scale
+        self.noisy = [torch.zeros((batch, 4, latent_hw, latent_hw), device=dev) for _ in self.timesteps]
+        self.hidden = torch.zeros((batch, text_len, text_dim), device=dev)
+        i32 = dict(dtype=torch.int32, device=dev)
+        self.bi, self.ai, self.pi = torch.zeros(max_triples, **i32), torch.zeros(max_triples, **i32), torch.zeros(max_triples, **i32)
+        self.ni = torch.zeros((max_triples, num_negatives), **i32)
+        self.count = torch.zeros((), **i32)
+        self.params = unet.parameters() + list(proj)
+        self.stream = torch.cuda.Stream(device=dev)   # warm-up and capture on ONE stream: the library keeps its scratch per (device, stream)
+        self.graph, self.loss = None, None
+
+    def _forward_backward(self):
+        ctx = F.linear(self.hidden, self.proj[0], self.proj[1])
+        feats, _ = v5_features(self.unet, self.vae_dec, None, ctx, self.timesteps, self.abar, out_hw=self.out_hw, noisy_list=self.noisy)
+        loss = ag.InfoNceFn.apply(feats, self.bi, self.ai, self.pi, self.ni, self.temperature, self.count)
+        (loss * self.loss_scale).backward()
+        if self.loss_scale != 1.0:
+            torch._foreach_mul_([p.grad for p in self.params if p.grad is not None], 1.0 / self.loss_scale)
+        return loss.detach()
+
+    def _capture(self):
+        cur = torch.cuda.current_stream()
+        self.stream.wait_stream(cur)
+        with torch.cuda.stream(self.stream):
+            for _ in range(2):   # sizes every lazily grown buffer (library scratch, derived weight layouts, allocator pools) before the capture
+                for p in self.params:
+                    p.grad = None
+                self._forward_backward()
+        cur.wait_stream(self.stream)
+        torch.cuda.synchronize()
+        for p in self.params:
+            p.grad = None
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph, stream=self.stream):
+            self.loss = self._forward_backward()
+        self.grads = [p.grad for p in self.params]   # the graph's static gradient buffers
+        self.graph.replay()   # (a capture records, it does not execute)
+
+    def set_batch(self, z0, text_hidden, pairs, u_list=None, seed=0, offset=0):
+        for dst, src in zip(self.noisy, v5_noisy(z0, self.timesteps, self.abar, u_list, seed, offset)):
+            dst.copy_(src)
+        self.hidden.copy_(text_hidden)
+        triples = [(b, tr) for b in range(len(pairs)) for tr in pairs[b]]
+        T, K = len(triples), self.ni.shape[1]
+        if T > self.bi.numel():
+            raise ValueError(f"GraphedStep: {T} sample triples exceed max_triples = {self.bi.numel()}")
+        if any(len(tr[2]) != K for _, tr in triples):
+            raise ValueError(f"GraphedStep: every triple must carry num_negatives = {K} negatives")
+        if T:
+            self.bi[:T].copy_(torch.tensor([b for b, _ in triples], dtype=torch.int32))
+            self.ai[:T].copy_(torch.tensor([tr[0] for _, tr in triples], dtype=torch.int32))
+            self.pi[:T].copy_(torch.tensor([tr[1] for _, tr in triples], dtype=torch.int32))
+            self.ni[:T].copy_(torch.tensor([tr[2] for _, tr in triples], dtype=torch.int32))
+        self.count.fill_(T)
+
+    def __call__(self, z0, text_hidden, pairs, u_list=None, seed=0, offset=0):
+        """Loads the batch, replays forward + backward; the parameter gradients are in `.grad` afterwards.  Returns the loss (device scalar)."""
+        self.set_batch(z0, text_hidden, pairs, u_list, seed, offset)
+        if self.graph is None:
+            self._capture()   # (the capture itself computes this batch)
+        else:
+            self.graph.replay()
+        for p, g in zip(self.params, self.grads):   # (a caller may have cleared or replaced .grad since the capture)
+            p.grad = g
+        return self.loss
+
+
+def train_step_graphed(gstep, z0, text_hidden, u_list, pairs, opt_state, lr=1e-5, weight_decay=0.01, max_grad_norm=None, seed=0, offset=0):
+    """`train_step` with forward + backward replayed from `gstep` (GraphedStep); exchange, clipping and AdamW as in the eager step."""
+    loss = gstep(z0, text_hidden, pairs, u_list, seed, offset)
+    allreduce_gradients(gstep.params)
+    if max_grad_norm is not None:
+        clip_grad_norm(gstep.params, max_grad_norm)
+    ag.adamw_step(gstep.params, [p.grad for p in gstep.params], opt_state, lr=lr, weight_decay=weight_decay)
+    return float(loss)

@@ -150,3 +150,43 @@ def test_train_step_runs_and_updates_parameters():
     print(f"three AdamW steps on one batch: loss {[round(x, 5) for x in losses]}")
     assert all(torch.isfinite(torch.tensor(losses))) and losses[-1] < losses[0]
     assert state["step"] == 3 and all(not torch.equal(unet.p[k].detach(), v) for k, v in before.items())
+
+
+def test_graphed_step_equals_the_eager_step():
+    """train.GraphedStep (forward + loss + backward captured once as a HIP graph, replayed per step) against the eager step on the same
+    batches: the first call captures, the second replays on a DIFFERENT batch with a different number of sample triples (the loss launch is
+    capacity-sized and reads the count from device memory).  Same kernels, same order: loss and every parameter gradient agree to float
+    atomics' reordering (the contrastive loss scatters its gradient with atomic adds)."""
+    ucfg, vcfg, usd, vsd, z0, hidden, proj_w, proj_b, sch, ts, u_list, pairs = _setup()
+    unet = train.TrainableUNet(ucfg, usd, DEV)
+    dec = train.FrozenVAEDecoder(vcfg, vsd, DEV)
+    pw, pb = proj_w.to(DEV).requires_grad_(True), proj_b.to(DEV).requires_grad_(True)
+    params = unet.parameters() + [pw, pb]
+    g = torch.Generator().manual_seed(3)
+    batch2 = (z0 * 0.7 + 0.1, hidden.flip(0) * 1.1, [u.flip(0) for u in u_list],
+              [[(int(torch.randint(0, 4096, (1,), generator=g)), int(torch.randint(0, 4096, (1,), generator=g)), torch.randint(0, 4096, (64,), generator=g).tolist())
+                for _ in range(n)] for n in (3, 7)])
+    gstep = train.GraphedStep(unet, dec, (pw, pb), z0.shape[0], ts, sch.alphas_cumprod, latent_hw=8, text_len=hidden.shape[1], text_dim=hidden.shape[2],
+                              max_triples=32, num_negatives=64)
+    for name, (z, h, ul, pr) in (("capture", (z0, hidden, u_list, pairs)), ("replay", batch2)):
+        for p_ in params:
+            p_.grad = None
+        ctx = F.linear(h.to(DEV), pw, pb)
+        feats, _ = train.v5_features(unet, dec, z.to(DEV), ctx, ts, sch.alphas_cumprod, [u.to(DEV) for u in ul])
+        loss = train.contrastive_loss(feats, pr)
+        (loss * train.LOSS_SCALE).backward()
+        ref = [None if p_.grad is None else (p_.grad / train.LOSS_SCALE).clone() for p_ in params]
+        got_loss = gstep(z.to(DEV), h.to(DEV), pr, [u.to(DEV) for u in ul])
+        torch.cuda.synchronize()
+        e_l = abs(got_loss.item() - loss.item()) / abs(loss.item())
+        worst = 0.0
+        for p_, r in zip(params, ref):
+            assert (p_.grad is None) == (r is None)
+            if r is not None:
+                worst = max(worst, ((p_.grad - r).abs().max() / r.abs().max().clamp_min(1e-20)).item())
+        print(f"graphed step ({name}): loss {got_loss.item():.6f} vs eager {loss.item():.6f} ({e_l:.1e}); worst parameter-gradient difference {worst:.1e} of the tensor's max")
+        assert e_l <= 1e-5 and worst <= 1e-3
+    state = {}
+    l0 = train.train_step_graphed(gstep, z0.to(DEV), hidden.to(DEV), [u.to(DEV) for u in u_list], pairs, state, lr=1e-4)
+    l1 = train.train_step_graphed(gstep, z0.to(DEV), hidden.to(DEV), [u.to(DEV) for u in u_list], pairs, state, lr=1e-4)
+    assert state["step"] == 2 and l1 < l0

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define LDIFF_VERSION 130 /* 0.1.3: + ldiff_op_infonce; dataflow conv3x3 kernel behind ldiff_op_conv */
+#define LDIFF_VERSION 130 /* 0.1.3: + ldiff_op_infonce, ldiff_window_accumulate; dataflow conv3x3 kernel behind ldiff_op_conv */
 #define LDIFF_MAX_BLOCKS 8
 
 typedef enum { LDIFF_OK = 0, LDIFF_ERR_INVALID = -1, LDIFF_ERR_RUNTIME = -2, LDIFF_ERR_STATE = -3 } ldiff_status;
@@ -141,6 +141,13 @@ int ldiff_pndm_alphas_cumprod(float* out_host, int n);
 int ldiff_laplace_add(const void* z0, float scale, const void* u_or_null, uint64_t seed, uint64_t offset, void* out, int64_t n, void* stream);
 /* logits [B,C,H,W] f32 -> mask [B,H,W] u8 = argmax over C  (segmentor.py:536-537) */
 int ldiff_argmax_u8(const void* logits, int B, int C, int H, int W, void* mask_u8, void* stream);
+/* One tile of a sliding-window / tile merge: acc[:, y0:y0+th, x0:x0+tw] += pred * weight;  cnt[y0:.., x0:..] += weight (weight NULL: 1)
+ * acc [C,H,W], cnt [H,W], pred [C,th,tw], weight [th,tw]; dtypes 0: all float32, 1: all float16, 3: float16 accumulators and weight with a
+ * float32 prediction (the product then stays float32, as type promotion makes it); product and sum rounded separately, as the tensor
+ * formulation does (nnU-Net predictor, model/nnunetv2/inference/predict_from_raw_data.py:563-570,
+ * called from segmentor.py:388-488; float16 accumulators there). */
+int ldiff_window_accumulate(void* acc, void* cnt, const void* pred, const void* weight_or_null, int C, int H, int W, int th, int tw, int y0, int x0, int dtypes,
+                            void* stream);
 /* rgb [B,3,H,W] f32 -> gray [B,1,H,W] f32 = (rgb*[0.2989,0.5870,0.1140]).sum(1)  (ldiffusion.py:241-242) */
 int ldiff_luma_float(const void* rgb_nchw, void* gray, int B, int H, int W, void* stream);
 /* F.interpolate(x, size=(out_h,out_w), mode="bilinear", align_corners=False) on fp32 NCHW (ldiffusion.py:240,250: the decoded

@@ -67,6 +67,7 @@ SIGNATURES = {
     "ldiff_pndm_coeffs": (I, [F, F, C.POINTER(F), C.POINTER(F)]),
     "ldiff_laplace_add": (I, [P, F, P, U64, U64, P, I64, P]),
     "ldiff_argmax_u8": (I, [P, I, I, I, I, P, P]),
+    "ldiff_window_accumulate": (I, [P, P, P, P, I, I, I, I, I, I, I, I, P]),
     "ldiff_luma_float": (I, [P, P, I, I, I, P]),
     "ldiff_bilinear_resize": (I, [P, P, I, I, I, I, I, I, P]),
     "ldiff_pipeline_create": (I, [C.POINTER(P), P, P]),

@@ -193,6 +193,13 @@ int ldiff_argmax_u8(const void* logits, int B, int C, int H, int W, void* mask_u
   launch_argmax_u8((const float*)logits, B, C, H, W, (uint8_t*)mask_u8, (hipStream_t)stream);
   API_END
 }
+int ldiff_window_accumulate(void* acc, void* cnt, const void* pred, const void* weight_or_null, int C, int H, int W, int th, int tw, int y0, int x0, int dtypes,
+                            void* stream) {
+  API_BEGIN
+  LDIFF_CHECK(acc && cnt && pred, LDIFF_ERR_INVALID, "window_accumulate: null argument");
+  launch_window_accumulate(acc, cnt, pred, weight_or_null, C, H, W, th, tw, y0, x0, dtypes, (hipStream_t)stream);
+  API_END
+}
 int ldiff_luma_float(const void* rgb_nchw, void* gray, int B, int H, int W, void* stream) {
   API_BEGIN
   LDIFF_CHECK(rgb_nchw && gray, LDIFF_ERR_INVALID, "luma_float: null argument");

@@ -279,6 +279,36 @@ void launch_argmax_u8(const float* logits, int B, int C, int H, int W, uint8_t* 
   HIP_CHECK(hipGetLastError());
 }
 
+// ---- sliding-window / tile merge: logits[:, window] += pred * g;  n[window] += g  --------------------------------------------
+// (nnU-Net's predictor, model/nnunetv2/inference/predict_from_raw_data.py:563-570 as called from /root/reference/segmentor.py:388-488,
+// and the sampler's own tile merge of BASELINE configs[3]).  The arithmetic is the tensor formulation's, rounding for rounding: the
+// product is rounded to the storage type, then the sum (no fused multiply-add), so that float16 accumulators reproduce the reference's.
+template <typename T, typename P>
+__global__ void window_accumulate_kernel(T* __restrict__ acc, T* __restrict__ cnt, const P* __restrict__ pred, const T* __restrict__ g, int C, int H, int W,
+                                         int th, int tw, int y0, int x0) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= th * tw) return;
+  const int ty = i / tw, tx = i - ty * tw;
+  const long long o = (long long)(y0 + ty) * W + x0 + tx;
+  const float gv = g ? (float)g[i] : 1.0f;
+  for (int c = 0; c < C; ++c) {
+    const float pv = (float)pred[(long long)c * th * tw + i];
+    // the product has the promoted type of (prediction, weight): rounded to float16 only when both are float16
+    const float prod = g ? (float)(P)__fmul_rn(pv, gv) : pv;
+    acc[(long long)c * H * W + o] = (T)__fadd_rn((float)acc[(long long)c * H * W + o], prod);
+  }
+  cnt[o] = (T)__fadd_rn((float)cnt[o], gv);
+}
+void launch_window_accumulate(void* acc, void* cnt, const void* pred, const void* g, int C, int H, int W, int th, int tw, int y0, int x0, int dtypes, hipStream_t s) {
+  LDIFF_CHECK(C >= 1 && th >= 1 && tw >= 1 && y0 >= 0 && x0 >= 0 && y0 + th <= H && x0 + tw <= W, LDIFF_ERR_INVALID, "window_accumulate: the window must lie inside the image");
+  LDIFF_CHECK(dtypes == 0 || dtypes == 1 || dtypes == 3, LDIFF_ERR_INVALID, "window_accumulate: dtypes 0 (all float32), 1 (all float16) or 3 (float16 accumulators, float32 prediction)");
+  const dim3 grid(nblocks((long long)th * tw)), block(256);
+  if (dtypes == 1) hipLaunchKernelGGL((window_accumulate_kernel<f16, f16>), grid, block, 0, s, (f16*)acc, (f16*)cnt, (const f16*)pred, (const f16*)g, C, H, W, th, tw, y0, x0);
+  else if (dtypes == 3) hipLaunchKernelGGL((window_accumulate_kernel<f16, float>), grid, block, 0, s, (f16*)acc, (f16*)cnt, (const float*)pred, (const f16*)g, C, H, W, th, tw, y0, x0);
+  else hipLaunchKernelGGL((window_accumulate_kernel<float, float>), grid, block, 0, s, (float*)acc, (float*)cnt, (const float*)pred, (const float*)g, C, H, W, th, tw, y0, x0);
+  HIP_CHECK(hipGetLastError());
+}
+
 // ---- float luma of the training-time features (ldiffusion.py:241-242) ---------------------------
 __global__ void luma_float_kernel(const float* __restrict__ rgb, float* __restrict__ gray, int B, int HW) {
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;

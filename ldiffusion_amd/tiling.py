@@ -75,6 +75,25 @@ def compute_gaussian(tile_size: Sequence[int], sigma_scale: float = 1.0 / 8, val
     return g
 
 
+def _window_accumulate(acc: torch.Tensor, cnt: torch.Tensor, pred: torch.Tensor, g, y: int, x: int) -> None:
+    """acc[:, y:y+th, x:x+tw] += pred * g;  cnt[y:y+th, x:x+tw] += g  (g None: weight 1).  Device tensors: ONE launch of
+    ldiff_window_accumulate (the same two roundings per element as the tensor formulation below, which serves host tensors: the CPU tests
+    pin it to the reference's predictor)."""
+    th, tw = pred.shape[-2:]
+    if acc.is_cuda:
+        from . import _lib
+        kinds = {(torch.float32, torch.float32): 0, (torch.float16, torch.float16): 1, (torch.float16, torch.float32): 3}
+        if acc.dtype != cnt.dtype or (acc.dtype, pred.dtype) not in kinds or not (acc.is_contiguous() and cnt.is_contiguous()):
+            raise ValueError("window accumulate: contiguous float32 accumulators with a float32 prediction, or float16 ones with a float16 / float32 prediction")
+        pred = pred.contiguous()
+        gg = None if g is None else g.to(acc.dtype).contiguous()
+        _lib.check(_lib.load().ldiff_window_accumulate(_lib.ptr(acc), _lib.ptr(cnt), _lib.ptr(pred), _lib.ptr(gg), acc.shape[0], acc.shape[1], acc.shape[2],
+                                                       th, tw, int(y), int(x), kinds[(acc.dtype, pred.dtype)], _lib.stream_ptr()))
+        return
+    acc[:, y:y + th, x:x + tw] += pred * g if g is not None else pred
+    cnt[y:y + th, x:x + tw] += g if g is not None else 1
+
+
 def merge_tile_logits(tiles: torch.Tensor, origins: Sequence[Tuple[int, int]], image_hw: Tuple[int, int], use_gaussian: bool = True,
                       dtype=torch.float32) -> torch.Tensor:
     """[n, C, th, tw] logits -> [C, H, W]: `logits[sl] += pred * g; n[sl] += g; logits /= n` on the tiles' device.
@@ -88,8 +107,7 @@ def merge_tile_logits(tiles: torch.Tensor, origins: Sequence[Tuple[int, int]], i
     acc = torch.zeros((C,) + tuple(image_hw), dtype=dtype, device=tiles.device)
     cnt = torch.zeros(tuple(image_hw), dtype=dtype, device=tiles.device)
     for t, (y, x) in zip(tiles, origins):
-        acc[:, y:y + th, x:x + tw] += t * g
-        cnt[y:y + th, x:x + tw] += g
+        _window_accumulate(acc, cnt, t if (dtype == torch.float16 and t.dtype == torch.float32) else t.to(dtype), g, y, x)
     if not bool((cnt > 0).all()):
         raise RuntimeError("tiles do not cover the ROI")
     return acc / cnt
@@ -138,8 +156,7 @@ def predict_sliding_window_return_logits(image: torch.Tensor, network, num_heads
     g = compute_gaussian((th, tw), sigma_scale=1.0 / 8, value_scaling_factor=10, dtype=acc_dtype, device=data.device) if use_gaussian else None
     for y, x in tile_origins(tuple(data.shape[1:]), tile_hw, tile_step_size):
         pred = maybe_mirror_and_predict(network, data[None, :, y:y + th, x:x + tw], mirror_axes)[0]
-        logits[:, y:y + th, x:x + tw] += pred * g if use_gaussian else pred
-        n_pred[y:y + th, x:x + tw] += g if use_gaussian else 1
+        _window_accumulate(logits, n_pred, pred, g if use_gaussian else None, y, x)
     logits /= n_pred
     if bool(torch.isinf(logits).any()):
         raise RuntimeError("Encountered inf in predicted array. Aborting... If this problem persists, reduce value_scaling_factor in "

@@ -421,30 +421,37 @@ class GraphedStep:
         self.graph, self.loss = None, None
 
     def _forward_backward(self):
-        ctx = F.linear(self.hidden, self.proj[0], self.proj[1])
-        feats, _ = v5_features(self.unet, self.vae_dec, None, ctx, self.timesteps, self.abar, out_hw=self.out_hw, noisy_list=self.noisy)
-        loss = ag.InfoNceFn.apply(feats, self.bi, self.ai, self.pi, self.ni, self.temperature, self.count)
-        (loss * self.loss_scale).backward()
-        if self.loss_scale != 1.0:
-            torch._foreach_mul_([p.grad for p in self.params if p.grad is not None], 1.0 / self.loss_scale)
-        return loss.detach()
+        # The graph is built on fresh leaves that ALIAS the parameters' storage: a parameter's gradient arrives at its AccumulateGrad node on the
+        # stream that node was created on, and an autograd graph the caller still holds from an eager step keeps the old nodes (default stream)
+        # alive -- the engine would synchronise the capturing stream with the default stream inside the capture (hipStreamEndCapture crashes).
+        own = self.unet.p
+        alias = {k: (v.detach().requires_grad_(True) if v.requires_grad else v) for k, v in own.items()}
+        pw, pb = (t.detach().requires_grad_(True) for t in self.proj)
+        self.unet.p = alias
+        try:
+            ctx = F.linear(self.hidden, pw, pb)
+            feats, _ = v5_features(self.unet, self.vae_dec, None, ctx, self.timesteps, self.abar, out_hw=self.out_hw, noisy_list=self.noisy)
+            loss = ag.InfoNceFn.apply(feats, self.bi, self.ai, self.pi, self.ni, self.temperature, self.count)
+            leaves = [v for v in alias.values() if v.requires_grad] + [pw, pb]   # the order of self.params
+            grads = torch.autograd.grad(loss * self.loss_scale, leaves, allow_unused=True)
+        finally:
+            self.unet.p = own
+        live = [g for g in grads if g is not None]
+        if self.loss_scale != 1.0 and live:
+            torch._foreach_mul_(live, 1.0 / self.loss_scale)
+        return loss.detach(), list(grads)
 
     def _capture(self):
         cur = torch.cuda.current_stream()
         self.stream.wait_stream(cur)
         with torch.cuda.stream(self.stream):
             for _ in range(2):   # sizes every lazily grown buffer (library scratch, derived weight layouts, allocator pools) before the capture
-                for p in self.params:
-                    p.grad = None
                 self._forward_backward()
         cur.wait_stream(self.stream)
         torch.cuda.synchronize()
-        for p in self.params:
-            p.grad = None
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph, stream=self.stream):
-            self.loss = self._forward_backward()
-        self.grads = [p.grad for p in self.params]   # the graph's static gradient buffers
+            self.loss, self.grads = self._forward_backward()   # the graph's static loss and gradient buffers
         self.graph.replay()   # (a capture records, it does not execute)
 
     def set_batch(self, z0, text_hidden, pairs, u_list=None, seed=0, offset=0):

@@ -1,5 +1,4 @@
-mkdir -p gpurun_out/r3v; O=gpurun_out/r3v
-timeout 3000 python -m pytest tests/ -q -m gpu -x 2>&1 | tail -15 > $O/gpu_tests.txt
-timeout 600 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.txt 2>&1
-timeout 600 python scripts/bench_train.py > $O/bench_train.txt 2>&1
-tail -5 $O/gpu_tests.txt; tail -6 $O/smoke.txt; tail -8 $O/bench_train.txt
+mkdir -p gpurun_out/r4c; O=gpurun_out/r4c; rm -f $O/*.txt
+timeout 900 python -m pytest tests/test_gpu_train.py -q -m gpu -x -s -k "graphed or fixture" 2>&1 | grep -E "graphed step|infonce fixture|passed|failed|Error|error|Segm|Warning" | tail -20 > $O/t1.txt
+timeout 600 python scripts/bench_train.py --graph 2>&1 | tail -2 >> $O/t1.txt
+cat $O/t1.txt

@@ -190,3 +190,26 @@ def test_graphed_step_equals_the_eager_step():
     l0 = train.train_step_graphed(gstep, z0.to(DEV), hidden.to(DEV), [u.to(DEV) for u in u_list], pairs, state, lr=1e-4)
     l1 = train.train_step_graphed(gstep, z0.to(DEV), hidden.to(DEV), [u.to(DEV) for u in u_list], pairs, state, lr=1e-4)
     assert state["step"] == 2 and l1 < l0
+
+
+def test_contrastive_loss_kernel_at_the_reference_fixture():
+    """tests/golden/reference_infonce.npz holds losses computed by the REFERENCE's own InfoNceLoss (model/loss.py, run in the build container by
+    scripts/gen_golden_loss.py) for seeded label maps: with the same torch seed the mirror draws the same triples on the host, and the loss
+    + gradient over them come from the one-launch kernel.  Value against the reference's number, gradient against the host statement."""
+    import os
+    import numpy as np
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "reference_infonce.npz"))
+    for tag in "abc":
+        feats, labels = torch.from_numpy(z[tag + "_features"]), torch.from_numpy(z[tag + "_labels"])
+        torch.manual_seed(int(z[tag + "_seed"]))
+        triples = InfoNceLoss().sample_triples(labels)
+        ref_in = feats.double().requires_grad_(True)
+        InfoNceLoss().compute_contrastive_loss(ref_in, labels, triples=triples).backward()
+        x = feats.to(DEV).requires_grad_(True)
+        torch.manual_seed(int(z[tag + "_seed"]))
+        loss = InfoNceLoss().compute_contrastive_loss(x, labels)      # draws the triples itself (host RNG), then ldiff_op_infonce
+        loss.backward()
+        e_l = abs(loss.item() - float(z[tag + "_loss"])) / abs(float(z[tag + "_loss"]))
+        e_g = ((x.grad.cpu().double() - ref_in.grad).abs().max() / ref_in.grad.abs().max()).item()
+        print(f"[infonce fixture {tag}] {sum(len(t) for t in triples)} triples: loss {loss.item():.6f} vs the reference's {float(z[tag + '_loss']):.6f} ({e_l:.1e}); gradient {e_g:.1e}")
+        assert e_l <= 1e-5 and e_g <= 1e-5

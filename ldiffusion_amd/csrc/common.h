@@ -163,6 +163,7 @@ void launch_fold_gn_weights(const f16* w, const float* bias, const float* scale,
                             hipStream_t s);
 void launch_bilinear_resize(const float* x, float* y, int B, int C, int H, int W, int oh, int ow, hipStream_t s);
 void launch_luma_float(const float* rgb_nchw, float* gray, int B, int H, int W, hipStream_t s);
+void launch_zero_bytes(void* p, size_t bytes, hipStream_t s);   // zero fill by a kernel (capturable; see kernels_elem.hip)
 void launch_window_accumulate(void* acc, void* cnt, const void* pred, const void* g, int C, int H, int W, int th, int tw, int y0, int x0, int dtypes, hipStream_t s);
 
 // ---- backward-pass primitives of the fine-tuning step (kernels_bwd.hip) -------------------------------------

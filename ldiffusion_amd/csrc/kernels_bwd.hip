@@ -238,8 +238,8 @@ void launch_geglu_bwd(const f16* x, const f16* dy, f16* dx, long long M, int C4,
 // Lq * Lk <= 8192 scores (32 KiB of LDS).  Layout as the forward kernel: [B, L, ld] with head h at column h*d. ----
 __global__ __launch_bounds__(256) void attn_bwd_kernel(const f16* __restrict__ q, int ldq, const f16* __restrict__ k, int ldk, const f16* __restrict__ v, int ldv,
                                                        const f16* __restrict__ dO, int ldo, f16* __restrict__ dq, f16* __restrict__ dk, f16* __restrict__ dv, int Lq,
-                                                       int Lk, int d, long long q_bs, long long kv_bs, long long o_bs, float scale) {
-  extern __shared__ float sm[];   // P [Lq][Lk], dS [Lq][Lk]
+                                                       int Lk, int d, long long q_bs, long long kv_bs, long long o_bs, float scale, int staged) {
+  extern __shared__ float sm[];   // P [Lq][Lk], dS [Lq][Lk], then (staged) the operand chunks
   float* P = sm;
   float* dS = sm + Lq * Lk;
   const int b = blockIdx.y, h = blockIdx.x, tid = threadIdx.x;
@@ -247,6 +247,54 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const f16* __restrict__ q
   const f16* kb = k + b * kv_bs + h * d;
   const f16* vb = v + b * kv_bs + h * d;
   const f16* ob = dO + b * o_bs + h * d;
+  if (staged) {
+    // scores and dP with the operands staged through LDS in chunks of 64 head-dim columns (coalesced global reads, rows padded to 33 words:
+    // lanes differ in the key row).  The direct loop below walks q / k / dO / v rows with one lane per row: at d = 512 (VAE mid block,
+    // 64 x 64 scores, ONE head) that was 2.7 ms of latency-bound loads per call
+    constexpr int CH = 64, RW = CH / 2 + 1;
+    unsigned* Qs = reinterpret_cast<unsigned*>(sm + 2 * Lq * Lk);
+    unsigned* Os = Qs + Lq * RW;
+    unsigned* Ks = Os + Lq * RW;
+    unsigned* Vs = Ks + Lk * RW;
+    float sacc[32], dacc[32];
+#pragma unroll
+    for (int r = 0; r < 32; ++r) { sacc[r] = 0.f; dacc[r] = 0.f; }
+    for (int c0 = 0; c0 < d; c0 += CH) {
+      const int cw2 = min(CH, d - c0) >> 1;
+      for (int e = tid; e < Lq * cw2; e += 256) {
+        const int row = e / cw2, cc = e - row * cw2;
+        Qs[row * RW + cc] = *reinterpret_cast<const unsigned*>(qb + (long long)row * ldq + c0 + 2 * cc);
+        Os[row * RW + cc] = *reinterpret_cast<const unsigned*>(ob + (long long)row * ldo + c0 + 2 * cc);
+      }
+      for (int e = tid; e < Lk * cw2; e += 256) {
+        const int row = e / cw2, cc = e - row * cw2;
+        Ks[row * RW + cc] = *reinterpret_cast<const unsigned*>(kb + (long long)row * ldk + c0 + 2 * cc);
+        Vs[row * RW + cc] = *reinterpret_cast<const unsigned*>(vb + (long long)row * ldv + c0 + 2 * cc);
+      }
+      __syncthreads();
+#pragma unroll
+      for (int r = 0; r < 32; ++r) {
+        const int i = tid + 256 * r;
+        if (i < Lq * Lk) {
+          const int iq = i / Lk, ik = i - iq * Lk;
+          float a = 0.f, b2 = 0.f;
+          for (int cc = 0; cc < cw2; ++cc) {
+            const f16x2 q2 = __builtin_bit_cast(f16x2, Qs[iq * RW + cc]), k2 = __builtin_bit_cast(f16x2, Ks[ik * RW + cc]);
+            const f16x2 o2 = __builtin_bit_cast(f16x2, Os[iq * RW + cc]), v2 = __builtin_bit_cast(f16x2, Vs[ik * RW + cc]);
+            a += (float)q2[0] * (float)k2[0] + (float)q2[1] * (float)k2[1];
+            b2 += (float)o2[0] * (float)v2[0] + (float)o2[1] * (float)v2[1];
+          }
+          sacc[r] += a; dacc[r] += b2;
+        }
+      }
+      __syncthreads();
+    }
+#pragma unroll
+    for (int r = 0; r < 32; ++r) {
+      const int i = tid + 256 * r;
+      if (i < Lq * Lk) { P[i] = sacc[r] * scale; dS[i] = dacc[r]; }
+    }
+  } else
   for (int i = tid; i < Lq * Lk; i += 256) {   // scores and dP
     const int iq = i / Lk, ik = i - iq * Lk;
     float s = 0.f, dp = 0.f;
@@ -289,49 +337,90 @@ void launch_attn_bwd(const AttnParams& p, const f16* dO, f16* dq, f16* dk, f16* 
   LDIFF_CHECK((long long)p.Lq * p.Lk <= 8192, LDIFF_ERR_INVALID, "attn_bwd: Lq*Lk = %d*%d exceeds the 8192 scores of the short-sequence kernel", p.Lq, p.Lk);
   LDIFF_CHECK(p.kv_bstride != 0 || p.B == 1, LDIFF_ERR_INVALID, "attn_bwd: broadcast K/V need their gradients summed over the batch by the caller (pass expanded K/V)");
   if (p.B == 0) return;
-  const size_t smem = (size_t)2 * p.Lq * p.Lk * sizeof(float);
+  size_t smem = (size_t)2 * p.Lq * p.Lk * sizeof(float);
+  const size_t stage = (size_t)2 * (p.Lq + p.Lk) * 33 * sizeof(unsigned);
+  const int staged = (smem + stage <= 150 * 1024 && p.d % 2 == 0 && p.ldq % 2 == 0 && p.ldk % 2 == 0 && p.ldv % 2 == 0 && p.ldo % 2 == 0) ? 1 : 0;
+  if (staged) smem += stage;
   ensure_dyn_smem(reinterpret_cast<const void*>(attn_bwd_kernel), (int)smem);
   hipLaunchKernelGGL(attn_bwd_kernel, dim3(p.heads, p.B), dim3(256), smem, s, p.q, p.ldq, p.k, p.ldk, p.v, p.ldv, dO, p.ldo, dq, dk, dv, p.Lq, p.Lk, p.d,
-                     p.q_bstride, p.kv_bstride, p.o_bstride, p.scale);
+                     p.q_bstride, p.kv_bstride, p.o_bstride, p.scale, staged);
   HIP_CHECK(hipGetLastError());
 }
 
 // ---- weight layouts of the training step in one pass each (the torch formulation was zeros + permute + cast + slice-assign per call) ----
 // mode 0 (forward):  dst[n][ky][kx][c] = w[n][c][ky][kx]            dst rows R >= Cout, row length k*k*Cp, Cp >= Cin; zero elsewhere
 // mode 1 (dgrad):    dst[c][ky][kx][n] = w[n][c][k-1-ky][k-1-kx]    dst rows R >= Cin,  row length k*k*Cp, Cp >= Cout; zero elsewhere
-__global__ void pack_weight_kernel(const float* __restrict__ w, f16* __restrict__ dst, int Cout, int Cin, int k, int R, int Cp, int mode) {
-  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  const long long total = (long long)R * k * k * Cp;
-  if (i >= total) return;
-  const int c = (int)(i % Cp);
-  const int tap = (int)((i / Cp) % (k * k));
-  const int r = (int)(i / ((long long)Cp * k * k));
-  const int ky = tap / k, kx = tap % k;
-  float v = 0.f;
-  if (mode == 0) { if (r < Cout && c < Cin) v = w[(((long long)r * Cin + c) * k + ky) * k + kx]; }
-  else { if (r < Cin && c < Cout) v = w[(((long long)c * Cin + r) * k + (k - 1 - ky)) * k + (k - 1 - kx)]; }
-  dst[i] = (f16)v;
+// Both are transposes of a matrix whose rows are far apart in memory; they go through LDS so that every global access is a contiguous
+// run (the one-thread-per-destination formulation read the fp32 master with a stride of 36 B (forward) or Cin * 36 B (dgrad) between
+// lanes: 10.5 ms per step for 860 M parameters whose traffic takes 2 ms).
+constexpr int PW_CT = 256;   // forward: channels per workgroup (one output row n)
+__global__ __launch_bounds__(256) void pack_weight_fwd_kernel(const float* __restrict__ w, f16* __restrict__ dst, int Cout, int Cin, int kk, int Cp) {
+  __shared__ float t[PW_CT * 9];
+  const int r = blockIdx.y, c0 = blockIdx.x * PW_CT, tid = threadIdx.x;
+  const int nc = min(PW_CT, Cp - c0);   // destination columns of this chunk
+  const int ncs = r < Cout ? max(0, min(PW_CT, Cin - c0)) : 0;   // of which exist in the source
+  const float* src = w + ((long long)r * Cin + c0) * kk;
+  for (int e = tid; e < nc * kk; e += 256) t[e] = e < ncs * kk ? src[e] : 0.f;   // [c][tap], contiguous in memory
+  __syncthreads();
+  f16* d = dst + (long long)r * kk * Cp + c0;
+  for (int e = tid; e < nc * kk; e += 256) {
+    const int tap = e / nc, cc = e - tap * nc;
+    d[(long long)tap * Cp + cc] = (f16)t[cc * kk + tap];   // (stride kk = 1 or 9 between lanes: odd, conflict-free)
+  }
+}
+template <int KK, int TC>   // dgrad: a tile of 64 output channels n x TC input channels c x KK taps
+__global__ __launch_bounds__(256) void pack_weight_dgrad_kernel(const float* __restrict__ w, f16* __restrict__ dst, int Cout, int Cin, int R, int Cp) {
+  constexpr int ROW = TC * KK + 1;
+  __shared__ float t[64 * ROW];
+  const int n0 = blockIdx.x * 64, c0 = blockIdx.y * TC, tid = threadIdx.x;
+  for (int e = tid; e < 64 * TC * KK; e += 256) {
+    const int nl = e / (TC * KK), off = e - nl * (TC * KK);
+    const int n = n0 + nl, c = c0 + off / KK;
+    t[nl * ROW + off] = (n < Cout && c < Cin) ? w[((long long)n * Cin + c0) * KK + off] : 0.f;   // per n: TC * KK contiguous floats
+  }
+  __syncthreads();
+  for (int e = tid; e < TC * KK * 64; e += 256) {
+    const int nl = e & 63, ct = e >> 6;            // ct = cc * KK + tap' (destination order)
+    const int cc = ct / KK, tap = ct - cc * KK;
+    const int c = c0 + cc, n = n0 + nl;
+    if (c < R && n < Cp) dst[((long long)c * KK + tap) * Cp + n] = (f16)t[nl * ROW + cc * KK + (KK - 1 - tap)];   // taps flipped: (k-1-ky, k-1-kx) = KK-1-tap
+  }
 }
 void launch_pack_weight(const float* w, f16* dst, int Cout, int Cin, int k, int R, int Cp, int mode, hipStream_t s) {
   const long long total = (long long)R * k * k * Cp;
   if (total == 0) return;
-  hipLaunchKernelGGL(pack_weight_kernel, dim3(nblk(total)), dim3(256), 0, s, w, dst, Cout, Cin, k, R, Cp, mode);
+  LDIFF_CHECK(k == 1 || k == 3, LDIFF_ERR_INVALID, "pack_weight: kernel size %d (1 or 3)", k);
+  if (mode == 0) {
+    hipLaunchKernelGGL(pack_weight_fwd_kernel, dim3((Cp + PW_CT - 1) / PW_CT, R), dim3(256), 0, s, w, dst, Cout, Cin, k * k, Cp);
+  } else if (k == 3) {
+    hipLaunchKernelGGL((pack_weight_dgrad_kernel<9, 16>), dim3((Cp + 63) / 64, (R + 15) / 16), dim3(256), 0, s, w, dst, Cout, Cin, R, Cp);
+  } else {
+    hipLaunchKernelGGL((pack_weight_dgrad_kernel<1, 64>), dim3((Cp + 63) / 64, (R + 63) / 64), dim3(256), 0, s, w, dst, Cout, Cin, R, Cp);
+  }
   HIP_CHECK(hipGetLastError());
 }
-// wgrad GEMM output g[n][tap*Cx + c] (row pitch ldg) -> dw[n][c][ky][kx] in the parameter's own layout
-__global__ void unpack_wgrad_kernel(const float* __restrict__ g, float* __restrict__ dw, int Cout, int Cin, int k, int Cx, int ldg) {
-  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  const long long total = (long long)Cout * Cin * k * k;
-  if (i >= total) return;
-  const int tap = (int)(i % (k * k));
-  const int c = (int)((i / (k * k)) % Cin);
-  const int n = (int)(i / ((long long)k * k * Cin));
-  dw[i] = g[(long long)n * ldg + (long long)tap * Cx + c];
+// wgrad GEMM output g[n][tap*Cx + c] (row pitch ldg) -> dw[n][c][ky][kx] in the parameter's own layout (the inverse transpose, per row n)
+__global__ __launch_bounds__(256) void unpack_wgrad_kernel(const float* __restrict__ g, float* __restrict__ dw, int Cin, int kk, int Cx, int ldg) {
+  __shared__ float t[9 * (PW_CT + 1)];
+  const int n = blockIdx.y, c0 = blockIdx.x * PW_CT, tid = threadIdx.x;
+  const int nc = min(PW_CT, Cin - c0);
+  const float* src = g + (long long)n * ldg + c0;
+  for (int e = tid; e < nc * kk; e += 256) {
+    const int tap = e / nc, cc = e - tap * nc;
+    t[tap * (PW_CT + 1) + cc] = src[(long long)tap * Cx + cc];
+  }
+  __syncthreads();
+  float* d = dw + ((long long)n * Cin + c0) * kk;
+  for (int e = tid; e < nc * kk; e += 256) {
+    const int cc = e / kk, tap = e - cc * kk;
+    d[e] = t[tap * (PW_CT + 1) + cc];
+  }
 }
 void launch_unpack_wgrad(const float* g, float* dw, int Cout, int Cin, int k, int Cx, int ldg, hipStream_t s) {
   const long long total = (long long)Cout * Cin * k * k;
   if (total == 0) return;
-  hipLaunchKernelGGL(unpack_wgrad_kernel, dim3(nblk(total)), dim3(256), 0, s, g, dw, Cout, Cin, k, Cx, ldg);
+  LDIFF_CHECK(k == 1 || k == 3, LDIFF_ERR_INVALID, "unpack_wgrad: kernel size %d (1 or 3)", k);
+  hipLaunchKernelGGL(unpack_wgrad_kernel, dim3((Cin + PW_CT - 1) / PW_CT, Cout), dim3(256), 0, s, g, dw, Cin, k * k, Cx, ldg);
   HIP_CHECK(hipGetLastError());
 }
 
@@ -450,8 +539,9 @@ __global__ __launch_bounds__(256) void infonce_kernel(const float* __restrict__ 
 void launch_infonce(const float* feat, int B, int n, long long HW, const int* bi, const int* ai, const int* pi, const int* ni, int T, const int* t_dev, int K,
                     float temperature, float* loss, float* dfeat, hipStream_t s) {
   LDIFF_CHECK(n >= 1 && n <= 32 && K >= 1 && K <= 8192 && temperature > 0.f, LDIFF_ERR_INVALID, "infonce: 1..32 feature planes, 1..8192 negatives");
-  HIP_CHECK(hipMemsetAsync(loss, 0, sizeof(float), s));
-  HIP_CHECK(hipMemsetAsync(dfeat, 0, (size_t)B * n * HW * sizeof(float), s));
+  // (zeroed by a kernel, not hipMemsetAsync: launch_zero_bytes, kernels_elem.hip)
+  launch_zero_bytes(dfeat, (size_t)B * n * HW * sizeof(float), s);
+  launch_zero_bytes(loss, sizeof(float), s);
   if (T == 0) return;
   const size_t smem = (size_t)(K + 1 + 8 + n) * sizeof(float);
   hipLaunchKernelGGL(infonce_kernel, dim3(T), dim3(256), smem, s, feat, n, HW, bi, ai, pi, ni, T, t_dev, K, 1.0f / temperature, loss, dfeat);

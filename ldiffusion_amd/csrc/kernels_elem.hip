@@ -254,6 +254,19 @@ void launch_decode_post(const float* x, int ldx, int B, int H, int W, float* img
   HIP_CHECK(hipGetLastError());
 }
 
+// ---- zero fill as a KERNEL: hipMemsetAsync nodes inside a captured graph were not ordered with the kernels behind them on this runtime
+// (seen in train.GraphedStep: garbage on every second of two back-to-back replays), so nothing that may be captured uses memset ----
+__global__ void zero_bytes_kernel(unsigned* __restrict__ p, long long words) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < words) p[i] = 0u;
+}
+void launch_zero_bytes(void* p, size_t bytes, hipStream_t s) {
+  LDIFF_CHECK(bytes % 4 == 0 && ((size_t)p & 3) == 0, LDIFF_ERR_INVALID, "zero fill: 4-byte granularity");
+  if (bytes == 0) return;
+  hipLaunchKernelGGL(zero_bytes_kernel, dim3(nblocks((long long)(bytes / 4))), dim3(256), 0, s, (unsigned*)p, (long long)(bytes / 4));
+  HIP_CHECK(hipGetLastError());
+}
+
 // ---- mask tail: argmax over classes (segmentor.py:536; softmax is monotone) ----------------------
 __global__ void argmax_u8_kernel(const float* __restrict__ logits, int B, int C, int HW, uint8_t* __restrict__ mask) {
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;

@@ -370,7 +370,7 @@ Act Exec::conv(const MatW& w, const Act& x, const Act* x2, const ConvOpts& o) {
   } else {
     const int C = o.ldy ? o.ldy : (o.split_out ? roundup(p.N, 4) : roundup(p.N, 8));
     y = new_act(x.B, p.Hout, p.Wout, C, o.split_out);
-    if (C > p.N) HIP_CHECK(hipMemsetAsync(y.p, 0, y.bytes(), s));  // zero the pad columns
+    if (C > p.N) launch_zero_bytes(y.p, y.bytes(), s);  // zero the pad columns (a kernel: the forward may be inside a captured graph)
     p.y = y.p; p.ldy = y.ld(); p.y_lo = y.lo();
     if (o.ups && conv3x3_eligible(p))   // nearest-2x upsample folded algebraically (4 parity convs with pre-summed taps)
       p.w_par = derived_par(w, wsrc, Cin_eff, o.split_in ? w.dup_par : w.par);

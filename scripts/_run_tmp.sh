@@ -1,5 +1,8 @@
-mkdir -p gpurun_out/r4i; O=gpurun_out/r4i; rm -f $O/*.txt
-timeout 900 python scripts/debug_graph.py tiny 1 2 --poison 2>&1 | grep -v amdgpu | grep -E "replay|Error" | cut -c1-200 >> $O/t1.txt
-timeout 900 python scripts/debug_graph.py tiny 3 2 --keep-eager --check 2>&1 | grep -v amdgpu | grep -E "   loss|Error" | cut -c1-120 >> $O/t1.txt
-timeout 600 python -m pytest tests/test_gpu_train.py -q -m gpu -x -s -k "graphed or contrastive" 2>&1 | grep -E "graphed|AdamW|passed|failed" | tail -6 >> $O/t1.txt
-cat $O/t1.txt
+mkdir -p gpurun_out/r4l; O=gpurun_out/r4l; rm -f $O/*
+for rep in 1 2; do for r in 2 3 4; do
+  LDIFF_C3D_RUN=$r timeout 400 python bench.py --steps 6 --warmup 2 --no-cpu-baseline > $O/run_${r}_$rep.json 2> $O/err.txt
+  python3 -c "
+import json
+d=json.loads(open('$O/run_${r}_$rep.json').read().strip().splitlines()[-1])
+print('run $r', round(d['value'],2), round(d['ms_per_step'],2), round(d['roofline']['frac'],3), round(d['roofline']['serial']['frac'],3))"
+done; done

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define LDIFF_VERSION 130 /* 0.1.3: + ldiff_op_infonce, ldiff_window_accumulate; dataflow conv3x3 kernel behind ldiff_op_conv */
+#define LDIFF_VERSION 130 /* 0.1.3: + ldiff_op_infonce, ldiff_window_accumulate, ldiff_op_pack_weight_multi; dataflow conv3x3 kernel behind ldiff_op_conv */
 #define LDIFF_MAX_BLOCKS 8
 
 typedef enum { LDIFF_OK = 0, LDIFF_ERR_INVALID = -1, LDIFF_ERR_RUNTIME = -2, LDIFF_ERR_STATE = -3 } ldiff_status;
@@ -271,6 +271,11 @@ int ldiff_op_infonce(const void* features, int B, int n, int64_t HW, const void*
  * and back: the wgrad GEMM's g[n][tap*Cx + c] (row pitch ldg) -> dw[n][c][ky][kx] (loss.backward() of /root/reference/ldiffusion.py:254). */
 int ldiff_op_pack_weight(const void* w_f32, void* dst_f16, int Cout, int Cin, int k, int rows, int Cpad, int mode, void* stream);
 int ldiff_op_unpack_wgrad(const void* g_f32, void* dw_f32, int Cout, int Cin, int k, int Cx, int ldg, void* stream);
+/* ldiff_op_pack_weight for MANY (tensor, layout) pairs in one launch.  entries: device array of n_entries records of 48 bytes
+ *   { const float* w; _Float16* dst; int32 Cout, Cin, kk (= k*k: 1 or 9), rows, Cpad, mode, tiles_x, 0 }
+ * tile_prefix: device int32 [n_entries + 1], tile_prefix[e] = first workgroup of entry e, tile_prefix[n_entries] = n_tiles.  Tiles per entry:
+ *   mode 0: tiles_x = ceil(Cpad / 256) times (kk == 1 ? ceil(rows / 8) : rows);  mode 1: tiles_x = ceil(Cpad / 64) times ceil(rows / (kk == 1 ? 64 : 16)). */
+int ldiff_op_pack_weight_multi(const void* entries, const void* tile_prefix, int n_entries, int n_tiles, void* stream);
 
 /* All parameters of a model in one launch (the reference's optimiser step, /root/reference/ldiffusion.py:168-171,255: engine.step()).
  * Device tables: tensors[t] = {float* p, float* m, float* v, int64 n} (32 bytes), grads[t] = const float* (gradient of tensor t),

@@ -98,6 +98,7 @@ SIGNATURES = {
     "ldiff_op_adamw": (I, [P, P, P, P, I64, F, F, F, F, F, I, P]),
     "ldiff_op_pack_weight": (I, [P, P, I, I, I, I, I, I, P]),
     "ldiff_op_unpack_wgrad": (I, [P, P, I, I, I, I, I, P]),
+    "ldiff_op_pack_weight_multi": (I, [P, P, I, I, P]),
     "ldiff_op_adamw_multi": (I, [P, P, P, I64, F, F, F, F, F, I, P]),
     "ldiff_op_infonce": (I, [P, I, I, I64, P, P, P, P, I, P, I, F, P, P, P]),
     "ldiff_prof_enable": (I, [I]),

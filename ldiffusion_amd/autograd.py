@@ -32,24 +32,104 @@ def _check_act(x, what):
         raise ValueError(f"{what} must be a contiguous float16 CUDA tensor")
 
 
+_PACK_CACHE: dict | None = None   # (weight data_ptr, dgrad) -> packed tensor, while a PackPlan is active (train.GraphedStep)
+
+
+def _pack_dims(Cout, Cin, dgrad, cols=None):
+    if dgrad:
+        return _r(_r(Cin, 8), 16), (cols if cols is not None else _r(Cout, 8))
+    return _r(Cout, 16), _r(Cin, 8)
+
+
 def pack_weight(w: torch.Tensor, dgrad: bool = False, cols: int | None = None) -> torch.Tensor:
     """[Cout, Cin, k, k] (or [out, in]) float32 -> the kernel layout, float16, one launch (ldiff_op_pack_weight):
     forward  [roundup(Cout,16)][k*k*roundup(Cin,8)]        rows >= Cout zero;
-    dgrad    [roundup(cols_x,16)][k*k*cols]  = the weights rearranged to [Cin][k][k][Cout] with the taps flipped (`cols` = channels of dy)."""
+    dgrad    [roundup(cols_x,16)][k*k*cols]  = the weights rearranged to [Cin][k][k][Cout] with the taps flipped (`cols` = channels of dy).
+    While a PackPlan is active, the layouts it has already produced for this storage are returned instead."""
     lib = _lib.load()
     w = w.detach()
     if w.dim() == 2:
         w = w[:, :, None, None]
+    if _PACK_CACHE is not None:
+        hit = _PACK_CACHE.get((w.data_ptr(), bool(dgrad)))
+        if hit is not None and (not dgrad or cols is None or hit.shape[1] == w.shape[2] * w.shape[3] * cols):
+            return hit
     if not (w.is_cuda and w.dtype == torch.float32 and w.is_contiguous()):
         w = w.float().contiguous()
     Cout, Cin, k, _ = w.shape
-    if dgrad:
-        rows, cp = _r(_r(Cin, 8), 16), (cols if cols is not None else _r(Cout, 8))
-    else:
-        rows, cp = _r(Cout, 16), _r(Cin, 8)
+    rows, cp = _pack_dims(Cout, Cin, dgrad, cols)
     out = torch.empty((rows, k * k * cp), dtype=torch.float16, device=w.device)
     _lib.check(lib.ldiff_op_pack_weight(w.data_ptr(), out.data_ptr(), Cout, Cin, k, rows, cp, int(dgrad), _sp()))
     return out
+
+
+class PackPlan:
+    """Forward and dgrad layouts of MANY conv / linear weights ([Cout, Cin, k, k] or [out, in], contiguous float32 CUDA) in ONE launch
+    (ldiff_op_pack_weight_multi) into persistent float16 buffers; `run()` refreshes them from the current master values, `cache()` is the
+    (data_ptr, dgrad) -> packed tensor map `pack_weight` consults while the plan is active (`with plan:`)."""
+
+    def __init__(self, weights):
+        import numpy as np
+        ws = [w for w in weights if w.dim() in (2, 4)]
+        if not ws:
+            raise ValueError("PackPlan: no weights")
+        dev = ws[0].device
+        metas, total = [], 0
+        for w in ws:
+            if not (w.is_cuda and w.dtype == torch.float32 and w.is_contiguous()):
+                raise ValueError("PackPlan: weights must be contiguous float32 CUDA tensors")
+            Cout, Cin = w.shape[0], w.shape[1]
+            k = w.shape[2] if w.dim() == 4 else 1
+            if k not in (1, 3):
+                raise ValueError("PackPlan: kernel size 1 or 3")
+            for dgrad in (False, True):
+                rows, cp = _pack_dims(Cout, Cin, dgrad)
+                metas.append((w, dgrad, Cout, Cin, k * k, rows, cp, total))
+                total += rows * k * k * cp
+        self.flat = torch.empty(total, dtype=torch.float16, device=dev)
+        self._cache, rec, prefix, tiles = {}, [], [0], 0
+        for w, dgrad, Cout, Cin, kk, rows, cp, off in metas:
+            view = self.flat[off:off + rows * kk * cp].view(rows, kk * cp)
+            self._cache[(w.data_ptr(), dgrad)] = view
+            if dgrad:
+                tx, ty = -(-cp // 64), -(-rows // (64 if kk == 1 else 16))
+            else:
+                tx, ty = -(-cp // 256), (-(-rows // 8) if kk == 1 else rows)
+            rec.append((w.data_ptr(), view.data_ptr(), Cout, Cin, kk, rows, cp, int(dgrad), tx, 0))
+            tiles += tx * ty
+            prefix.append(tiles)
+        arr = np.zeros(len(rec), dtype=np.dtype([("w", "<u8"), ("dst", "<u8"), ("i", "<i4", (8,))]))
+        for j, r in enumerate(rec):
+            arr[j] = (r[0], r[1], r[2:])
+        self.entries = torch.from_numpy(arr.view(np.uint8).reshape(-1).copy()).to(dev)
+        self.prefix = torch.tensor(prefix, dtype=torch.int32).to(dev)
+        self.n_entries, self.n_tiles = len(rec), tiles
+        self._keep = ws
+
+    def run(self):
+        _lib.check(_lib.load().ldiff_op_pack_weight_multi(self.entries.data_ptr(), self.prefix.data_ptr(), self.n_entries, self.n_tiles, _sp()))
+
+    def cache(self):
+        return self._cache
+
+
+class packed_weights:
+    """`with packed_weights(plan_a, plan_b, ...):` -- pack_weight returns the plans' layouts for the storages they cover."""
+
+    def __init__(self, *plans):
+        self.map = {}
+        for p in plans:
+            self.map.update(p.cache())
+
+    def __enter__(self):
+        global _PACK_CACHE
+        self.prev, _PACK_CACHE = _PACK_CACHE, self.map
+        return self
+
+    def __exit__(self, *exc):
+        global _PACK_CACHE
+        _PACK_CACHE = self.prev
+        return False
 
 
 def _conv_call(x, w16, Cout, k, stride, ups, bias=None, Ho=None, Wo=None, out_f32=False, pad=None):

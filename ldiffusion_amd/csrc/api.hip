@@ -579,8 +579,14 @@ int ldiff_op_infonce(const void* features, int B, int n, int64_t HW, const void*
 int ldiff_op_pack_weight(const void* w_f32, void* dst_f16, int Cout, int Cin, int k, int rows, int Cpad, int mode, void* stream) {
   API_BEGIN
   LDIFF_CHECK(w_f32 && dst_f16 && Cout >= 1 && Cin >= 1 && (k == 1 || k == 3) && (mode == 0 || mode == 1) && rows >= (mode ? Cin : Cout) &&
-                  Cpad >= (mode ? Cout : Cin), LDIFF_ERR_INVALID, "op_pack_weight: bad arguments");
+                  Cpad >= (mode ? Cout : Cin) && Cpad % 2 == 0, LDIFF_ERR_INVALID, "op_pack_weight: bad arguments (Cpad must be even and cover the channels)");
   launch_pack_weight((const float*)w_f32, (f16*)dst_f16, Cout, Cin, k, rows, Cpad, mode, (hipStream_t)stream);
+  API_END
+}
+int ldiff_op_pack_weight_multi(const void* entries, const void* tile_prefix, int n_entries, int n_tiles, void* stream) {
+  API_BEGIN
+  LDIFF_CHECK(n_entries >= 0 && n_tiles >= 0 && (n_entries == 0 || (entries && tile_prefix)), LDIFF_ERR_INVALID, "op_pack_weight_multi: bad arguments");
+  launch_pack_weight_multi((const PackEntry*)entries, (const int*)tile_prefix, n_entries, n_tiles, (hipStream_t)stream);
   API_END
 }
 int ldiff_op_unpack_wgrad(const void* g_f32, void* dw_f32, int Cout, int Cin, int k, int Cx, int ldg, void* stream) {

@@ -181,6 +181,9 @@ void launch_pack_weight(const float* w, f16* dst, int Cout, int Cin, int k, int 
 void launch_unpack_wgrad(const float* g, float* dw, int Cout, int Cin, int k, int Cx, int ldg, hipStream_t s);
 // multi-tensor AdamW (kernels_bwd.hip): device tables built by the host side (ldiffusion_amd/autograd.py)
 #define ADAMW_CHUNK 16384
+// one (weight tensor, layout) of ldiff_op_pack_weight_multi: mode 0 forward / 1 dgrad (kernels_bwd.hip), tiles_x = workgroup tiles per row of tiles
+struct PackEntry { const float* w; f16* dst; int Cout, Cin, kk, R, Cp, mode, tiles_x, pad; };
+void launch_pack_weight_multi(const PackEntry* entries, const int* tile_prefix, int n_entries, int n_tiles, hipStream_t s);
 struct AdamTensor { float* p; float* m; float* v; long long n; };
 struct AdamChunk { int tensor; int pad; long long first; };
 void launch_adamw_multi(const AdamTensor* tensors, const float* const* grads, const AdamChunk* chunks, long long nchunks, float lr, float b1, float b2, float eps,

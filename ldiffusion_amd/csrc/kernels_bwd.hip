@@ -353,50 +353,92 @@ void launch_attn_bwd(const AttnParams& p, const f16* dO, f16* dq, f16* dk, f16* 
 // Both are transposes of a matrix whose rows are far apart in memory; they go through LDS so that every global access is a contiguous
 // run (the one-thread-per-destination formulation read the fp32 master with a stride of 36 B (forward) or Cin * 36 B (dgrad) between
 // lanes: 10.5 ms per step for 860 M parameters whose traffic takes 2 ms).
-constexpr int PW_CT = 256;   // forward: channels per workgroup (one output row n)
-__global__ __launch_bounds__(256) void pack_weight_fwd_kernel(const float* __restrict__ w, f16* __restrict__ dst, int Cout, int Cin, int kk, int Cp) {
-  __shared__ float t[PW_CT * 9];
-  const int r = blockIdx.y, c0 = blockIdx.x * PW_CT, tid = threadIdx.x;
+constexpr int PW_CT = 256;   // forward: channels per workgroup tile; rows per tile: 1 (3x3) or 8 (1x1), i.e. <= 2304 elements
+__device__ __forceinline__ void pack_fwd_tile(float* t, const float* __restrict__ w, f16* __restrict__ dst, int Cout, int Cin, int kk, int R, int Cp, int bx, int by) {
+  const int rb = kk == 1 ? 8 : 1;
+  const int r0 = by * rb, c0 = bx * PW_CT, tid = threadIdx.x;
   const int nc = min(PW_CT, Cp - c0);   // destination columns of this chunk
-  const int ncs = r < Cout ? max(0, min(PW_CT, Cin - c0)) : 0;   // of which exist in the source
-  const float* src = w + ((long long)r * Cin + c0) * kk;
-  for (int e = tid; e < nc * kk; e += 256) t[e] = e < ncs * kk ? src[e] : 0.f;   // [c][tap], contiguous in memory
+  for (int rr = 0; rr < rb; ++rr) {
+    const int r = r0 + rr;
+    if (r >= R) break;
+    const int ncs = r < Cout ? max(0, min(PW_CT, Cin - c0)) : 0;   // of which exist in the source
+    const float* src = w + ((long long)r * Cin + c0) * kk;
+    float* tr = t + rr * PW_CT;   // (rb > 1 only with kk == 1)
+    for (int e = tid; e < nc * kk; e += 256) tr[e] = e < ncs * kk ? src[e] : 0.f;   // [c][tap], contiguous in memory
+  }
   __syncthreads();
-  f16* d = dst + (long long)r * kk * Cp + c0;
-  for (int e = tid; e < nc * kk; e += 256) {
-    const int tap = e / nc, cc = e - tap * nc;
-    d[(long long)tap * Cp + cc] = (f16)t[cc * kk + tap];   // (stride kk = 1 or 9 between lanes: odd, conflict-free)
+  for (int rr = 0; rr < rb; ++rr) {
+    const int r = r0 + rr;
+    if (r >= R) break;
+    const float* tr = t + rr * PW_CT;
+    f16* d = dst + (long long)r * kk * Cp + c0;
+    for (int tap = 0; tap < kk; ++tap)   // two channels per lane: 4-byte stores (Cp and c0 are even)
+      for (int cc = 2 * tid; cc < nc; cc += 512) {
+        const f16x2 v = {(f16)tr[cc * kk + tap], (f16)tr[(cc + 1) * kk + tap]};
+        *reinterpret_cast<f16x2*>(d + (long long)tap * Cp + cc) = v;
+      }
   }
 }
 template <int KK, int TC>   // dgrad: a tile of 64 output channels n x TC input channels c x KK taps
-__global__ __launch_bounds__(256) void pack_weight_dgrad_kernel(const float* __restrict__ w, f16* __restrict__ dst, int Cout, int Cin, int R, int Cp) {
+__device__ __forceinline__ void pack_dgrad_tile(float* t, const float* __restrict__ w, f16* __restrict__ dst, int Cout, int Cin, int R, int Cp, int bx, int by) {
   constexpr int ROW = TC * KK + 1;
-  __shared__ float t[64 * ROW];
-  const int n0 = blockIdx.x * 64, c0 = blockIdx.y * TC, tid = threadIdx.x;
+  const int n0 = bx * 64, c0 = by * TC, tid = threadIdx.x;
   for (int e = tid; e < 64 * TC * KK; e += 256) {
     const int nl = e / (TC * KK), off = e - nl * (TC * KK);
     const int n = n0 + nl, c = c0 + off / KK;
     t[nl * ROW + off] = (n < Cout && c < Cin) ? w[((long long)n * Cin + c0) * KK + off] : 0.f;   // per n: TC * KK contiguous floats
   }
   __syncthreads();
-  for (int e = tid; e < TC * KK * 64; e += 256) {
-    const int nl = e & 63, ct = e >> 6;            // ct = cc * KK + tap' (destination order)
+  for (int e = tid; e < TC * KK * 32; e += 256) {   // two output channels per lane: 4-byte stores (Cp and n0 are even)
+    const int nl = (e & 31) * 2, ct = e >> 5;      // ct = cc * KK + tap' (destination order)
     const int cc = ct / KK, tap = ct - cc * KK;
     const int c = c0 + cc, n = n0 + nl;
-    if (c < R && n < Cp) dst[((long long)c * KK + tap) * Cp + n] = (f16)t[nl * ROW + cc * KK + (KK - 1 - tap)];   // taps flipped: (k-1-ky, k-1-kx) = KK-1-tap
+    if (c < R && n < Cp) {
+      const int src = cc * KK + (KK - 1 - tap);    // taps flipped: (k-1-ky, k-1-kx) = KK-1-tap
+      const f16x2 v = {(f16)t[nl * ROW + src], (f16)t[(nl + 1) * ROW + src]};
+      *reinterpret_cast<f16x2*>(dst + ((long long)c * KK + tap) * Cp + n) = v;
+    }
   }
+}
+constexpr int PW_LDS = 64 * (16 * 9 + 1);   // floats: the largest tile (dgrad 3x3); forward tiles use 2304, dgrad 1x1 64 * 65
+__global__ __launch_bounds__(256) void pack_weight_fwd_kernel(const float* __restrict__ w, f16* __restrict__ dst, int Cout, int Cin, int kk, int R, int Cp) {
+  __shared__ float t[PW_CT * 9];
+  pack_fwd_tile(t, w, dst, Cout, Cin, kk, R, Cp, blockIdx.x, blockIdx.y);
+}
+template <int KK, int TC>
+__global__ __launch_bounds__(256) void pack_weight_dgrad_kernel(const float* __restrict__ w, f16* __restrict__ dst, int Cout, int Cin, int R, int Cp) {
+  __shared__ float t[64 * (TC * KK + 1)];
+  pack_dgrad_tile<KK, TC>(t, w, dst, Cout, Cin, R, Cp, blockIdx.x, blockIdx.y);
 }
 void launch_pack_weight(const float* w, f16* dst, int Cout, int Cin, int k, int R, int Cp, int mode, hipStream_t s) {
   const long long total = (long long)R * k * k * Cp;
   if (total == 0) return;
   LDIFF_CHECK(k == 1 || k == 3, LDIFF_ERR_INVALID, "pack_weight: kernel size %d (1 or 3)", k);
   if (mode == 0) {
-    hipLaunchKernelGGL(pack_weight_fwd_kernel, dim3((Cp + PW_CT - 1) / PW_CT, R), dim3(256), 0, s, w, dst, Cout, Cin, k * k, Cp);
+    hipLaunchKernelGGL(pack_weight_fwd_kernel, dim3((Cp + PW_CT - 1) / PW_CT, k == 1 ? (R + 7) / 8 : R), dim3(256), 0, s, w, dst, Cout, Cin, k * k, R, Cp);
   } else if (k == 3) {
     hipLaunchKernelGGL((pack_weight_dgrad_kernel<9, 16>), dim3((Cp + 63) / 64, (R + 15) / 16), dim3(256), 0, s, w, dst, Cout, Cin, R, Cp);
   } else {
     hipLaunchKernelGGL((pack_weight_dgrad_kernel<1, 64>), dim3((Cp + 63) / 64, (R + 63) / 64), dim3(256), 0, s, w, dst, Cout, Cin, R, Cp);
   }
+  HIP_CHECK(hipGetLastError());
+}
+// Both layouts of MANY weight tensors in one launch (the fine-tuning step inside a captured graph: 642 launches of ~14 us each were
+// 9 ms of a 38 ms replay).  entries[e] = one (tensor, layout); tile_prefix[e] = first workgroup of entry e (tile_prefix[n] = all).
+__global__ __launch_bounds__(256) void pack_weight_multi_kernel(const PackEntry* __restrict__ entries, const int* __restrict__ tile_prefix, int n_entries) {
+  __shared__ float t[PW_LDS];
+  int lo = 0, hi = n_entries;   // the entry this workgroup belongs to: last e with tile_prefix[e] <= blockIdx.x
+  while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (tile_prefix[mid] <= (int)blockIdx.x) lo = mid; else hi = mid; }
+  const PackEntry en = entries[lo];
+  const int local = (int)blockIdx.x - tile_prefix[lo];
+  const int bx = local % en.tiles_x, by = local / en.tiles_x;
+  if (en.mode == 0) pack_fwd_tile(t, en.w, en.dst, en.Cout, en.Cin, en.kk, en.R, en.Cp, bx, by);
+  else if (en.kk == 9) pack_dgrad_tile<9, 16>(t, en.w, en.dst, en.Cout, en.Cin, en.R, en.Cp, bx, by);
+  else pack_dgrad_tile<1, 64>(t, en.w, en.dst, en.Cout, en.Cin, en.R, en.Cp, bx, by);
+}
+void launch_pack_weight_multi(const PackEntry* entries, const int* tile_prefix, int n_entries, int n_tiles, hipStream_t s) {
+  if (n_entries == 0 || n_tiles == 0) return;
+  hipLaunchKernelGGL(pack_weight_multi_kernel, dim3(n_tiles), dim3(256), 0, s, entries, tile_prefix, n_entries);
   HIP_CHECK(hipGetLastError());
 }
 // wgrad GEMM output g[n][tap*Cx + c] (row pitch ldg) -> dw[n][c][ky][kx] in the parameter's own layout (the inverse transpose, per row n)

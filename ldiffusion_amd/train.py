@@ -419,6 +419,11 @@ class GraphedStep:
         self.params = unet.parameters() + list(proj)
         self.stream = torch.cuda.Stream(device=dev)   # warm-up and capture on ONE stream: the library keeps its scratch per (device, stream)
         self.graph, self.loss = None, None
+        # every weight layout of a step in ONE launch at its start (inside the graph: the masters change with every AdamW step); the frozen
+        # decoder's once, here.  Launched one by one they were 642 graph nodes of ~14 us: 9 ms of a 38 ms replay.
+        self.plan_unet = ag.PackPlan([v for v in unet.p.values() if v.dim() in (2, 4)])
+        self.plan_dec = ag.PackPlan([v for v in vae_dec.p.values() if v.dim() in (2, 4)])
+        self.plan_dec.run()
 
     def _forward_backward(self):
         # The graph is built on fresh leaves that ALIAS the parameters' storage: a parameter's gradient arrives at its AccumulateGrad node on the
@@ -429,11 +434,13 @@ class GraphedStep:
         pw, pb = (t.detach().requires_grad_(True) for t in self.proj)
         self.unet.p = alias
         try:
-            ctx = F.linear(self.hidden, pw, pb)
-            feats, _ = v5_features(self.unet, self.vae_dec, None, ctx, self.timesteps, self.abar, out_hw=self.out_hw, noisy_list=self.noisy)
-            loss = ag.InfoNceFn.apply(feats, self.bi, self.ai, self.pi, self.ni, self.temperature, self.count)
-            leaves = [v for v in alias.values() if v.requires_grad] + [pw, pb]   # the order of self.params
-            grads = torch.autograd.grad(loss * self.loss_scale, leaves, allow_unused=True)
+            self.plan_unet.run()
+            with ag.packed_weights(self.plan_unet, self.plan_dec):
+                ctx = F.linear(self.hidden, pw, pb)
+                feats, _ = v5_features(self.unet, self.vae_dec, None, ctx, self.timesteps, self.abar, out_hw=self.out_hw, noisy_list=self.noisy)
+                loss = ag.InfoNceFn.apply(feats, self.bi, self.ai, self.pi, self.ni, self.temperature, self.count)
+                leaves = [v for v in alias.values() if v.requires_grad] + [pw, pb]   # the order of self.params
+                grads = torch.autograd.grad(loss * self.loss_scale, leaves, allow_unused=True)
         finally:
             self.unet.p = own
         live = [g for g in grads if g is not None]

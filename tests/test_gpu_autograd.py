@@ -179,3 +179,22 @@ def test_adamw_matches_torch():
         ag.adamw_step(dev, [gr.to(DEV) for gr in grads], state, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01)
     for d, r in zip(dev, ref):
         assert (d.cpu() - r.detach()).abs().max() <= 2e-6 * max(1.0, r.abs().max().item())
+
+
+def test_pack_weight_multi_equals_the_single_launches():
+    """ag.PackPlan (ldiff_op_pack_weight_multi: every forward and dgrad layout of a weight list in one launch) against ldiff_op_pack_weight
+    tensor by tensor: 3x3 and 1x1 convs, linears, ragged channel counts (padding rows / columns must come out zero)."""
+    g = torch.Generator().manual_seed(9)
+    shapes = [(64, 4, 3, 3), (4, 64, 3, 3), (320, 320, 3, 3), (130, 70, 3, 3), (640, 320, 1, 1), (96, 200), (1280, 320), (24, 40, 1, 1)]
+    ws = [torch.randn(s, generator=g).to(DEV) for s in shapes]
+    plan = ag.PackPlan(ws)
+    plan.flat.fill_(float("nan"))
+    plan.run()
+    torch.cuda.synchronize()
+    for w in ws:
+        for dgrad in (False, True):
+            one = ag.pack_weight(w, dgrad=dgrad)
+            with ag.packed_weights(plan):
+                many = ag.pack_weight(w, dgrad=dgrad)
+            assert many.data_ptr() != one.data_ptr() and many.shape == one.shape
+            assert torch.equal(many, one), (tuple(w.shape), dgrad)

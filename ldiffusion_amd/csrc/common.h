@@ -79,6 +79,7 @@ struct ConvParams {
   float* splitk_ws;       // [splitk][M][N] fp32 workspace (then reduced + epilogue by splitk_reduce)
   const f16* w_par;       // conv3x3 with ups=1 only: parity weights [4][Nrows][4*Cin] (see kernels_conv3x3.hip); nullptr => 9-tap gather
   unsigned div_ntn, div_tx, div_ty;   // conv3x3 8x16 kernel only, set by its launcher: reciprocals of its tile decode (0 = divisor 1)
+  unsigned div_tm; int tiles_m, img_fast;   // conv3x3 halo-tile kernels, set by their launchers: pixel tiles of the launch; tile order (see conv3x3_img_fast)
   const f16* w_frag;      // conv3x3 dataflow kernel only (conv3x3d_selected): the weights fragment-packed by launch_pack_frag_weights
 };
 void launch_igemm(const ConvParams& p, hipStream_t s);   // dispatches to the halo-tile 3x3 kernel when eligible

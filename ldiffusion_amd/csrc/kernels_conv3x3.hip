@@ -53,8 +53,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const ConvParams p) {  
   int nwg = gridDim.x, id = blockIdx.x;
   int q8 = nwg >> 3, r8 = nwg & 7, xcd = id & 7, idx = id >> 3;
   int sw = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
-  const int tile_n = sw % ntn;
-  int tm = sw / ntn;
+  // small maps (conv3x3_img_fast): an XCD's consecutive workgroups share the n-tile (its weight slice stays in that XCD's L2), not the halo
+  const int tile_n = p.img_fast ? sw / p.tiles_m : sw % ntn;
+  int tm = p.img_fast ? sw - tile_n * p.tiles_m : sw / ntn;
   const int tx = tm % tiles_x; tm /= tiles_x;
   const int ty = tm % tiles_y;
   const int b = tm / tiles_y;
@@ -343,8 +344,9 @@ __global__ __launch_bounds__(256, BN > 128 ? 1 : 2) void conv3x3w_kernel(const C
   // division is ~25 dependent scalar / vector instructions with a VALU -> SALU round trip, and three of them stood in front of the
   // first halo load of every tile
   auto fdiv = [](int n, unsigned m) { return m ? (int)__umulhi((unsigned)n, m) : n; };   // m = 0 encodes a divisor of 1
-  const int tm = fdiv(sw, p.div_ntn);
-  const int tile_n = sw - tm * ntn;
+  int tm, tile_n;
+  if (p.img_fast) { tile_n = fdiv(sw, p.div_tm); tm = sw - tile_n * p.tiles_m; }   // (see conv3x3_kernel)
+  else { tm = fdiv(sw, p.div_ntn); tile_n = sw - tm * ntn; }
   const int tq = fdiv(tm, p.div_tx);
   const int tx = tm - tq * tiles_x;
   const int b = fdiv(tq, p.div_ty);
@@ -740,6 +742,21 @@ void launch_splitk_reduce_impl(const ConvParams& p, hipStream_t s) {
   HIP_CHECK(hipGetLastError());
 }
 
+// Tile order inside an XCD's run of workgroups.  Default: the n-tiles of one pixel tile are neighbours (they share the halo).  On the small
+// maps of the UNet's lower levels the halo is a few hundred KB and the WEIGHTS are what every pixel tile re-reads (1280 -> 1280 at 8 x 8:
+// 29.5 MB against 164 KB of input per image; with the n-tiles of one image on an XCD every XCD streamed the whole matrix: 7-12x its size
+// in HBM traffic, 50 us per launch = 4.7 TB/s).  There the pixel tiles of one n-tile are neighbours: its 128 x K weight slice (<= 2.9 MB)
+// is fetched once per XCD and hit in that XCD's L2 (4 MB) by the other images.  LDIFF_CONV3X3_IMGFAST: -1 (default) automatic, 0 off, n > 0 =
+// at most n pixel tiles per image.
+static bool conv3x3_img_fast(const ConvParams& p, int tiles_per_image, int ntn, int bn) {
+  static const int mode = [] { const char* e = getenv("LDIFF_CONV3X3_IMGFAST"); return e ? atoi(e) : -1; }();
+  if (mode == 0 || ntn <= 1 || p.B <= 1) return false;
+  if (mode > 0) return tiles_per_image <= mode;
+  (void)bn;
+  return tiles_per_image <= 2;   // 8 x 8 and 16 x 16 maps (measured, same box: 1280 -> 1280 at 8 x 8 45.6 -> 39.5 us, the 2560-channel concat
+                                 // layers 77.4 -> 58.1 us; 16 x 16: -2 ... -8 %; 32 x 32 and larger: no change)
+}
+
 template <int TH, int TW, int BN, bool GN>
 void launch_c3(const ConvParams& p, hipStream_t s) {
   constexpr int HP = (TH + 2) * (TW + 2);
@@ -756,7 +773,9 @@ void launch_c3(const ConvParams& p, hipStream_t s) {
   // flops = MFMA work actually executed: parity mode (nearest-2x folded into 4 taps) runs 16/36 of the 9-tap MACs
   ProfScope prof(pname.c_str(), 2.0 * p.M * (double)p.N * p.K * (par ? 16.0 / 36.0 : 1.0), bytes, s);
   const int S = p.splitk > 1 ? p.splitk : 1;
-  hipLaunchKernelGGL(kern, dim3(tiles * ntn, S, par ? 4 : 1), dim3(256), smem, s, p);
+  ConvParams q = p;
+  q.tiles_m = tiles; q.img_fast = conv3x3_img_fast(p, tiles / p.B, ntn, BN) ? 1 : 0;
+  hipLaunchKernelGGL(kern, dim3(tiles * ntn, S, par ? 4 : 1), dim3(256), smem, s, q);
   HIP_CHECK(hipGetLastError());
   if (S > 1) {
     const long long n = (long long)p.M * (p.N >> 2);
@@ -786,6 +805,7 @@ void launch_c3w(const ConvParams& p, hipStream_t s) {
   ConvParams q = p;
   auto recip = [](int d) { return d == 1 ? 0u : (unsigned)((1ULL << 32) / (unsigned)d + 1ULL); };   // 0 encodes a divisor of 1
   q.div_ntn = recip(ntn); q.div_tx = recip(tiles_x); q.div_ty = recip(tiles_y);
+  q.tiles_m = tiles; q.div_tm = recip(tiles); q.img_fast = conv3x3_img_fast(p, tiles / p.B, ntn, BN) ? 1 : 0;
   hipLaunchKernelGGL(kern, dim3(tiles * ntn, S, par ? 4 : 1), dim3(256), smem, s, q);
   HIP_CHECK(hipGetLastError());
   if (S > 1) {

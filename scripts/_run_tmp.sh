@@ -1,7 +1,7 @@
-mkdir -p gpurun_out/r4q; O=gpurun_out/r4q; rm -f $O/*
-timeout 900 python -m pytest tests/test_gpu_autograd.py -q -m gpu -x 2>&1 | tail -2 > $O/t.txt
-timeout 900 python -m pytest tests/test_gpu_train.py -q -m gpu -x 2>&1 | tail -2 >> $O/t.txt
-timeout 600 python scripts/bench_train.py --graph 2>&1 | tail -1 >> $O/t.txt
-timeout 600 python scripts/bench_train.py 2>&1 | tail -1 >> $O/t.txt
-timeout 600 python scripts/train_graph_prof.py 2>&1 | grep -v amdgpu >> $O/t.txt
-cat $O/t.txt
+mkdir -p gpurun_out/r4s; O=gpurun_out/r4s; rm -f $O/*
+for m in 0 -1; do LDIFF_CONV3X3_IMGFAST=$m timeout 400 python bench.py --steps 6 --warmup 2 --no-cpu-baseline > $O/b_$m.json 2>/dev/null; python3 -c "
+import json
+d=json.loads(open('$O/b_$m.json').read().strip().splitlines()[-1]); print('imgfast $m', round(d['value'],2), round(d['ms_per_step'],2), round(d['unet_step']['ms'],2))"; done
+for m in 0 -1; do LDIFF_CONV3X3_IMGFAST=$m timeout 400 python bench.py --steps 6 --warmup 2 --no-cpu-baseline > $O/c_$m.json 2>/dev/null; python3 -c "
+import json
+d=json.loads(open('$O/c_$m.json').read().strip().splitlines()[-1]); print('imgfast $m', round(d['value'],2), round(d['ms_per_step'],2), round(d['unet_step']['ms'],2))"; done

@@ -54,7 +54,9 @@ __global__ __launch_bounds__(256, 2) void gemm_dma_kernel(const ConvParams p) {
   int nwg = gridDim.x, id = blockIdx.x;
   int q8 = nwg >> 3, r8 = nwg & 7, xcd = id & 7, idx = id >> 3;
   int sw = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
-  const int m0 = (sw / ntn) * BM, n0 = (sw % ntn) * BN;
+  // tile order inside an XCD's run: n-tiles of one m-tile are neighbours (they share the activation rows), or -- where the weights are the
+  // larger operand (gemm_m_fast) -- the m-tiles of one n-tile (its weight rows stay in that XCD's L2)
+  const int m0 = (p.img_fast ? sw % p.tiles_m : sw / ntn) * BM, n0 = (p.img_fast ? sw / p.tiles_m : sw % ntn) * BN;
 
   // ---- operand slices by `buffer_load_dwordx4 ... lds` (see the wide conv3x3 kernel): wave w owns rows [w*B/4, (w+1)*B/4)
   // of each [B][64] slice = B/32 pieces of 8 rows (1 KiB); per-lane voffsets are fixed, a step moves only the scalar soffset;
@@ -300,6 +302,16 @@ __global__ __launch_bounds__(256, 2) void gemm_dma_kernel(const ConvParams p) {
   }
 }
 
+// LDIFF_GEMM_MFAST: -1 (default) automatic, 0 off, 1 always.  Automatic: the weight matrix is the larger operand and does not fit an XCD's L2
+// beside the activations (the UNet's 16 x 16 and 8 x 8 levels: M = 2048 / 512 rows against N = 1280 ... 10240).
+static bool gemm_m_fast(const ConvParams& p, int ntm, int ntn) {
+  static const int mode = [] { const char* e = getenv("LDIFF_GEMM_MFAST"); return e ? atoi(e) : -1; }();
+  if (mode == 0 || ntm <= 1 || ntn <= 1 || p.w_bstride != 0) return false;
+  if (mode > 0) return true;
+  // measured, same box: 1280 -> 10240 at 2048 rows 78.0 -> 64.3 us, 1280 -> 3840 at 512 rows 15.5 -> 10.9 us; the 64 x 64 / 32 x 32 levels lose 5-50 %
+  return 2LL * p.N > 3LL * p.M && (long long)p.N * p.K * 2 > (2LL << 20);
+}
+
 template <int BM, int BN>
 void launch_g(const ConvParams& p, hipStream_t s) {
   const size_t smem = (size_t)2 * (BM + BN) * 8 * 16;
@@ -311,7 +323,9 @@ void launch_g(const ConvParams& p, hipStream_t s) {
   ProfScope prof(pname.c_str(), 2.0 * p.M * (double)p.N * p.K, bytes, s);
   const int S = p.splitk > 1 ? p.splitk : 1;
   LDIFF_CHECK(S == 1 || (p.splitk_ws && !p.stats && !p.geglu && !p.out_f32 && p.w_bstride == 0), LDIFF_ERR_INVALID, "gemm: split-K needs a workspace and a plain fp16 epilogue");
-  hipLaunchKernelGGL(kern, dim3(ntm * ntn, S), dim3(256), smem, s, p);
+  ConvParams q = p;
+  q.tiles_m = ntm; q.img_fast = gemm_m_fast(p, ntm, ntn) ? 1 : 0;
+  hipLaunchKernelGGL(kern, dim3(ntm * ntn, S), dim3(256), smem, s, q);
   if (S > 1) { HIP_CHECK(hipGetLastError()); launch_splitk_reduce(p, s); }
   HIP_CHECK(hipGetLastError());
 }

@@ -44,6 +44,10 @@ SHAPES = {
     "lin_L0_out_320_320": (1, 320, 0, 1, 32768, 320, 1, 1, 0, 0),
     "lin_L2_ff1_1280_10240": (1, 1280, 0, 1, 2048, 10240, 1, 1, 0, 0),
     "lin_L2_ff2_5120_1280": (1, 5120, 0, 1, 2048, 1280, 1, 1, 0, 0),
+    "lin_L3_qkv_1280_3840": (1, 1280, 0, 1, 512, 3840, 1, 1, 0, 0),
+    "lin_L3_ff1_1280_10240": (1, 1280, 0, 1, 512, 10240, 1, 1, 0, 0),
+    "lin_L3_ff2_5120_1280": (1, 5120, 0, 1, 512, 1280, 1, 1, 0, 0),
+    "lin_L1_ff1_640_5120b": (1, 640, 0, 1, 8192, 5120, 1, 1, 0, 0),
     "conv1x1_L0_320_320_gn": (8, 320, 0, 64, 64, 320, 1, 1, 0, 1),
     "down_L0_320_320_s2": (8, 320, 0, 64, 64, 320, 3, 2, 0, 0),
     "down_L1_640_640_s2": (8, 640, 0, 32, 32, 640, 3, 2, 0, 0),

@@ -1,6 +1,8 @@
-mkdir -p gpurun_out/r4u; O=gpurun_out/r4u; rm -f $O/*
-timeout 900 python -m pytest tests/test_gpu_kernels.py -q -m gpu -x 2>&1 | tail -2 > $O/t.txt
-for m in 0 -1 0 -1; do LDIFF_GEMM_MFAST=$m timeout 400 python bench.py --steps 6 --warmup 2 --no-cpu-baseline > $O/b.json 2>/dev/null; python3 -c "
-import json
-d=json.loads(open('$O/b.json').read().strip().splitlines()[-1]); print('mfast $m', round(d['value'],2), round(d['ms_per_step'],2), round(d['unet_step']['ms'],2))" >> $O/t.txt; done
-cat $O/t.txt
+mkdir -p gpurun_out/r4v; O=gpurun_out/r4v; rm -f $O/*
+timeout 3000 python -m pytest tests/ -q -m gpu -x 2>&1 | tail -3 > $O/gpu_tests.txt
+timeout 600 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | grep -v amdgpu > $O/smoke.txt
+timeout 600 python scripts/unet_launches.py > $O/unet_launches.txt 2>&1
+timeout 600 python scripts/vae_launches.py > $O/vae_launches.txt 2>&1
+timeout 600 python bench.py > $O/bench.json 2> $O/bench.err
+bash scripts/final_profiles.sh > $O/final.log 2>&1
+tail -2 $O/gpu_tests.txt; tail -3 $O/smoke.txt; head -3 $O/unet_launches.txt; tail -c 600 $O/bench.json; tail -5 $O/final.log | cut -c1-300

@@ -361,6 +361,10 @@ int gemm_dma_splitk_plan(const ConvParams& p) {
 }
 
 void launch_gemm_dma(const ConvParams& p, hipStream_t s) {
+  static const int force = [] { const char* e = getenv("LDIFF_GEMM_TILE"); return e ? atoi(e) : 0; }();   // diagnostic: 1 = 128x128, 2 = 128x64, 3 = 64x64
+  if (force == 1 && (p.w_bstride == 0 || (p.Hout * p.Wout) % 128 == 0)) return launch_g<128, 128>(p, s);
+  if (force == 2 && (p.w_bstride == 0 || (p.Hout * p.Wout) % 128 == 0)) return launch_g<128, 64>(p, s);
+  if (force == 3) return launch_g<64, 64>(p, s);
   const int S = p.splitk > 1 ? p.splitk : 1;   // split-K multiplies the workgroups of a tile shape
   auto tiles = [&](int bm, int bn) { return (long long)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn); };
   const bool n_small = p.N <= 64 || (p.N % 128 != 0 && p.N % 128 <= 64 && p.N < 512);

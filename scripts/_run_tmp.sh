@@ -1,8 +1,11 @@
-mkdir -p gpurun_out/r4v; O=gpurun_out/r4v; rm -f $O/*
-timeout 3000 python -m pytest tests/ -q -m gpu -x 2>&1 | tail -3 > $O/gpu_tests.txt
-timeout 600 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | grep -v amdgpu > $O/smoke.txt
-timeout 600 python scripts/unet_launches.py > $O/unet_launches.txt 2>&1
-timeout 600 python scripts/vae_launches.py > $O/vae_launches.txt 2>&1
-timeout 600 python bench.py > $O/bench.json 2> $O/bench.err
-bash scripts/final_profiles.sh > $O/final.log 2>&1
-tail -2 $O/gpu_tests.txt; tail -3 $O/smoke.txt; head -3 $O/unet_launches.txt; tail -c 600 $O/bench.json; tail -5 $O/final.log | cut -c1-300
+mkdir -p gpurun_out/r4w; O=gpurun_out/r4w; rm -f $O/*
+for m in 0 1 2 3; do echo "== LDIFF_GEMM_TILE=$m" >> $O/ab.txt; LDIFF_GEMM_TILE=$m timeout 200 python scripts/bench_conv.py lin_ --iters 30 2>&1 | grep -E "lin_" >> $O/ab.txt; done
+python3 - <<'PY'
+import re,collections
+d=collections.defaultdict(dict); cur=None
+for l in open('gpurun_out/r4w/ab.txt'):
+    if l.startswith('=='): cur=l.split('=')[-1].strip(); continue
+    m=re.match(r"(\S+)\s+([\d.]+) us",l)
+    if m: d[m.group(1)][cur]=float(m.group(2))
+for k,v in d.items(): print(f"{k:26s}", "  ".join(f"{t}:{v.get(t,0):7.1f}" for t in "0123"))
+PY

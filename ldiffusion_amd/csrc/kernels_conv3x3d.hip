@@ -19,15 +19,21 @@
 //     SiLU in place (ds_read -> common.h gn_quad: the v_fma_mix form, no packed-fp32 VALU beside the matrix stream -> mask -> ds_write).
 //     Nothing asynchronous ever targets a VGPR on this side (the register allocator may copy an asm load's destination before the data
 //     has landed wherever the value lives across control flow: measured).
-//   * progress words (LDS): producer wave w publishes "slabs complete", consumer wave w "slabs whose pixels are all in registers"; a
-//     producer may fill image k % 3 once every consumer has finished slab k - 3, a consumer starts slab k when every producer has it.
+//     The same waves run the EPILOGUE: a consumer only rounds its sums to fp16 and writes them to LDS (a staging area + the halo image its
+//     unit's last slab has just released); producer wave w then stores what consumer wave w computed as full 128-byte lines -- residual
+//     (read in the same shape, added in fp16) and the fused GroupNorm statistics of the stored values on its side -- while the consumers
+//     are already in the next unit.  (The memory pipe works in lines: stores in the accumulator shape, 32 bytes per pixel and
+//     instruction, cost 6 % of a plain layer and twice that with a residual.)  The fp16 hand-over rounds a residual layer's output twice.
+//   * progress words (LDS): producer wave w publishes "slabs complete" and "tiles read from the staging area", consumer wave w "slabs
+//     whose pixels are all in registers" and "tiles staged"; a producer may fill image k % 3 once every consumer has finished slab k - 3
+//     (and, where that image carried a staged tile, once every producer has it in registers), a consumer starts slab k when every
+//     producer has it.
 // A workgroup walks a contiguous run of (pixel tile, channel tile) units (XCD-aware: the runs of one XCD's workgroups are adjacent);
-// the slab sequence runs through unit boundaries on the producer side; the consumer's epilogue (residual, fp16 rounding, fused GroupNorm
-// statistics, 16-byte stores) is the only phase in which a SIMD's matrix pipe idles.  Workgroups start staggered: in lock-step all 256
-// of them would store their output tiles in the same few microseconds.
+// the slab sequence runs through unit boundaries on both sides.  Workgroups start staggered: in lock-step all 256 of them would hand
+// over their output tiles in the same few microseconds.
 //
 // Scope (conv3x3d_selected): one source, Cin % 64 == 0, N % 128 == 0, H, W % 16 == 0, GroupNorm + SiLU prologue, plain fp16 output and
-// residual.  Everything else stays on the kernels of kernels_conv3x3.hip / kernels_conv3x3p.hip.
+// residual (no split hi|lo tensors: the staged tile is fp16).  Everything else stays on the kernels of kernels_conv3x3.hip / kernels_conv3x3p.hip.
 #include "common.h"
 #include <map>
 #include <mutex>

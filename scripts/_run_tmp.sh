@@ -1,11 +1,4 @@
-mkdir -p gpurun_out/r4w; O=gpurun_out/r4w; rm -f $O/*
-for m in 0 1 2 3; do echo "== LDIFF_GEMM_TILE=$m" >> $O/ab.txt; LDIFF_GEMM_TILE=$m timeout 200 python scripts/bench_conv.py lin_ --iters 30 2>&1 | grep -E "lin_" >> $O/ab.txt; done
-python3 - <<'PY'
-import re,collections
-d=collections.defaultdict(dict); cur=None
-for l in open('gpurun_out/r4w/ab.txt'):
-    if l.startswith('=='): cur=l.split('=')[-1].strip(); continue
-    m=re.match(r"(\S+)\s+([\d.]+) us",l)
-    if m: d[m.group(1)][cur]=float(m.group(2))
-for k,v in d.items(): print(f"{k:26s}", "  ".join(f"{t}:{v.get(t,0):7.1f}" for t in "0123"))
-PY
+bash scripts/pmc_conv.sh vae512_128_128_gn r4x_plain > /dev/null 2>&1
+LDIFF_BENCH_RES=1 LDIFF_BENCH_STATS=1 bash scripts/pmc_conv.sh vae512_128_128_gn r4x_res > /dev/null 2>&1
+LDIFF_CONV3X3_DATAFLOW=0 bash scripts/pmc_conv.sh vae512_128_128_gn r4x_old > /dev/null 2>&1
+echo "== dataflow plain"; cat gpurun_out/r4x_plain/summary.txt; echo "== dataflow res+stats"; cat gpurun_out/r4x_res/summary.txt; echo "== 8x16 plain"; cat gpurun_out/r4x_old/summary.txt

@@ -1,4 +1,3 @@
-bash scripts/pmc_conv.sh vae512_128_128_gn r4x_plain > /dev/null 2>&1
-LDIFF_BENCH_RES=1 LDIFF_BENCH_STATS=1 bash scripts/pmc_conv.sh vae512_128_128_gn r4x_res > /dev/null 2>&1
-LDIFF_CONV3X3_DATAFLOW=0 bash scripts/pmc_conv.sh vae512_128_128_gn r4x_old > /dev/null 2>&1
-echo "== dataflow plain"; cat gpurun_out/r4x_plain/summary.txt; echo "== dataflow res+stats"; cat gpurun_out/r4x_res/summary.txt; echo "== 8x16 plain"; cat gpurun_out/r4x_old/summary.txt
+mkdir -p gpurun_out/r4y; O=gpurun_out/r4y; rm -f $O/*
+for r in 2 0 3; do echo "== LDIFF_C3D_RUN=$r" >> $O/s.txt; LDIFF_C3D_RUN=$r LDIFF_CONV3X3_DATAFLOW=2 timeout 600 python scripts/stress_c3d.py 150 2>&1 | grep -v amdgpu >> $O/s.txt; done
+cat $O/s.txt

@@ -1,3 +1,7 @@
-mkdir -p gpurun_out/r4y; O=gpurun_out/r4y; rm -f $O/*
-for r in 2 0 3; do echo "== LDIFF_C3D_RUN=$r" >> $O/s.txt; LDIFF_C3D_RUN=$r LDIFF_CONV3X3_DATAFLOW=2 timeout 600 python scripts/stress_c3d.py 150 2>&1 | grep -v amdgpu >> $O/s.txt; done
-cat $O/s.txt
+mkdir -p gpurun_out/r4z; O=gpurun_out/r4z; rm -f $O/*
+timeout 600 python scripts/bench_modes.py 2>&1 | grep -v amdgpu > $O/modes.txt
+for i in 1 2 3; do timeout 400 python bench.py --no-cpu-baseline 2>/dev/null | python3 -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('bench run', round(d['value'],2), round(d['ms_per_step'],2), round(d['roofline']['frac'],3), round(d['roofline']['serial']['frac'],3), d['roofline'].get('traffic'))" >> $O/modes.txt; done
+bash scripts/final_profiles.sh > $O/final.log 2>&1
+cat $O/modes.txt; tail -3 $O/final.log | cut -c1-200

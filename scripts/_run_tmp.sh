@@ -1,7 +1,4 @@
-mkdir -p gpurun_out/r4z; O=gpurun_out/r4z; rm -f $O/*
-timeout 600 python scripts/bench_modes.py 2>&1 | grep -v amdgpu > $O/modes.txt
-for i in 1 2 3; do timeout 400 python bench.py --no-cpu-baseline 2>/dev/null | python3 -c "
-import json,sys
-d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('bench run', round(d['value'],2), round(d['ms_per_step'],2), round(d['roofline']['frac'],3), round(d['roofline']['serial']['frac'],3), d['roofline'].get('traffic'))" >> $O/modes.txt; done
-bash scripts/final_profiles.sh > $O/final.log 2>&1
-cat $O/modes.txt; tail -3 $O/final.log | cut -c1-200
+mkdir -p gpurun_out/r5b; O=gpurun_out/r5b; rm -f $O/*
+for m in 0 1 0 1; do echo "== LDIFF_ATTN_XCD=$m" >> $O/ab.txt; LDIFF_ATTN_XCD=$m timeout 200 python scripts/bench_conv.py attn_ --iters 30 2>&1 | grep -E "attn_" >> $O/ab.txt; done
+timeout 600 python -m pytest tests/test_gpu_kernels.py -q -m gpu -x -k "attn or attention" 2>&1 | tail -2 >> $O/ab.txt
+cat $O/ab.txt

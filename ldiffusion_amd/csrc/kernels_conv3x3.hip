@@ -43,7 +43,6 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const ConvParams p) {  
   // 3x3 taps that alias onto the same source pixel pre-summed (w_par).  4 taps per slab instead of 9.
   const bool par = p.w_par != nullptr;
   const int NTAPS = par ? 4 : 9;
-  const int q_par = par ? blockIdx.z : 0, py = q_par >> 1, px = q_par & 1;
   const int Ht = par ? p.Hin : p.Hout, Wt = par ? p.Win : p.Wout;   // tile-space extent
   const int tiles_x = (Wt + TW - 1) / TW, tiles_y = (Ht + TH - 1) / TH;
   const int ntn = (p.N + BN - 1) / BN;
@@ -56,6 +55,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const ConvParams p) {  
   // small maps (conv3x3_img_fast): an XCD's consecutive workgroups share the n-tile (its weight slice stays in that XCD's L2), not the halo
   const int tile_n = p.img_fast ? sw / p.tiles_m : sw % ntn;
   int tm = p.img_fast ? sw - tile_n * p.tiles_m : sw / ntn;
+  // parity mode: the four output parities of a source tile are neighbours in the list (they read the same halo: as the slowest grid
+  // dimension every parity streamed the whole input from HBM again)
+  const int q_par = par ? tm & 3 : 0, py = q_par >> 1, px = q_par & 1;
+  tm = par ? tm >> 2 : tm;
   const int tx = tm % tiles_x; tm /= tiles_x;
   const int ty = tm % tiles_y;
   const int b = tm / tiles_y;
@@ -333,7 +336,6 @@ __global__ __launch_bounds__(256, BN > 128 ? 1 : 2) void conv3x3w_kernel(const C
   const int g = lane >> 4, l15 = lane & 15;
   const int Cin = p.C1 + p.C2;
   const bool par = p.w_par != nullptr;
-  const int q_par = par ? blockIdx.z : 0, py = q_par >> 1, px = q_par & 1;
   const int Ht = par ? p.Hin : p.Hout, Wt = par ? p.Win : p.Wout;
   const int tiles_x = (Wt + TW - 1) / TW, tiles_y = (Ht + TH - 1) / TH;
   const int ntn = (p.N + BN - 1) / BN;
@@ -347,6 +349,8 @@ __global__ __launch_bounds__(256, BN > 128 ? 1 : 2) void conv3x3w_kernel(const C
   int tm, tile_n;
   if (p.img_fast) { tile_n = fdiv(sw, p.div_tm); tm = sw - tile_n * p.tiles_m; }   // (see conv3x3_kernel)
   else { tm = fdiv(sw, p.div_ntn); tile_n = sw - tm * ntn; }
+  const int q_par = par ? tm & 3 : 0, py = q_par >> 1, px = q_par & 1;   // parity next to the n-tile (see conv3x3_kernel)
+  tm = par ? tm >> 2 : tm;
   const int tq = fdiv(tm, p.div_tx);
   const int tx = tm - tq * tiles_x;
   const int b = fdiv(tq, p.div_ty);
@@ -774,8 +778,9 @@ void launch_c3(const ConvParams& p, hipStream_t s) {
   ProfScope prof(pname.c_str(), 2.0 * p.M * (double)p.N * p.K * (par ? 16.0 / 36.0 : 1.0), bytes, s);
   const int S = p.splitk > 1 ? p.splitk : 1;
   ConvParams q = p;
-  q.tiles_m = tiles; q.img_fast = conv3x3_img_fast(p, tiles / p.B, ntn, BN) ? 1 : 0;
-  hipLaunchKernelGGL(kern, dim3(tiles * ntn, S, par ? 4 : 1), dim3(256), smem, s, q);
+  const int npar = par ? 4 : 1;
+  q.tiles_m = tiles * npar; q.img_fast = conv3x3_img_fast(p, tiles / p.B, ntn, BN) ? 1 : 0;
+  hipLaunchKernelGGL(kern, dim3(tiles * ntn * npar, S, 1), dim3(256), smem, s, q);
   HIP_CHECK(hipGetLastError());
   if (S > 1) {
     const long long n = (long long)p.M * (p.N >> 2);
@@ -801,12 +806,13 @@ void launch_c3w(const ConvParams& p, hipStream_t s) {
   ProfScope prof(pname.c_str(), 2.0 * p.M * (double)p.N * p.K * (par ? 16.0 / 36.0 : 1.0), bytes, s);
   const int S = p.splitk > 1 ? p.splitk : 1;
   const int tiles_x = (Wt + TW - 1) / TW, tiles_y = (Ht + TH - 1) / TH;
-  LDIFF_CHECK((long long)tiles * ntn * std::max(ntn, std::max(tiles_x, tiles_y)) < (1LL << 32), LDIFF_ERR_INVALID, "conv3x3: %d tiles x %d channel tiles exceed the tile decode's range", tiles, ntn);
+  LDIFF_CHECK((long long)tiles * (par ? 4 : 1) * ntn * std::max(std::max(ntn, tiles * (par ? 4 : 1)), std::max(tiles_x, tiles_y)) < (1LL << 32), LDIFF_ERR_INVALID, "conv3x3: %d tiles x %d channel tiles exceed the tile decode's range", tiles, ntn);
   ConvParams q = p;
   auto recip = [](int d) { return d == 1 ? 0u : (unsigned)((1ULL << 32) / (unsigned)d + 1ULL); };   // 0 encodes a divisor of 1
   q.div_ntn = recip(ntn); q.div_tx = recip(tiles_x); q.div_ty = recip(tiles_y);
-  q.tiles_m = tiles; q.div_tm = recip(tiles); q.img_fast = conv3x3_img_fast(p, tiles / p.B, ntn, BN) ? 1 : 0;
-  hipLaunchKernelGGL(kern, dim3(tiles * ntn, S, par ? 4 : 1), dim3(256), smem, s, q);
+  const int npar = par ? 4 : 1;
+  q.tiles_m = tiles * npar; q.div_tm = recip(tiles * npar); q.img_fast = conv3x3_img_fast(p, tiles / p.B, ntn, BN) ? 1 : 0;
+  hipLaunchKernelGGL(kern, dim3(tiles * ntn * npar, S, 1), dim3(256), smem, s, q);
   HIP_CHECK(hipGetLastError());
   if (S > 1) {
     const long long n = (long long)p.M * (p.N >> 2);

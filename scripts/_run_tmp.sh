@@ -1,8 +1,11 @@
-mkdir -p gpurun_out/r5e; O=gpurun_out/r5e; rm -f $O/*
-for rep in 1 2; do for v in ldiffusion_amd build/prev; do
-  LDIFF_LIB=$v/libldiff_hip.so timeout 200 python scripts/bench_conv.py _up_ --iters 20 2>&1 | grep -E "_up_" | sed "s|^|$v |" >> $O/t.txt
-  timeout 400 python scripts/bench_variant.py $v/libldiff_hip.so --steps 6 --warmup 2 --no-cpu-baseline > $O/b.json 2>/dev/null; python3 -c "
+mkdir -p gpurun_out/r5f; O=gpurun_out/r5f; rm -f $O/*
+timeout 3000 python -m pytest tests/ -q -m gpu -x 2>&1 | tail -2 > $O/gpu_tests.txt
+timeout 600 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | grep -v amdgpu > $O/smoke.txt
+timeout 600 python scripts/unet_launches.py > $O/unet_launches.txt 2>&1
+bash scripts/final_profiles.sh > $O/final.log 2>&1
+mkdir -p profiles_tmp; H=$(python3 -c "import bench; print(bench.kernel_source_hash())"); cp gpurun_out/final/pmc_traffic_$H.json profiles/
+timeout 600 python bench.py > $O/bench.json 2> $O/bench.err
+tail -2 $O/gpu_tests.txt; tail -1 $O/smoke.txt; head -1 $O/unet_launches.txt
+python3 -c "
 import json
-d=json.loads(open('$O/b.json').read().strip().splitlines()[-1]); print('$v bench', round(d['value'],2), round(d['ms_per_step'],2), round(d['unet_step']['ms'],2), [ (k['name'],k['ms']) for k in d['kernels'] if k['name'] in ('conv3x3<16x16,128>','conv3x3<8x16,128>')])" >> $O/t.txt
-done; done
-cat $O/t.txt
+d=json.loads(open('$O/bench.json').read().strip().splitlines()[-1]); print('bench', round(d['value'],2), round(d['ms_per_step'],2), round(d['roofline']['frac'],3), round(d['roofline']['serial']['frac'],3), d['unet_step']['ms'], d['roofline'].get('traffic'), d['cpu_baseline']['value'])"

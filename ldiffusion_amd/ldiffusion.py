@@ -89,6 +89,10 @@ class LDiffusionModel:
         checkpoint = 100
         n_sched = min(int(num_inference_steps / 5), len(self.pipeline.scheduler.alphas_cumprod))
         state, noise_offset = {}, 0   # Philox counters consumed so far: every step draws fresh Laplace noise (the reference samples anew each time)
+        # forward + loss + backward as ONE captured HIP graph per step (train.GraphedStep) where the loss is the contrastive term alone and the
+        # batch has the captured shape; anything else (content term, a short last batch, more triples than the capture holds) runs eagerly
+        use_graph = bool(getattr(args, "use_graph", True)) and loss_obj.vgg is None
+        gstep = None
         for epoch in range(num_epochs):
             if hasattr(train_loader, "sampler") and hasattr(train_loader.sampler, "set_epoch"):
                 train_loader.sampler.set_epoch(epoch)
@@ -111,8 +115,27 @@ class LDiffusionModel:
                     big = F.interpolate(rgb, size=(1024, 1024), mode="bilinear", align_corners=False)
                     return loss_obj.compute_content_loss(image, big) + contrastive
 
-                total += T.train_step(unet, dec, proj, latents, text_hidden, ts, self.pipeline.scheduler.alphas_cumprod, None, None, state, lr=1e-5,
-                                      weight_decay=0.01, loss_fn=loss_fn, max_grad_norm=1.0, seed=self.rank, offset=noise_offset)
+                pairs = None
+                if use_graph:
+                    pairs = loss_obj.sample_triples(lab.to("cpu"))   # the draws compute_contrastive_loss would make (same torch random stream)
+                    n_tr = sum(len(t) for t in pairs)
+                    if gstep is None and n_tr > 0:
+                        gstep = T.GraphedStep(unet, dec, proj, B, ts, self.pipeline.scheduler.alphas_cumprod, latent_hw=latents.shape[-1],
+                                              text_len=text_hidden.shape[1], text_dim=text_hidden.shape[2], max_triples=max(256, 64 * B),
+                                              num_negatives=loss_obj.num_negatives, temperature=loss_obj.temperature)
+                    graphed = (gstep is not None and n_tr > 0 and B == gstep.hidden.shape[0] and ts == gstep.timesteps and n_tr <= gstep.bi.numel()
+                               and tuple(latents.shape[-2:]) == tuple(gstep.noisy[0].shape[-2:]) and text_hidden.shape[1] == gstep.hidden.shape[1])
+                    if n_tr == 0:
+                        pass                                          # no sample triples: the loss is a constant 0, nothing to step (as the eager path)
+                    elif graphed:
+                        total += T.train_step_graphed(gstep, latents, text_hidden, None, pairs, state, lr=1e-5, weight_decay=0.01, max_grad_norm=1.0,
+                                                      seed=self.rank, offset=noise_offset)
+                    else:
+                        total += T.train_step(unet, dec, proj, latents, text_hidden, ts, self.pipeline.scheduler.alphas_cumprod, None, pairs, state,
+                                              lr=1e-5, weight_decay=0.01, max_grad_norm=1.0, seed=self.rank, offset=noise_offset)
+                else:
+                    total += T.train_step(unet, dec, proj, latents, text_hidden, ts, self.pipeline.scheduler.alphas_cumprod, None, None, state, lr=1e-5,
+                                          weight_decay=0.01, loss_fn=loss_fn, max_grad_norm=1.0, seed=self.rank, offset=noise_offset)
                 noise_offset += len(ts) * latents.numel()   # v5_features draws offset + i * numel for pass i
             current = self._reduce_mean(total / max(1, len(train_loader)))
             if self._is_main_process():

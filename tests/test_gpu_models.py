@@ -1032,3 +1032,11 @@ def test_train_ldiffusion_mirror_end_to_end(tiny, tmp_path):
     ctx = torch.randn((1, 6, 64), generator=g).to(DEV)
     assert not torch.equal(unet(x, 1, ctx).sample, tiny["unet"](x, 1, ctx).sample)
     assert tuple(torch.load(os.path.join(saved, "proj_weights.pt"))["weight"].shape) == (64, 32)
+    # the same loop with the step driven from the Python tape (use_graph=False) instead of the captured graph: same draws, same losses
+    args2 = SimpleNamespace(diffusion_path=str(sd_dir), num_inference_steps=5, batch_size=2, ldiffusion_epochs=2, output_root=str(tmp_path / "out2"), use_graph=False)
+    torch.manual_seed(5)
+    LDiffusionModel(str(sd_dir), "cell").train(args2, component="ldiffusion", train_loader=loader)
+    rows2 = list(csv.reader(open(next((tmp_path / "out2" / "train_save" / "loss").glob("*/contrast_loss.csv")))))
+    print(f"  eager loop: epoch losses {[round(float(r[1]), 4) for r in rows2[1:]]}")
+    for a, b in zip(rows[1:], rows2[1:]):
+        assert abs(float(a[1]) - float(b[1])) <= 2e-3 * abs(float(b[1])), (a, b)

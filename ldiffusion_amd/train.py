@@ -490,9 +490,15 @@ class GraphedStep:
         return self.loss
 
 
-def train_step_graphed(gstep, z0, text_hidden, u_list, pairs, opt_state, lr=1e-5, weight_decay=0.01, max_grad_norm=None, seed=0, offset=0):
-    """`train_step` with forward + backward replayed from `gstep` (GraphedStep); exchange, clipping and AdamW as in the eager step."""
+def train_step_graphed(gstep, z0, text_hidden, u_list, pairs, opt_state, lr=1e-5, weight_decay=0.01, max_grad_norm=None, seed=0, offset=0,
+                       optimizer=None):
+    """`train_step` with forward + backward replayed from `gstep` (GraphedStep); exchange, clipping and AdamW as in the eager step, or --
+    `optimizer` = a ShardedAdamW over `gstep.params` -- reduce-scatter, sharded AdamW, all-gather.  (A ShardedAdamW moves the parameters
+    into its flat buffer: create it BEFORE the GraphedStep, whose graph and weight-layout plan hold the parameters' addresses.)"""
     loss = gstep(z0, text_hidden, pairs, u_list, seed, offset)
+    if optimizer is not None:
+        optimizer.step(max_grad_norm)
+        return float(loss)
     allreduce_gradients(gstep.params)
     if max_grad_norm is not None:
         clip_grad_norm(gstep.params, max_grad_norm)

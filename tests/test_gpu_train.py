@@ -214,3 +214,33 @@ def test_contrastive_loss_kernel_at_the_reference_fixture():
         e_g = ((x.grad.cpu().double() - ref_in.grad).abs().max() / ref_in.grad.abs().max()).item()
         print(f"[infonce fixture {tag}] {sum(len(t) for t in triples)} triples: loss {loss.item():.6f} vs the reference's {float(z[tag + '_loss']):.6f} ({e_l:.1e}); gradient {e_g:.1e}")
         assert e_l <= 1e-5 and e_g <= 1e-5
+
+
+def test_graphed_step_with_the_sharded_optimizer():
+    """train_step_graphed(optimizer=ShardedAdamW) on one rank (the slice is the whole flat buffer, no collective): the parameters after two
+    steps equal those of the multi-tensor AdamW path up to the rounding of the clipping norm (float64 over the flat slice there, float32
+    per tensor here: the clip coefficient differs in its last bits; the elementwise update is the same, and the collectives of the sharded
+    path are pinned bit for bit against the all-reduce path by the world-size-2 gloo test)."""
+    ucfg, vcfg, usd, vsd, z0, hidden, proj_w, proj_b, sch, ts, u_list, pairs = _setup()
+    dec = train.FrozenVAEDecoder(vcfg, vsd, DEV)
+    finals = []
+    for sharded in (False, True):
+        unet = train.TrainableUNet(ucfg, usd, DEV)
+        proj = (proj_w.to(DEV).requires_grad_(True), proj_b.to(DEV).requires_grad_(True))
+        opt = train.ShardedAdamW(unet.parameters() + list(proj), lr=1e-4, weight_decay=0.01) if sharded else None   # before the capture
+        gstep = train.GraphedStep(unet, dec, proj, z0.shape[0], ts, sch.alphas_cumprod, latent_hw=8, text_len=hidden.shape[1], text_dim=hidden.shape[2],
+                                  max_triples=32, num_negatives=64)
+        state, losses = {}, []
+        for _ in range(2):
+            losses.append(train.train_step_graphed(gstep, z0.to(DEV), hidden.to(DEV), [u.to(DEV) for u in u_list], pairs, state, lr=1e-4, weight_decay=0.01,
+                                                   max_grad_norm=1.0, optimizer=opt))
+        torch.cuda.synchronize()
+        finals.append(([p_.detach().clone() for p_ in unet.parameters() + list(proj)], losses))
+    print(f"two graphed steps: multi-tensor AdamW losses {finals[0][1]}, sharded {finals[1][1]}")
+    assert finals[0][1][1] < finals[0][1][0] and abs(finals[0][1][1] - finals[1][1][1]) <= 1e-4 * abs(finals[0][1][1])
+    # Parameters: Adam turns a gradient into a step of about lr whatever its size, so entries whose gradient is rounding noise (the q / k
+    # projections of the 1-token attention; the loss scatters with float atomics, whose order differs from run to run) may move by lr per step
+    # in either direction: the bound is 2 lr per step, and the entries that moved apart by more than a tenth of lr are a small minority.
+    diffs = torch.cat([(a - b).abs().reshape(-1) for a, b in zip(finals[0][0], finals[1][0])])
+    print(f"  parameters after two steps: max |difference| {diffs.max().item():.1e} (lr 1e-4), fraction beyond lr / 10: {(diffs > 1e-5).float().mean().item():.1e}")
+    assert diffs.max().item() <= 4.1e-4 and (diffs > 1e-5).float().mean().item() <= 0.02

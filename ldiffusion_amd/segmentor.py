@@ -107,6 +107,21 @@ class Segmentor:
             self._sampler = LaplaceSampler(pipeline)
         return self._sampler.sample(images, text_embeddings, 1, want_features=False, want_rgb=True)
 
+    def build_augmented_dataloader(self, dataloader, augment_fn, pipeline, unet, vae, device, batch_size, category, num_workers=0):
+        """segmentor.py:144-161: run `augment_fn(inputs, pipeline, unet, vae)` (e.g. `ldiffusion_augment`) once over `dataloader` -- batches
+        (inputs, masks, _) -- under no_grad, keep the augmented inputs and the masks on the host, and serve them from a shuffling
+        TensorDataset loader of `batch_size`.  `category` only labels the reference's progress bar."""
+        from torch.utils.data import DataLoader, TensorDataset
+        all_aug_inputs, all_masks = [], []
+        for inputs, masks, _ in dataloader:
+            inputs, masks = inputs.to(device), masks.to(device)
+            with torch.no_grad():
+                aug_inputs = augment_fn(inputs, pipeline, unet, vae)
+            all_aug_inputs.append(aug_inputs.cpu())
+            all_masks.append(masks.cpu())
+        dataset = TensorDataset(torch.cat(all_aug_inputs, dim=0), torch.cat(all_masks, dim=0))
+        return DataLoader(dataset, batch_size=batch_size, shuffle=True, num_workers=num_workers)
+
     @torch.no_grad()
     def ldiffusion_augment(self, inputs, pipeline, unet, vae, text_embeddings=None):
         """segmentor.py:86-112, batched: encode mean -> set_timesteps(1) -> one UNet pass -> step -> decode -> uint8 ->

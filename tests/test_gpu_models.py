@@ -795,6 +795,29 @@ def test_segmentor_mirror_augment_against_reference_fixture(tiny):
         seg.inference_cell_model("x.png", "sd", "w", None)     # no head: refuses instead of substituting one
 
 
+def test_segmentor_mirror_build_augmented_dataloader(tiny):
+    """segmentor.py:144-161 through the mirror: the augmented inputs of every batch (here: `ldiffusion_augment` itself, the reference's
+    caller passes it as `augment_fn`) and the masks, cached on the host and served by a shuffling loader of the requested batch size."""
+    from functools import partial
+    from ldiffusion_amd.segmentor import Segmentor
+    g = torch.Generator().manual_seed(12)
+    ctx = (torch.randn((1, 6, 64), generator=g) * 0.5).to(DEV)
+    batches = [(torch.rand((n, 3, 64, 64), generator=g), torch.randint(0, 3, (n, 64, 64), generator=g), None) for n in (2, 1, 2)]
+    seg = Segmentor(None, None, "cell", 3)
+    aug = partial(seg.ldiffusion_augment, text_embeddings=ctx)
+    torch.manual_seed(0)
+    loader = seg.build_augmented_dataloader(batches, aug, tiny["pipe"], tiny["unet"], tiny["vae"], DEV, batch_size=2, category="train")
+    got = list(loader)
+    assert [len(b[0]) for b in got] == [2, 2, 1] and all(not b[0].is_cuda and b[0].shape[1:] == (3, 1024, 1024) for b in got)
+    want_x = torch.cat([aug(x, tiny["pipe"], tiny["unet"], tiny["vae"]).cpu() for x, _, _ in batches])
+    want_m = torch.cat([m for _, m, _ in batches])
+    xs, ms = torch.cat([b[0] for b in got]), torch.cat([b[1] for b in got])
+    key = lambda m: tuple(m.reshape(-1)[:64].tolist())            # the masks identify the samples whatever the shuffle did
+    order = [[key(m) for m in want_m].index(key(m)) for m in ms]
+    assert sorted(order) == list(range(5))
+    assert torch.equal(xs, want_x[order]) and torch.equal(ms, want_m[order])
+
+
 def test_segmentor_mirror_inference_cell_model_end_to_end(tiny, tmp_path):
     """segmentor.py:490-545 through the mirror: checkpoint directories in the diffusers layout -> load_ldiffusion -> 1024x1024
     single pass -> decoded RGB handed to the head ON THE DEVICE -> arg-max -> NEAREST resize to the input size."""

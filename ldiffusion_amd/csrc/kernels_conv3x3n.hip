@@ -153,8 +153,27 @@ __global__ __launch_bounds__(256, 3) void conv3x3n_kernel(const ConvParams p) { 
     if (oy >= p.Hout || ox >= p.Wout) continue;
     const long long row = ((long long)b * p.Hout + oy) * p.Wout + ox;
     const f32x4 v = acc[m] + (f32x4){bb.x, bb.y, bb.z, bb.w};
-    if (p.out_f32) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.y) + row * p.ldy) = v;
-    else *reinterpret_cast<f16x4*>(reinterpret_cast<f16*>(p.y) + row * p.ldy) = cvt4(v);
+    if (!p.post_only) {
+      if (p.out_f32) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.y) + row * p.ldy) = v;
+      else *reinterpret_cast<f16x4*>(reinterpret_cast<f16*>(p.y) + row * p.ldy) = cvt4(v);
+    }
+    if (p.post_img || p.post_rgb || p.post_luma) {   // the decode_latents tail on the fp32 sums, operation for operation as decode_post_kernel
+      unsigned q[3];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        float u = __fadd_rn(__fmul_rn(v[c], 0.5f), 0.5f);
+        u = fminf(fmaxf(u, 0.f), 1.f);
+        if (v[c] != v[c]) u = v[c];   // clamp propagates NaN in torch
+        if (p.post_img) p.post_img[row * 3 + c] = u;
+        q[c] = (unsigned)(int)rintf(__fmul_rn(u, 255.0f));
+      }
+      if (p.post_rgb) { p.post_rgb[row * 3 + 0] = (uint8_t)q[0]; p.post_rgb[row * 3 + 1] = (uint8_t)q[1]; p.post_rgb[row * 3 + 2] = (uint8_t)q[2]; }
+      if (p.post_luma) {
+        const long long hw = (long long)p.Hout * p.Wout;
+        p.post_luma[((long long)b * p.post_slots + p.post_slot) * hw + (long long)oy * p.Wout + ox] =
+            (uint8_t)((19595u * q[0] + 38470u * q[1] + 7471u * q[2] + 0x8000u) >> 16);
+      }
+    }
   }
 }
 

@@ -95,6 +95,9 @@ struct ConvOpts {
   int ldy = 0;                  // fp16 output channel stride (default N stored rounded up to 8)
   bool want_stats = false;      // also emit GroupNorm partial statistics of the output (consumed by Exec::gn)
   bool geglu = false;           // apply x * gelu(gate) in the epilogue (weights must be MatW::geglu); output has N/2 channels
+  // decode_latents tail in the epilogue (VAE conv_out): applied iff the narrow-output kernel takes the launch; *post_done says whether it did
+  float* post_img = nullptr; uint8_t* post_rgb = nullptr; uint8_t* post_luma = nullptr; int post_slots = 0, post_slot = 0; bool post_only = false;
+  bool* post_done = nullptr;
 };
 
 class Exec {

@@ -367,6 +367,13 @@ Act Exec::conv(const MatW& w, const Act& x, const Act* x2, const ConvOpts& o) {
   } else if (o.out_f32) {
     LDIFF_CHECK(!o.split_out, LDIFF_ERR_INVALID, "conv: fp32 output cannot be split");
     p.y = o.out_f32; p.ldy = o.ldy_f32; p.out_f32 = 1;
+    if (o.post_done) {   // fused only where the narrow-output kernel runs (it is the one epilogue that knows the tail)
+      ConvParams t = p;
+      t.splitk = 1;
+      const bool fused = conv3x3_eligible(t) && conv3x3n_selected(t);
+      *o.post_done = fused;
+      if (fused) { p.post_img = o.post_img; p.post_rgb = o.post_rgb; p.post_luma = o.post_luma; p.post_slots = o.post_slots; p.post_slot = o.post_slot; p.post_only = o.post_only ? 1 : 0; }
+    }
   } else {
     const int C = o.ldy ? o.ldy : (o.split_out ? roundup(p.N, 4) : roundup(p.N, 8));
     y = new_act(x.B, p.Hout, p.Wout, C, o.split_out);
@@ -1109,22 +1116,29 @@ void ldiff_vae::decode(const float* z, int B, int h, int w, float z_scale, float
   GNss g = ex().gn(cur, nullptr, d_norm_out, cfg.norm_num_groups, 1e-6f);
   const int Nst = 4;
   float* o32 = ex().tmp<float>((size_t)B * H * W * Nst);
+  const bool want_post = image_nhwc || rgb || luma;
+  LDIFF_CHECK(!want_post || cfg.out_channels == 3, LDIFF_ERR_INVALID, "vae_decode: image outputs need 3 output channels");
+  bool post_done = false;
+  auto post = [&](ConvOpts& o) {   // the decode_latents tail inside conv_out's epilogue; the fp32 tensor only if `sample` is wanted too
+    if (!want_post) return;
+    o.post_img = image_nhwc; o.post_rgb = rgb; o.post_luma = luma; o.post_slots = n_slots; o.post_slot = slot; o.post_only = sample_nchw == nullptr;
+    o.post_done = &post_done;
+  };
   if (full) {
     Act a = ex().norm_apply(cur, nullptr, g, true, true);
     ConvOpts o; o.split_in = true; o.out_f32 = o32; o.ldy_f32 = Nst;
+    post(o);
     ex().conv(d_conv_out, a, nullptr, o);
     ex().release(a);
   } else {
     ConvOpts o; o.gn = &g; o.silu = 1; o.out_f32 = o32; o.ldy_f32 = Nst;
+    post(o);
     ex().conv(d_conv_out, cur, nullptr, o);
   }
   ex().release(g);
   ex().release(cur);
   if (sample_nchw) launch_nhwc_f32_to_nchw_f32(o32, sample_nchw, B, cfg.out_channels, H, W, Nst, s);
-  if (image_nhwc || rgb || luma) {
-    LDIFF_CHECK(cfg.out_channels == 3, LDIFF_ERR_INVALID, "vae_decode: image outputs need 3 output channels");
-    launch_decode_post(o32, Nst, B, H, W, image_nhwc, rgb, luma, n_slots, slot, s);
-  }
+  if (want_post && !post_done) launch_decode_post(o32, Nst, B, H, W, image_nhwc, rgb, luma, n_slots, slot, s);
   ex().arena.free(o32);
 }
 

@@ -1063,3 +1063,30 @@ def test_train_ldiffusion_mirror_end_to_end(tiny, tmp_path):
     print(f"  eager loop: epoch losses {[round(float(r[1]), 4) for r in rows2[1:]]}")
     for a, b in zip(rows[1:], rows2[1:]):
         assert abs(float(a[1]) - float(b[1])) <= 2e-3 * abs(float(b[1])), (a, b)
+
+
+@pytest.mark.parametrize("prec", [0, 2])
+def test_decode_tail_fused_into_conv_out(tiny, prec):
+    """decode_latents' tail ((x/2+0.5).clamp(0,1) -> (.*255).round() half-even -> PIL's integer luma) runs inside the epilogue of
+    the VAE's conv_out (narrow-output kernel), from its fp32 sums.  With every output requested the fp32 tensor is written too: the image,
+    uint8 and luma outputs must be, bit for bit, what the tensor formulation makes of that tensor; and the call that asks for the uint8
+    outputs only (no fp32 tensor at all: the sampler's feature path) must return the same bytes."""
+    vae = tiny["vae"]
+    vae.set_precision(decoder=prec)
+    try:
+        g = torch.Generator().manual_seed(4 + prec)
+        z = (torch.randn((3, 4, 16, 24), generator=g) * 1.5).to(DEV)
+        luma = torch.full((3, 2, 128, 192), 7, dtype=torch.uint8, device=DEV)
+        sample, image, rgb = vae._decode(z, 1.0 / 0.18215, want_sample=True, want_image=True, want_rgb=True, luma=luma, slot=1)
+        x = sample.permute(0, 2, 3, 1)
+        want_img = (x * 0.5 + 0.5).clamp(0, 1)
+        want_rgb = (want_img * 255.0).round().to(torch.uint8)
+        q = want_rgb.to(torch.int64)
+        want_luma = ((19595 * q[..., 0] + 38470 * q[..., 1] + 7471 * q[..., 2] + 0x8000) >> 16).to(torch.uint8)
+        assert torch.equal(image, want_img) and torch.equal(rgb, want_rgb)
+        assert torch.equal(luma[:, 1], want_luma) and bool((luma[:, 0] == 7).all())
+        luma2 = torch.zeros_like(luma)
+        _, _, rgb2 = vae._decode(z, 1.0 / 0.18215, want_rgb=True, luma=luma2, slot=0)
+        assert torch.equal(rgb2, rgb) and torch.equal(luma2[:, 0], want_luma)
+    finally:
+        vae.set_precision(decoder=0)

@@ -82,6 +82,7 @@ struct ConvParams {
   // decode_latents tail fused into the epilogue (narrow-output kernel only, conv3x3n_selected): from the fp32 sums (x/2+0.5).clamp(0,1) -> post_img
   // [M,3] f32, (.*255).round() half-even -> post_rgb [M,3] u8, ITU-601 integer luma -> post_luma[b, post_slot, pixel] (kernels_elem.hip decode_post)
   float* post_img = nullptr; uint8_t* post_rgb = nullptr; uint8_t* post_luma = nullptr; int post_slots = 0, post_slot = 0, post_only = 0;   // post_only: y is not written
+  int short_runs = 0;   // set by the executor of a graph that shares the chip with another stream (the VAE decoder beside the UNet): persistent kernels cap their run length
   unsigned div_tm; int tiles_m, img_fast;   // conv3x3 halo-tile kernels, set by their launchers: pixel tiles of the launch; tile order (see conv3x3_img_fast)
   const f16* w_frag;      // conv3x3 dataflow kernel only (conv3x3d_selected): the weights fragment-packed by launch_pack_frag_weights
 };

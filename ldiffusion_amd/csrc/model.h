@@ -108,6 +108,7 @@ class Exec {
   size_t gn_partial_cap = 0;
   std::vector<void*> owned;   // lazily built derived weights (parity weights of the upsampler convs)
   const int* weights_gen = nullptr;   // -> WeightStore::generation of the owning model
+  bool short_runs = false;            // this graph runs beside another stream's (ConvParams::short_runs)
   ~Exec();
   void ensure_gn_partial(size_t bytes);
   Act new_act(int B, int H, int W, int C, bool split = false);

@@ -395,6 +395,7 @@ Act Exec::conv(const MatW& w, const Act& x, const Act* x2, const ConvOpts& o) {
   }
   if (!o.out_f32 && p.splitk > 1) p.splitk_ws = tmp<float>((size_t)p.splitk * p.M * p.N);
   else p.splitk = 0;
+  p.short_runs = short_runs ? 1 : 0;
   if (!o.split_in && conv3x3_eligible(p) && conv3x3d_selected(p)) p.w_frag = derived_frag(w, p);   // dataflow kernel: MFMA-fragment-packed weights
   launch_igemm(p, s);
   if (p.splitk_ws) arena.free(p.splitk_ws);   // stream-ordered reuse: safe once the launches are enqueued
@@ -920,6 +921,7 @@ void ldiff_vae::wait_side(hipStream_t s) {
 
 void ldiff_vae::build() {
   ex_dec.weights_gen = &ws.generation;
+  ex_dec.short_runs = true;   // the sampler decodes on a side stream beside the next UNet pass; the encoder has the chip to itself
   ex_enc.weights_gen = &ws.generation;
   const int nb = cfg.n_blocks, lpb = cfg.layers_per_block, lat = cfg.latent_channels;
   const int* boc = cfg.block_out_channels;

@@ -366,7 +366,9 @@ int ldiff_sample(ldiff_pipeline* p, const void* images, int B, int H, int W, int
         HIP_CHECK(hipStreamWaitEvent(sd, p->ev_latents, 0));   // also orders the first decode behind the encode (same VAE workspace)
         zdec = snap;
       }
+      v->ex_dec.short_runs = overlap;   // beside the next UNet pass: persistent conv kernels walk short runs (ConvParams::short_runs); alone on the chip: one workgroup per CU
       v->decode(zdec, B, h, w, 1.0f / v->cfg.scaling_factor, nullptr, nullptr, last ? (uint8_t*)rgb_u8 : nullptr, (uint8_t*)features_u8, nts, i, sd);
+      v->ex_dec.short_runs = false;
       decoded_any = true;
     }
   }

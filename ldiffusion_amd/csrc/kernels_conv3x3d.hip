@@ -679,13 +679,13 @@ void launch_c3d(const ConvParams& p, hipStream_t s) {
   auto kern = conv3x3d_kernel<FLAGS>;
   ensure_dyn_smem(reinterpret_cast<const void*>(kern), (int)D_LDS);
   const int units = p.B * (p.Hout >> 4) * (p.Wout >> 4) * (p.N >> 7);
-  // Run length (units per workgroup): 2 where the executor says its graph shares the chip (the VAE decoder), else 0 = one workgroup per CU
-  // walking its whole share; LDIFF_C3D_RUN overrides.  The kernel alone is
+  // Run length (units per workgroup): 1 where the executor says its graph shares the chip (the sampler's decode beside the next UNet pass),
+  // else 0 = one workgroup per CU walking its whole share; LDIFF_C3D_RUN overrides.  The kernel alone is
   // fastest fully persistent (0.43 of the MFMA peak against 0.42), but the sampler decodes on a side stream beside the next UNet pass, and a
   // workgroup that holds a CU for half a millisecond keeps that pass's kernels out: measured on the whole step (8 patches, 5 passes)
   // 175.7 ms fully persistent, 175.1 / 174.7 / 171.6 ms at 8 / 4 / 2 units per workgroup, 178.2 ms with the 8x16 kernel.
-  static const int run_env = [] { const char* e = getenv("LDIFF_C3D_RUN"); return e ? atoi(e) : -1; }();   // -1: 2 units where the graph shares the chip (ConvParams::short_runs), else persistent
-  const int run_cap = run_env >= 0 ? run_env : (p.short_runs ? 2 : 0);
+  static const int run_env = [] { const char* e = getenv("LDIFF_C3D_RUN"); return e ? atoi(e) : -1; }();   // -1: 1 unit where the graph shares the chip (ConvParams::short_runs), else persistent
+  const int run_cap = run_env >= 0 ? run_env : (p.short_runs ? 1 : 0);   // (whole step, same box: 171.1 ms at 2 units, 169.6 at 1, 172.0 at 3)
   int grid = units < d_num_cus() ? units : d_num_cus();
   if (run_cap > 0 && units > grid * run_cap) grid = (units + run_cap - 1) / run_cap;
   const double bytes = (double)p.B * p.Hin * p.Win * p.C1 * 2.0 + (double)p.N * p.K * 2.0 + (double)p.M * p.N * 2.0 + (p.res ? (double)p.M * p.N * 2.0 : 0.0);

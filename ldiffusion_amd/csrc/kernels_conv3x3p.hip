@@ -611,8 +611,8 @@ void launch_c3p(const ConvParams& p, hipStream_t s) {
   const int total = p.B * ((Ht + 15) / 16) * ((Wt + 15) / 16) * ntn * (PAR ? 4 : 1);
   // persistent: one workgroup per CU walks the tile list (stride % 8 == 0); LDIFF_C3P_RUN = n > 0 caps a workgroup's walk at n tiles (more,
   // shorter workgroups: the decode side stream then leaves CUs to the UNet stream more often, as LDIFF_C3D_RUN does for the dataflow kernel)
-  static const int run_env = [] { const char* e = getenv("LDIFF_C3P_RUN"); return e ? atoi(e) : -1; }();   // -1: 2 tiles where the graph shares the chip, else persistent
-  const int run_cap = run_env >= 0 ? run_env : (p.short_runs ? 2 : 0);   // (whole step, same box: 176.5 ms persistent, 175.0 / 175.5 / 176.1 at 2 / 4 / 8 tiles)
+  static const int run_env = [] { const char* e = getenv("LDIFF_C3P_RUN"); return e ? atoi(e) : -1; }();   // -1: 1 tile where the graph shares the chip, else persistent
+  const int run_cap = run_env >= 0 ? run_env : (p.short_runs ? 1 : 0);   // (whole step, same box: 176.5 ms persistent, 175.0 / 175.5 / 176.1 at 2 / 4 / 8 tiles)
   int grid = total <= c3p_num_cus() ? total : (c3p_num_cus() & ~7);
   if (run_cap > 0 && total > grid * run_cap) grid = ((total + run_cap - 1) / run_cap + 7) & ~7;
   static const std::string pname = std::string("conv3x3<16x16,") + std::to_string(BN) + ">";

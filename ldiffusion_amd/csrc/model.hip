@@ -921,7 +921,6 @@ void ldiff_vae::wait_side(hipStream_t s) {
 
 void ldiff_vae::build() {
   ex_dec.weights_gen = &ws.generation;
-  ex_dec.short_runs = true;   // the sampler decodes on a side stream beside the next UNet pass; the encoder has the chip to itself
   ex_enc.weights_gen = &ws.generation;
   const int nb = cfg.n_blocks, lpb = cfg.layers_per_block, lat = cfg.latent_channels;
   const int* boc = cfg.block_out_channels;

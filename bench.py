@@ -50,6 +50,7 @@ def parse():
     ap.add_argument("--no-prof", action="store_true", help="skip the per-launch HIP-event profile")
     ap.add_argument("--no-unet-step", action="store_true", help="skip the separate UNet-step timing (used under rocprofv3 so that the\n                    kernel mix of the whole process equals the mix of the timed region)")
     ap.add_argument("--launch-check", action="store_true", help="rendezvous only (gloo, no GPU): every rank joins, all-reduces its rank and rank 0 prints\n                    {launch_check, n_gpus}; covers the self-launch / env contract on a CPU box")
+    ap.add_argument("--no-pipeline", action="store_true", help="one batch in flight: every step joins its own decodes before the next one is enqueued")
     ap.add_argument("--tiny", action="store_true", help="reduced-width graph + 64x64 patches (plumbing check only; not a valid bench line)")
     return ap.parse_args()
 
@@ -197,12 +198,30 @@ def main():
     def step():
         return finish(sampler.sample(images, ctx, N_PASSES, want_features=True, want_rgb=True))
 
+    sampler2 = LaplaceSampler(pipe)   # a second pipeline over the SAME UNet / VAE handles: its own latent / feature buffers
+
     def run_steps(n):
-        # (Deferring the side-stream join across batches -- ldiff_pipeline_set_overlap mode 2, batch k+1 enqueued before batch k
-        # is joined -- was measured at +0.5-0.9 % and is not used here: every step joins its own decodes.)
+        """n steps (batches).  Default: two batches in flight -- the side-stream join is deferred (ldiff_pipeline_set_overlap mode 2), batch
+        k + 1 is enqueued before batch k is joined and finished, so the trailing decodes of batch k run beside the encode and the first UNet
+        pass of batch k + 1 instead of alone (same work, same results: scripts/bench_pipelined.py, +1.6 ... +2.0 % since the persistent conv
+        kernels yield after every unit).  Every batch is joined and finished inside the call.  --no-pipeline: every step joins its own decodes."""
         m = None
-        for _ in range(n):
-            m = step()
+        if args.no_pipeline or n < 2:
+            for _ in range(n):
+                m = step()
+            return m
+        sampler.set_overlap(2); sampler2.set_overlap(2)
+        prev = None
+        for i in range(n):
+            sp = (sampler, sampler2)[i & 1]
+            out = sp.sample(images, ctx, N_PASSES, want_features=True, want_rgb=True)
+            if prev is not None:
+                prev[0].join()
+                m = finish(prev[1])
+            prev = (sp, out)
+        prev[0].join()
+        m = finish(prev[1])
+        sampler.set_overlap(1); sampler2.set_overlap(1)
         return m
 
     def sync():
@@ -285,7 +304,8 @@ def main():
         "config": {"workload": f"BASELINE.json configs[1]: {PATCHES_PER_GPU} patches/GPU of {img}x{img}, {N_PASSES}-pass Laplace/PLMS sampler, "
                                f"SD-v1.5-size UNet (859.5M) + VAE, seeded synthetic weights, ctx L=6; +linear-probe argmax mask"
                                + (", RCCL all-gather of masks" if world > 1 else ""),
-                   "patches_per_gpu": PATCHES_PER_GPU, "image": img, "n_passes": N_PASSES, "parallelism": f"dp{world} (patch sharding)"},
+                   "patches_per_gpu": PATCHES_PER_GPU, "image": img, "n_passes": N_PASSES, "parallelism": f"dp{world} (patch sharding)",
+                   "batches_in_flight": 1 if (args.no_pipeline or args.steps < 2) else 2},
     }
     result["config"]["precision"] = ("split residual stream (fp16 hi|lo), fp16 MFMA operands, fp32 accumulate; UNet mode 1, VAE encoder "
                                      "mode 2, decoder mode 0 (include/ldiff.h ldiff_unet_set_precision): latents within 1e-3 of the fp32 oracle, "
@@ -306,7 +326,10 @@ def main():
                               "algorithmic_GBps": dom["bytes"] / (dom["ms"] * 1e-3) / 1e9,
                               "share_of_profiled_time": next(r["ms"] for r in rows_all if r["name"] == dom["name"]) / tot_ms,
                               "measured": f"HIP events on the launch stream around its {dom['launches']} launches in the timed region, where the VAE "
-                                          "decode (side stream) shares the chip with the next UNet pass: durations include that sharing"}
+                                          "decode (side stream) shares the chip with the next UNet pass and, with two batches in flight, with the next "
+                                          "batch's encode; its workgroups retire after one unit there ON PURPOSE (ConvParams::short_runs), handing CUs to the "
+                                          "other stream: a launch's wall time inside the shared region is the sharing, not the kernel (the step got "
+                                          "shorter as this number fell: DESIGN.md section 7); `serial` is the kernel alone on the chip"}
         ser = next(r for r in rows_all if r["name"] == dom["name"])
         sa = ser["flops"] / (ser["ms"] * 1e-3) / 1e12
         result["roofline"]["serial"] = {"achieved": sa, "frac": sa / MFMA_PEAK_TFLOPS, "avg_launch_us": 1e3 * ser["ms"] / ser["launches"],

@@ -171,7 +171,7 @@ def main():
     from ldiffusion_amd import _lib, configs, weights
     from ldiffusion_amd.models import AutoencoderKL, UNet2DConditionModel
     from ldiffusion_amd.parallel import gather_masks, shard_range
-    from ldiffusion_amd.pipeline import LaplaceSampler, StableDiffusionImg2ImgPipeline, argmax_mask
+    from ldiffusion_amd.pipeline import LaplaceSampler, StableDiffusionImg2ImgPipeline, probe_argmax_mask
 
     ucfg, vcfg = (configs.TINY_UNET, configs.TINY_VAE) if args.tiny else (configs.SD15_UNET, configs.SD15_VAE)
     img = 64 if args.tiny else IMG
@@ -191,8 +191,9 @@ def main():
     head_b = (0.1 * torch.randn(N_CLASSES, generator=hg)).to(dev)
 
     def finish(out):
-        logits = torch.einsum("cn,bnhw->bchw", head_w, out["features"].float() * (1.0 / 255.0)) + head_b[None, :, None, None]
-        mask = argmax_mask(logits)
+        # mask tail: linear probe over the uint8 per-pixel latent vectors + arg-max, ONE library launch (ldiff_probe_argmax_u8): no
+        # vendor-library or ATen kernel runs inside the timed steps
+        mask = probe_argmax_mask(out["features"], head_w, head_b, 1.0 / 255.0)
         return gather_masks(mask, total) if world > 1 else mask
 
     def step():
@@ -267,6 +268,17 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
     assert masks.shape[0] == total and masks.dtype == torch.uint8
+    # result check (untimed): the masks of the LAST timed step (two batches in flight, deferred joins, persistent conv kernels on short
+    # runs) against one more step with everything on one stream and one batch in flight -- same inputs, so bit for bit
+    import zlib
+    sampler.set_overlap(0)
+    ref_masks = step()
+    sampler.set_overlap(1)
+    torch.cuda.synchronize()
+    checked = bool(torch.equal(masks, ref_masks))
+    masks_crc = zlib.crc32(masks.cpu().numpy().tobytes()) & 0xFFFFFFFF
+    if not checked:
+        raise SystemExit(f"bench: the pipelined step's masks differ from the serial step's ({int((masks != ref_masks).sum())} pixels)")
 
     # ---- UNet step alone (the metric's second half: UNet-step HBM GB/s vs peak), HIP events on the launch stream ----
     unet_ms = unet_eager_ms = None
@@ -310,6 +322,13 @@ def main():
     result["config"]["precision"] = ("split residual stream (fp16 hi|lo), fp16 MFMA operands, fp32 accumulate; UNet mode 1, VAE encoder "
                                      "mode 2, decoder mode 0 (include/ldiff.h ldiff_unet_set_precision): latents within 1e-3 of the fp32 oracle, "
                                      "uint8 features within one grey level")
+    result["checked"] = checked
+    result["check"] = {"masks_crc32": f"{masks_crc:08x}", "classes_present": int(masks.max().item()) + 1,
+                       "how": "masks of the last timed step == masks of an extra untimed step on ONE stream with one batch in flight (bit for bit); "
+                              "the same configuration against the fp32 CPU oracle: tests/test_gpu_models.py::test_config1_b8_bench_mode_against_oracle"}
+    if dist is not None:
+        result["comm"] = {"backend": dist.get_backend(), "world_size": dist.get_world_size(),
+                          "collective": "all_gather_into_tensor of uint8 masks, once per step (ldiffusion_amd/parallel.py gather_masks)"}
     if not args.tiny:
         sf = total * PATCH_FLOP / elapsed * args.steps / 1e12 / world   # algorithmic TFLOP/s per GPU over the whole timed region
         result["step"] = {"algorithmic_tflops_per_gpu": sf, "mfma_frac": sf / MFMA_PEAK_TFLOPS,

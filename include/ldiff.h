@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define LDIFF_VERSION 130 /* 0.1.3: + ldiff_op_infonce, ldiff_window_accumulate, ldiff_op_pack_weight_multi; dataflow conv3x3 kernel behind ldiff_op_conv */
+#define LDIFF_VERSION 140 /* 0.1.4: + ldiff_probe_argmax_u8 */
 #define LDIFF_MAX_BLOCKS 8
 
 typedef enum { LDIFF_OK = 0, LDIFF_ERR_INVALID = -1, LDIFF_ERR_RUNTIME = -2, LDIFF_ERR_STATE = -3 } ldiff_status;
@@ -141,6 +141,13 @@ int ldiff_pndm_alphas_cumprod(float* out_host, int n);
 int ldiff_laplace_add(const void* z0, float scale, const void* u_or_null, uint64_t seed, uint64_t offset, void* out, int64_t n, void* stream);
 /* logits [B,C,H,W] f32 -> mask [B,H,W] u8 = argmax over C  (segmentor.py:536-537) */
 int ldiff_argmax_u8(const void* logits, int B, int C, int H, int W, void* mask_u8, void* stream);
+/* Mask tail over the per-pixel latent vectors in ONE launch: features [B,N,H,W] u8 (the N luma planes of a pixel are its latent vector,
+ * pixel_latent_vector.py:85-93), weight [C,N] f32, bias [C] f32 or NULL -> mask [B,H,W] u8 = first argmax_c of
+ *   logit_c = bias_c + sum_n weight[c,n] * (feature_n * scale)      (argmax(softmax(.)): segmentor.py:536-537)
+ * with the arithmetic pinned (float32, x_n = fl(f_n * scale), acc = bias_c, acc = fl(acc + fl(w * x_n)) in plane order, no fused multiply-add)
+ * so that a host statement reproduces the mask bit for bit (oracle/noise_post.py probe_argmax).  C <= 32, N <= 64, H*W % 4 == 0. */
+int ldiff_probe_argmax_u8(const void* features_u8, int B, int N, int H, int W, const void* weight, const void* bias_or_null, float scale, int C, void* mask_u8,
+                          void* stream);
 /* One tile of a sliding-window / tile merge: acc[:, y0:y0+th, x0:x0+tw] += pred * weight;  cnt[y0:.., x0:..] += weight (weight NULL: 1)
  * acc [C,H,W], cnt [H,W], pred [C,th,tw], weight [th,tw]; dtypes 0: all float32, 1: all float16, 3: float16 accumulators and weight with a
  * float32 prediction (the product then stays float32, as type promotion makes it); product and sum rounded separately, as the tensor
@@ -203,6 +210,8 @@ typedef struct {
   int ld1, ld2;                                     /* row pitch (elements) of x / x2; 0 = C1 / C2 */
   int res_lo;                                       /* > 0: res is a split tensor (value = hi + lo), lo half res_lo elements after the hi half */
   int y_lo;                                         /* > 0: write y split: hi at column n, lo = f16(v - hi) at column y_lo + n */
+  int short_runs;                                   /* 1: the persistent conv kernels retire a workgroup after ONE unit / tile (what ldiff_sample sets for the VAE
+                                                       decodes that run beside the next UNet pass); 0: one workgroup per CU walks its whole share */
 } ldiff_conv_args;
 int ldiff_op_conv(const ldiff_conv_args*, void* stream);
 /* row blocks per image the launch would emit statistics for (0 = unsupported for this shape) */

@@ -35,7 +35,7 @@ class ConvArgs(C.Structure):
                 ("gn_scale", C.c_void_p), ("gn_shift", C.c_void_p), ("silu_in", C.c_int),
                 ("bias", C.c_void_p), ("temb", C.c_void_p), ("ld_temb", C.c_int),
                 ("res", C.c_void_p), ("ld_res", C.c_int), ("y", C.c_void_p), ("ldy", C.c_int), ("out_f32", C.c_int), ("stats", C.c_void_p),
-                ("geglu", C.c_int), ("ld1", C.c_int), ("ld2", C.c_int), ("res_lo", C.c_int), ("y_lo", C.c_int)]
+                ("geglu", C.c_int), ("ld1", C.c_int), ("ld2", C.c_int), ("res_lo", C.c_int), ("y_lo", C.c_int), ("short_runs", C.c_int)]
 
 
 # name -> (restype, argtypes); every symbol include/ldiff.h declares
@@ -67,6 +67,7 @@ SIGNATURES = {
     "ldiff_pndm_coeffs": (I, [F, F, C.POINTER(F), C.POINTER(F)]),
     "ldiff_laplace_add": (I, [P, F, P, U64, U64, P, I64, P]),
     "ldiff_argmax_u8": (I, [P, I, I, I, I, P, P]),
+    "ldiff_probe_argmax_u8": (I, [P, I, I, I, I, P, P, F, I, P, P]),
     "ldiff_window_accumulate": (I, [P, P, P, P, I, I, I, I, I, I, I, I, P]),
     "ldiff_luma_float": (I, [P, P, I, I, I, P]),
     "ldiff_bilinear_resize": (I, [P, P, I, I, I, I, I, I, P]),

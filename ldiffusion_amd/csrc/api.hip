@@ -193,6 +193,15 @@ int ldiff_argmax_u8(const void* logits, int B, int C, int H, int W, void* mask_u
   launch_argmax_u8((const float*)logits, B, C, H, W, (uint8_t*)mask_u8, (hipStream_t)stream);
   API_END
 }
+int ldiff_probe_argmax_u8(const void* features_u8, int B, int N, int H, int W, const void* weight, const void* bias_or_null, float scale, int C, void* mask_u8,
+                          void* stream) {
+  API_BEGIN
+  LDIFF_CHECK(B >= 0 && H >= 0 && W >= 0, LDIFF_ERR_INVALID, "probe_argmax: negative extent");
+  if ((long long)B * H * W == 0) return LDIFF_OK;
+  LDIFF_CHECK(features_u8 && weight && mask_u8, LDIFF_ERR_INVALID, "probe_argmax: null pointer");
+  launch_probe_argmax_u8((const uint8_t*)features_u8, B, N, H, W, (const float*)weight, (const float*)bias_or_null, scale, C, (uint8_t*)mask_u8, (hipStream_t)stream);
+  API_END
+}
 int ldiff_window_accumulate(void* acc, void* cnt, const void* pred, const void* weight_or_null, int C, int H, int W, int th, int tw, int y0, int x0, int dtypes,
                             void* stream) {
   API_BEGIN
@@ -421,6 +430,7 @@ static void conv_args_to_params(const ldiff_conv_args* a, ConvParams& p) {
   p.res = (const f16*)a->res; p.ld_res = a->ld_res;
   p.y = a->y; p.ldy = a->ldy; p.out_f32 = a->out_f32;
   p.ld1 = a->ld1; p.ld2 = a->ld2; p.res_lo = a->res_lo; p.y_lo = a->y_lo;
+  p.short_runs = a->short_runs != 0;
   p.M = a->B * a->Hout * a->Wout;
   p.stats = (float*)a->stats;
   p.geglu = a->geglu != 0;

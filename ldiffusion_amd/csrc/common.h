@@ -165,6 +165,7 @@ void launch_decode_post(const float* x, int ldx, int B, int H, int W, float* img
                         uint8_t* rgb_u8 /*[B,H,W,3] or null*/, uint8_t* luma /*base of [B,N,H,W] or null*/, int n_slots, int slot,
                         hipStream_t s);
 void launch_argmax_u8(const float* logits, int B, int C, int H, int W, uint8_t* mask, hipStream_t s);
+void launch_probe_argmax_u8(const uint8_t* feat, int B, int N, int H, int W, const float* w, const float* bias, float scale, int C, uint8_t* mask, hipStream_t s);
 void launch_fold_gn_weights(const f16* w, const float* bias, const float* scale, const float* shift, f16* wb, float* biasb, int B, int Nrows, int C,
                             hipStream_t s);
 void launch_bilinear_resize(const float* x, float* y, int B, int C, int H, int W, int oh, int ow, hipStream_t s);

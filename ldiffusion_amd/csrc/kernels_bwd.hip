@@ -339,7 +339,10 @@ void launch_attn_bwd(const AttnParams& p, const f16* dO, f16* dq, f16* dk, f16* 
   if (p.B == 0) return;
   size_t smem = (size_t)2 * p.Lq * p.Lk * sizeof(float);
   const size_t stage = (size_t)2 * (p.Lq + p.Lk) * 33 * sizeof(unsigned);
-  const int staged = (smem + stage <= 150 * 1024 && p.d % 2 == 0 && p.ldq % 2 == 0 && p.ldk % 2 == 0 && p.ldv % 2 == 0 && p.ldo % 2 == 0) ? 1 : 0;
+  // the staged path reads q, k, v and dO as 32-bit words: head dim, row pitches AND batch strides even, base pointers 4-byte aligned
+  const bool even = p.d % 2 == 0 && p.ldq % 2 == 0 && p.ldk % 2 == 0 && p.ldv % 2 == 0 && p.ldo % 2 == 0 && p.q_bstride % 2 == 0 && p.kv_bstride % 2 == 0 &&
+                    p.o_bstride % 2 == 0 && (((size_t)p.q | (size_t)p.k | (size_t)p.v | (size_t)dO) & 3) == 0;
+  const int staged = (smem + stage <= 150 * 1024 && even) ? 1 : 0;
   if (staged) smem += stage;
   ensure_dyn_smem(reinterpret_cast<const void*>(attn_bwd_kernel), (int)smem);
   hipLaunchKernelGGL(attn_bwd_kernel, dim3(p.heads, p.B), dim3(256), smem, s, p.q, p.ldq, p.k, p.ldk, p.v, p.ldv, dO, p.ldo, dq, dk, dv, p.Lq, p.Lk, p.d,
@@ -526,7 +529,7 @@ __global__ __launch_bounds__(256) void infonce_kernel(const float* __restrict__ 
                                                       float* __restrict__ loss, float* __restrict__ dfeat) {
   extern __shared__ float lg[];   // K + 1 logits, then 2 x 4 reduction slots, then the anchor (n)
   const int t = blockIdx.x, tid = threadIdx.x;
-  const int T = t_dev ? *t_dev : T_arg;   // count from device memory: the launch (grid = capacity) is shape-stable, e.g. inside a captured graph
+  const int T = t_dev ? min(max(*t_dev, 0), T_arg) : T_arg;   // count from device memory, clamped to the capacity of the index arrays: the launch (grid = capacity) is shape-stable, e.g. inside a captured graph
   if (t >= T) return;
   const long long base = (long long)bi[t] * n * HW;
   float* red = lg + K + 1;

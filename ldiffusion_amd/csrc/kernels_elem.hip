@@ -292,6 +292,52 @@ void launch_argmax_u8(const float* logits, int B, int C, int H, int W, uint8_t* 
   HIP_CHECK(hipGetLastError());
 }
 
+// ---- mask tail over the per-pixel latent vectors: linear probe + argmax in ONE launch ------------------------------------------------
+// features u8 [B,N,H,W] (pixel_latent_vector.py:85-93: the N luma planes of a pixel are its latent vector) -> logits_c = bias_c +
+// sum_n w[c,n] * (f_n * scale) -> first maximal class (segmentor.py:536-537).  The arithmetic is fixed so that a host statement can
+// reproduce it bit for bit: x_n = fl(float(f_n) * scale); acc = bias_c; acc = fl(acc + fl(w[c,n] * x_n)) for n = 0..N-1 (no fused
+// multiply-add).  Four pixels per thread (one dword of every plane), weights in LDS.
+constexpr int PROBE_MAX_C = 32, PROBE_MAX_N = 64;
+__global__ __launch_bounds__(256) void probe_argmax_u8_kernel(const uint8_t* __restrict__ feat, int B, int N, long long HW, const float* __restrict__ w,
+                                                              const float* __restrict__ bias, float scale, int C, uint8_t* __restrict__ mask) {
+  __shared__ float sw[PROBE_MAX_C * PROBE_MAX_N + PROBE_MAX_C];
+  for (int i = threadIdx.x; i < C * N; i += blockDim.x) sw[i] = w[i];
+  for (int i = threadIdx.x; i < C; i += blockDim.x) sw[PROBE_MAX_C * PROBE_MAX_N + i] = bias ? bias[i] : 0.f;
+  __syncthreads();
+  const long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x, quads = HW / 4;   // HW % 4 == 0 (checked by the launcher)
+  if (q >= (long long)B * quads) return;
+  const int b = (int)(q / quads);
+  const long long pix = (q - (long long)b * quads) * 4;
+  const uint8_t* f = feat + (long long)b * N * HW + pix;
+  float best[4];
+  int bi[4] = {0, 0, 0, 0};
+  for (int c = 0; c < C; ++c) {
+    float acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] = sw[PROBE_MAX_C * PROBE_MAX_N + c];
+    for (int n = 0; n < N; ++n) {
+      const unsigned v = *reinterpret_cast<const unsigned*>(f + (long long)n * HW);   // L1/L2 resident after class 0
+      const float wv = sw[c * N + n];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[j] = __fadd_rn(acc[j], __fmul_rn(wv, __fmul_rn((float)((v >> (8 * j)) & 255u), scale)));
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (c == 0 || acc[j] > best[j]) { best[j] = acc[j]; bi[j] = c; }   // first maximal class, like torch.argmax (finite logits by construction)
+  }
+  *reinterpret_cast<unsigned*>(mask + (long long)b * HW + pix) = (unsigned)bi[0] | ((unsigned)bi[1] << 8) | ((unsigned)bi[2] << 16) | ((unsigned)bi[3] << 24);
+}
+void launch_probe_argmax_u8(const uint8_t* feat, int B, int N, int H, int W, const float* w, const float* bias, float scale, int C, uint8_t* mask, hipStream_t s) {
+  LDIFF_CHECK(C >= 1 && C <= PROBE_MAX_C && N >= 1 && N <= PROBE_MAX_N, LDIFF_ERR_INVALID, "probe_argmax: %d classes x %d planes out of range [1,%d] x [1,%d]", C, N,
+              PROBE_MAX_C, PROBE_MAX_N);
+  const long long HW = (long long)H * W;
+  LDIFF_CHECK(HW % 4 == 0 && ((size_t)feat & 3) == 0 && ((size_t)mask & 3) == 0, LDIFF_ERR_INVALID, "probe_argmax: H*W must be a multiple of 4 and the buffers 4-byte aligned");
+  const long long n = (long long)B * (HW / 4);
+  if (n == 0) return;
+  hipLaunchKernelGGL(probe_argmax_u8_kernel, dim3(nblocks(n)), dim3(256), 0, s, feat, B, N, HW, w, bias, scale, C, mask);
+  HIP_CHECK(hipGetLastError());
+}
+
 // ---- sliding-window / tile merge: logits[:, window] += pred * g;  n[window] += g  --------------------------------------------
 // (nnU-Net's predictor, model/nnunetv2/inference/predict_from_raw_data.py:563-570 as called from /root/reference/segmentor.py:388-488,
 // and the sampler's own tile merge of BASELINE configs[3]).  The arithmetic is the tensor formulation's, rounding for rounding: the

@@ -123,16 +123,11 @@ class LDiffusionModel:
                         gstep = T.GraphedStep(unet, dec, proj, B, ts, self.pipeline.scheduler.alphas_cumprod, latent_hw=latents.shape[-1],
                                               text_len=text_hidden.shape[1], text_dim=text_hidden.shape[2], max_triples=max(256, 64 * B),
                                               num_negatives=loss_obj.num_negatives, temperature=loss_obj.temperature)
-                    graphed = (gstep is not None and n_tr > 0 and B == gstep.hidden.shape[0] and ts == gstep.timesteps and n_tr <= gstep.bi.numel()
-                               and tuple(latents.shape[-2:]) == tuple(gstep.noisy[0].shape[-2:]) and text_hidden.shape[1] == gstep.hidden.shape[1])
-                    if n_tr == 0:
-                        pass                                          # no sample triples: the loss is a constant 0, nothing to step (as the eager path)
-                    elif graphed:
-                        total += T.train_step_graphed(gstep, latents, text_hidden, None, pairs, state, lr=1e-5, weight_decay=0.01, max_grad_norm=1.0,
-                                                      seed=self.rank, offset=noise_offset)
-                    else:
-                        total += T.train_step(unet, dec, proj, latents, text_hidden, ts, self.pipeline.scheduler.alphas_cumprod, None, pairs, state,
-                                              lr=1e-5, weight_decay=0.01, max_grad_norm=1.0, seed=self.rank, offset=noise_offset)
+                    # never skipped per rank: a batch without sample triples still runs the (eager) step with zero gradients, so that every rank
+                    # enters the same gradient collective (train.run_step)
+                    val, _ = T.run_step(gstep, unet, dec, proj, latents, text_hidden, ts, self.pipeline.scheduler.alphas_cumprod, pairs, state,
+                                        lr=1e-5, weight_decay=0.01, max_grad_norm=1.0, seed=self.rank, offset=noise_offset)
+                    total += val
                 else:
                     total += T.train_step(unet, dec, proj, latents, text_hidden, ts, self.pipeline.scheduler.alphas_cumprod, None, None, state, lr=1e-5,
                                           weight_decay=0.01, loss_fn=loss_fn, max_grad_norm=1.0, seed=self.rank, offset=noise_offset)

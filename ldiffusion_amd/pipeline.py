@@ -143,6 +143,27 @@ def argmax_mask(logits: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def probe_argmax_mask(features: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor = None, scale: float = 1.0 / 255.0) -> torch.Tensor:
+    """Linear probe over the per-pixel latent vectors + the mask tail in one launch (`ldiff_probe_argmax_u8`): features uint8 [B,N,H,W]
+    (pixel_latent_vector.py:85-93), weight [C,N], bias [C] -> uint8 [B,H,W] = argmax_c(bias_c + sum_n weight[c,n] * features_n * scale)
+    (segmentor.py:536-537), without materialising the float logits."""
+    _lib.require_gpu()
+    if features.dim() != 4 or features.dtype != torch.uint8:
+        raise ValueError(f"features must be uint8 [B,N,H,W], got {features.dtype} {tuple(features.shape)}")
+    B, N, H, W = features.shape
+    if weight.dim() != 2 or weight.shape[1] != N:
+        raise ValueError(f"weight must be [C,{N}], got {tuple(weight.shape)}")
+    Cc = weight.shape[0]
+    if bias is not None and tuple(bias.shape) != (Cc,):
+        raise ValueError(f"bias must be [{Cc}], got {tuple(bias.shape)}")
+    f = features.detach().contiguous()
+    w = weight.detach().to(f.device, dtype=torch.float32).contiguous()
+    bvec = None if bias is None else bias.detach().to(f.device, dtype=torch.float32).contiguous()
+    out = torch.empty((B, H, W), device=f.device, dtype=torch.uint8)
+    _lib.check(_lib.load().ldiff_probe_argmax_u8(_lib.ptr(f), B, N, H, W, _lib.ptr(w), _lib.ptr(bvec), float(scale), Cc, _lib.ptr(out), _lib.stream_ptr()))
+    return out
+
+
 def laplace_noise(z0: torch.Tensor, scale: float, u: torch.Tensor = None, seed: int = 0, offset: int = 0) -> torch.Tensor:
     """ldiffusion.py:234-237: z0 + Laplace(0, scale).sample() -- given `u` (parity) or from the device Philox stream."""
     _lib.require_gpu()

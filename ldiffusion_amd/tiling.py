@@ -80,8 +80,16 @@ def _window_accumulate(acc: torch.Tensor, cnt: torch.Tensor, pred: torch.Tensor,
     ldiff_window_accumulate (the same two roundings per element as the tensor formulation below, which serves host tensors: the CPU tests
     pin it to the reference's predictor)."""
     th, tw = pred.shape[-2:]
+    if tuple(pred.shape) != (acc.shape[0], th, tw):   # the kernel indexes pred with acc's class count: a head with fewer channels would be read out of bounds
+        raise ValueError(f"window accumulate: prediction {tuple(pred.shape)} does not match the accumulator's {acc.shape[0]} classes")
+    if g is not None and tuple(g.shape) != (th, tw):
+        raise ValueError(f"window accumulate: importance map {tuple(g.shape)} does not match the tile {(th, tw)}")
+    if y < 0 or x < 0 or y + th > acc.shape[1] or x + tw > acc.shape[2]:
+        raise ValueError(f"window accumulate: tile {(th, tw)} at {(y, x)} leaves the {tuple(acc.shape[1:])} accumulator")
     if acc.is_cuda:
         from . import _lib
+        if acc.dtype == torch.float32 and pred.dtype in (torch.float16, torch.bfloat16):
+            pred = pred.float()   # a half-precision head (autocast) into float32 accumulators: identical to the tensor formulation's type promotion
         kinds = {(torch.float32, torch.float32): 0, (torch.float16, torch.float16): 1, (torch.float16, torch.float32): 3}
         if acc.dtype != cnt.dtype or (acc.dtype, pred.dtype) not in kinds or not (acc.is_contiguous() and cnt.is_contiguous()):
             raise ValueError("window accumulate: contiguous float32 accumulators with a float32 prediction, or float16 ones with a float16 / float32 prediction")

@@ -325,9 +325,10 @@ class ShardedAdamW:
         self.v = torch.zeros(self.shard, dtype=torch.float32, device=dev)
         self.gshard = torch.zeros(self.shard, dtype=torch.float32, device=dev)
         self.step_count = 0
+        self.skipped = 0
 
     def step(self, max_grad_norm=None):
-        """Exchange, clip, update.  Returns the global gradient norm (after averaging, before clipping)."""
+        """Exchange, clip, update.  Returns the global gradient norm (after averaging, before clipping); a non-finite norm skips the update."""
         dist = _dist()
         off = 0
         for p in self.params:   # shape-stable bucket: zeros where a parameter has no gradient on this rank
@@ -345,6 +346,11 @@ class ShardedAdamW:
         if dist is not None:
             dist.all_reduce(sq)
         total = float(sq.sqrt())
+        if not math.isfinite(total):
+            # an overflowed float16 activation gradient (static / dynamic loss scale): every rank sees the same all-reduced norm, so every rank
+            # skips -- parameters, moments and the step count stay as they are (the caller lowers the loss scale, train.finish_step)
+            self.skipped += 1
+            return total
         if max_grad_norm is not None:
             coef = float(max_grad_norm) / max(total, float(max_grad_norm))
             if coef < 1.0:
@@ -363,23 +369,48 @@ def clip_grad_norm(params, max_norm):
     if not grads:
         return 0.0
     total = float(torch.linalg.vector_norm(torch.stack(torch._foreach_norm(grads))))
+    if max_norm is None or not math.isfinite(total):
+        return total            # non-finite: the caller skips the update (finish_step); scaling by inf * 0 would plant NaN everywhere
     coef = float(max_norm) / max(total, float(max_norm))
     if coef < 1.0:
         torch._foreach_mul_(grads, coef)
     return total
 
 
-LOSS_SCALE = 1024.0   # static loss scale of the backward pass: activation gradients are stored in float16 (the reference trains in fp32,
+LOSS_SCALE = 1024.0   # initial loss scale of the backward pass: activation gradients are stored in float16 (the reference trains in fp32,
                       # ldiffusion.py:172 `fp16.enabled: False`); unscaled, 0.5 % of the non-negligible parameter-gradient entries underflow to zero
 
 
+def finish_step(params, opt_state, lr, weight_decay, max_grad_norm, optimizer=None, update=None):
+    """What follows the backward pass on every rank: gradient exchange -> global norm -> (clipping) -> AdamW.  The norm is taken AFTER the
+    exchange, so all ranks see the same value and take the same branch: a non-finite norm (a float16 activation gradient overflowed under the
+    loss scale; the reference trains in fp32 and cannot hit this) skips the update -- parameters, moments and the AdamW step count untouched --
+    and halves `opt_state["loss_scale"]` (dynamic loss scaling; the next step's backward reads it).  Returns True when the update ran.
+    `optimizer` = a ShardedAdamW (reduce-scatter / sharded update / all-gather) or None (flattened all-reduce + ag.adamw_step)."""
+    if optimizer is not None:
+        total = optimizer.step(max_grad_norm)
+    else:
+        allreduce_gradients(params)
+        total = clip_grad_norm(params, max_grad_norm)
+    if not math.isfinite(total):
+        opt_state["skipped_steps"] = opt_state.get("skipped_steps", 0) + 1
+        opt_state["loss_scale"] = max(1.0, opt_state.get("loss_scale", LOSS_SCALE) * 0.5)
+        return False
+    if optimizer is None:
+        (update or ag.adamw_step)(params, [p.grad for p in params], opt_state, lr=lr, weight_decay=weight_decay)
+    return True
+
+
 def train_step(unet, vae_dec, proj, z0, text_hidden, timesteps, abar, u_list, pairs, opt_state, lr=1e-5, weight_decay=0.01, loss_fn=None,
-               max_grad_norm=None, seed=0, offset=0, loss_scale=LOSS_SCALE):
+               max_grad_norm=None, seed=0, offset=0, loss_scale=None):
     """One fine-tuning step (ldiffusion.py:209-255): text projection -> V5 features -> loss -> backward through the VAE decoder and the
     UNet -> gradient all-reduce -> (clipping) -> AdamW on the UNet and projection parameters.
     `proj` = (weight [D, 768], bias [D]) float32 CUDA parameters of the text projection.  `loss_fn(features, last_rgb)` defaults to the
-    contrastive loss on the given sample triples `pairs`.  Returns the loss value."""
+    contrastive loss on the given sample triples `pairs`.  Returns the loss value.  `loss_scale` None: opt_state["loss_scale"] (starts at
+    LOSS_SCALE, halved by finish_step whenever the exchanged gradient norm is not finite)."""
     params = unet.parameters() + list(proj)
+    if loss_scale is None:
+        loss_scale = opt_state.setdefault("loss_scale", LOSS_SCALE)
     for p in params:
         p.grad = None
     ctx = F.linear(text_hidden, proj[0], proj[1])
@@ -388,10 +419,7 @@ def train_step(unet, vae_dec, proj, z0, text_hidden, timesteps, abar, u_list, pa
     (loss * loss_scale).backward()
     if loss_scale != 1.0:   # the parameter gradients are float32: unscale before the exchange, the clipping and AdamW
         torch._foreach_mul_([p.grad for p in params if p.grad is not None], 1.0 / loss_scale)
-    allreduce_gradients(params)
-    if max_grad_norm is not None:
-        clip_grad_norm(params, max_grad_norm)
-    ag.adamw_step(params, [p.grad for p in params], opt_state, lr=lr, weight_decay=weight_decay)
+    finish_step(params, opt_state, lr, weight_decay, max_grad_norm)
     return float(loss.detach())
 
 
@@ -409,7 +437,10 @@ class GraphedStep:
         dev = unet.device
         self.unet, self.vae_dec, self.proj = unet, vae_dec, proj
         self.timesteps, self.abar = [int(t) for t in timesteps], abar.detach().cpu()
-        self.out_hw, self.temperature, self.loss_scale = out_hw, temperature, loss_scale
+        self.out_hw, self.temperature, self.loss_scale = out_hw, temperature, float(loss_scale)
+        # the scale is a DEVICE scalar inside the captured graph (finish_step halves it after an overflow: no re-capture)
+        self.scale_t = torch.full((), float(loss_scale), dtype=torch.float32, device=dev)
+        self.inv_scale_t = torch.full((), 1.0 / float(loss_scale), dtype=torch.float32, device=dev)
         self.noisy = [torch.zeros((batch, 4, latent_hw, latent_hw), device=dev) for _ in self.timesteps]
         self.hidden = torch.zeros((batch, text_len, text_dim), device=dev)
         i32 = dict(dtype=torch.int32, device=dev)
@@ -440,13 +471,20 @@ class GraphedStep:
                 feats, _ = v5_features(self.unet, self.vae_dec, None, ctx, self.timesteps, self.abar, out_hw=self.out_hw, noisy_list=self.noisy)
                 loss = ag.InfoNceFn.apply(feats, self.bi, self.ai, self.pi, self.ni, self.temperature, self.count)
                 leaves = [v for v in alias.values() if v.requires_grad] + [pw, pb]   # the order of self.params
-                grads = torch.autograd.grad(loss * self.loss_scale, leaves, allow_unused=True)
+                grads = torch.autograd.grad(loss * self.scale_t, leaves, allow_unused=True)
         finally:
             self.unet.p = own
         live = [g for g in grads if g is not None]
-        if self.loss_scale != 1.0 and live:
-            torch._foreach_mul_(live, 1.0 / self.loss_scale)
+        if live:
+            torch._foreach_mul_(live, self.inv_scale_t)
         return loss.detach(), list(grads)
+
+    def set_loss_scale(self, scale):
+        """New loss scale for the following replays (device scalars read by the captured graph)."""
+        if float(scale) != self.loss_scale:
+            self.loss_scale = float(scale)
+            self.scale_t.fill_(self.loss_scale)
+            self.inv_scale_t.fill_(1.0 / self.loss_scale)
 
     def _capture(self):
         cur = torch.cuda.current_stream()
@@ -471,6 +509,10 @@ class GraphedStep:
             raise ValueError(f"GraphedStep: {T} sample triples exceed max_triples = {self.bi.numel()}")
         if any(len(tr[2]) != K for _, tr in triples):
             raise ValueError(f"GraphedStep: every triple must carry num_negatives = {K} negatives")
+        npix = self.out_hw * self.out_hw   # the indices address the feature map of the captured graph: validate on the host, before the upload
+        if T and (len(pairs) > self.hidden.shape[0] or min(min(tr[0], tr[1], min(tr[2])) for _, tr in triples) < 0
+                  or max(max(tr[0], tr[1], max(tr[2])) for _, tr in triples) >= npix):
+            raise IndexError(f"GraphedStep: sample indices out of range for {self.hidden.shape[0]} feature maps of {self.out_hw}x{self.out_hw}")
         if T:
             self.bi[:T].copy_(torch.tensor([b for b, _ in triples], dtype=torch.int32))
             self.ai[:T].copy_(torch.tensor([tr[0] for _, tr in triples], dtype=torch.int32))
@@ -495,12 +537,21 @@ def train_step_graphed(gstep, z0, text_hidden, u_list, pairs, opt_state, lr=1e-5
     """`train_step` with forward + backward replayed from `gstep` (GraphedStep); exchange, clipping and AdamW as in the eager step, or --
     `optimizer` = a ShardedAdamW over `gstep.params` -- reduce-scatter, sharded AdamW, all-gather.  (A ShardedAdamW moves the parameters
     into its flat buffer: create it BEFORE the GraphedStep, whose graph and weight-layout plan hold the parameters' addresses.)"""
+    gstep.set_loss_scale(opt_state.setdefault("loss_scale", gstep.loss_scale))
     loss = gstep(z0, text_hidden, pairs, u_list, seed, offset)
-    if optimizer is not None:
-        optimizer.step(max_grad_norm)
-        return float(loss)
-    allreduce_gradients(gstep.params)
-    if max_grad_norm is not None:
-        clip_grad_norm(gstep.params, max_grad_norm)
-    ag.adamw_step(gstep.params, [p.grad for p in gstep.params], opt_state, lr=lr, weight_decay=weight_decay)
+    finish_step(gstep.params, opt_state, lr, weight_decay, max_grad_norm, optimizer=optimizer)
     return float(loss)
+
+
+def run_step(gstep, unet, vae_dec, proj, z0, text_hidden, timesteps, abar, pairs, opt_state, graph_ok=True, **kw):
+    """The per-batch dispatch of LDiffusionModel.train_ldiffusion (ldiffusion.py:227-255: every rank runs engine.backward + engine.step for EVERY
+    batch): the graph replay where the batch fits the capture, the eager step otherwise -- and NEVER nothing: a rank whose batch yields no
+    sample triples still runs the eager step (its loss is a constant 0, its gradients are zeros), so that it enters the same gradient
+    collective as the other ranks and AdamW advances in lock-step everywhere.  Returns (loss value, "graph" | "eager")."""
+    n_tr = sum(len(t) for t in pairs)
+    B = z0.shape[0]
+    fits = (graph_ok and gstep is not None and n_tr > 0 and B == gstep.hidden.shape[0] and [int(t) for t in timesteps] == gstep.timesteps
+            and n_tr <= gstep.bi.numel() and tuple(z0.shape[-2:]) == tuple(gstep.noisy[0].shape[-2:]) and text_hidden.shape[1] == gstep.hidden.shape[1])
+    if fits:
+        return train_step_graphed(gstep, z0, text_hidden, None, pairs, opt_state, **kw), "graph"
+    return train_step(unet, vae_dec, proj, z0, text_hidden, timesteps, abar, None, pairs, opt_state, **kw), "eager"

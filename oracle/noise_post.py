@@ -68,3 +68,25 @@ def argmax_mask(logits: torch.Tensor) -> np.ndarray:
     """segmentor.py:536-537: argmax(softmax(out,1),1) -> uint8.  Softmax is monotone so the
     argmax of the logits is identical; ties resolve to the lowest class index (torch.argmax)."""
     return torch.argmax(torch.softmax(logits, dim=1), dim=1).cpu().numpy().astype(np.uint8)
+
+
+def probe_argmax(features_u8: np.ndarray, weight: np.ndarray, bias, scale: float = 1.0 / 255.0) -> np.ndarray:
+    """Linear probe over the per-pixel latent vectors (pixel_latent_vector.py:85-93: the N luma planes of a pixel) followed by the mask
+    tail of segmentor.py:536-537, in the arithmetic `ldiff_probe_argmax_u8` pins (include/ldiff.h): float32 throughout,
+    x_n = f_n * scale; acc = bias_c; acc = acc + w[c,n] * x_n in plane order, every operation rounded (no fused multiply-add);
+    first maximal class.  features [B,N,H,W] uint8, weight [C,N], bias [C] or None -> uint8 [B,H,W]."""
+    f = features_u8.astype(np.float32) * np.float32(scale)
+    w = np.asarray(weight, dtype=np.float32)
+    C, N = w.shape
+    best, idx = None, None
+    for c in range(C):
+        acc = np.full(f[:, 0].shape, np.float32(0.0 if bias is None else bias[c]), dtype=np.float32)
+        for n in range(N):
+            acc = (acc + (w[c, n] * f[:, n]).astype(np.float32)).astype(np.float32)
+        if c == 0:
+            best, idx = acc.copy(), np.zeros(acc.shape, dtype=np.uint8)
+        else:
+            m = acc > best
+            best = np.where(m, acc, best)
+            idx = np.where(m, np.uint8(c), idx)
+    return idx

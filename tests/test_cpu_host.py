@@ -24,7 +24,7 @@ def test_library_exports_every_symbol_declared_in_header(lib):
     assert declared == set(_lib.SIGNATURES), f"header vs ctypes table differ: {declared ^ set(_lib.SIGNATURES)}"
     for name in declared:
         assert hasattr(lib, name), f"{name} not exported by libldiff_hip.so"
-    assert lib.ldiff_version() == 130
+    assert lib.ldiff_version() == int(re.search(r"#define LDIFF_VERSION (\d+)", open(os.path.join(ROOT, "include", "ldiff.h")).read()).group(1))
 
 
 def test_host_only_entry_points_match_oracle(lib):
@@ -239,3 +239,95 @@ def test_pixel_latent_vector_export_matches_reference_loop(tmp_path):
         assert p.read_bytes() == ope.pixel_csv_bytes([feats[k] for k in range(n)], label)
     with pytest.raises(ValueError):
         plv.pixel_table(np.zeros((2, 3, 3), np.uint8), np.zeros((4, 3), np.uint8))
+
+
+_STEP_WORKER = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, {root!r})
+from ldiffusion_amd import train
+dist.init_process_group("gloo")
+rank = dist.get_rank()
+# The per-batch dispatch of train_ldiffusion (train.run_step) with the two device steps replaced by stand-ins that do what the real ones do
+# AFTER the backward pass: finish_step = gradient all-reduce -> norm -> AdamW.  Rank 1's batches are all background (no sample triples):
+# it must still enter every collective (ADVICE round 3: a skipped step paired rank 0's gradient bucket with the epoch-end reduction).
+ps = [torch.nn.Parameter(torch.ones(3)), torch.nn.Parameter(torch.ones(2, 2))]
+calls = []
+def upd(params, grads, state, lr, weight_decay):
+    state["step"] = state.get("step", 0) + 1
+    for p, g in zip(params, grads):
+        p.data -= lr * g
+def fake(kind):
+    def f(*a, **kw):
+        pairs, state = (a[4], a[5]) if kind == "graph" else (a[8], a[9])
+        n = sum(len(t) for t in pairs)
+        for p in ps:
+            p.grad = torch.full_like(p, float(n))           # zero gradients on the rank without triples
+        train.finish_step(ps, state, 0.5, 0.0, None, update=upd)
+        calls.append(kind)
+        return float(n)
+    return f
+train.train_step, train.train_step_graphed = fake("eager"), fake("graph")
+class G:   # the attributes run_step reads from a captured GraphedStep
+    hidden = torch.zeros(2, 6, 8); timesteps = [801, 1]; bi = torch.zeros(64); noisy = [torch.zeros(2, 4, 8, 8)]
+z0, text = torch.zeros(2, 4, 8, 8), torch.zeros(2, 6, 8)
+state = {{}}
+for it in range(3):
+    pairs = [[(0, 1, [2, 3])], [(4, 5, [6, 7])]] if rank == 0 else [[], []]
+    val, kind = train.run_step(G, None, None, None, z0, text, [801, 1], None, pairs, state, lr=1e-5)
+    assert kind == ("graph" if rank == 0 else "eager"), (rank, kind)
+t = torch.tensor([float(rank)], dtype=torch.float64)        # the epoch-end reduction (_reduce_mean) must pair with itself
+dist.all_reduce(t)
+assert t.item() == 1.0
+assert len(calls) == 3 and state["step"] == 3
+for p in ps:                                                # averaged gradient (2 + 0) / 2 = 1 per step, lr 0.5, three steps
+    assert torch.allclose(p.data, torch.full_like(p, 1.0 - 1.5)), (rank, p.data)
+dist.barrier()
+dist.destroy_process_group()
+open(os.path.join({out!r}, "step%d.ok" % rank), "w").write("ok")
+"""
+
+
+def test_no_rank_skips_the_step_world_size_2_gloo(tmp_path):
+    """One rank with an all-background label (no sample triples) and one with triples: both enter the same gradient collective every batch."""
+    script = tmp_path / "sworker.py"
+    script.write_text(_STEP_WORKER.format(root=ROOT, out=str(tmp_path)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), str(script)]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=240, env=dict(os.environ, OMP_NUM_THREADS="1"))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert (tmp_path / "step0.ok").exists() and (tmp_path / "step1.ok").exists()
+
+
+def test_non_finite_gradient_skips_the_update_and_halves_the_loss_scale():
+    """an inf / NaN gradient behind the float16 loss scale must not reach AdamW -- the step is skipped with the
+    parameters, moments and step count untouched, and the loss scale halves.  Both optimizer paths (replicated, ShardedAdamW)."""
+    from ldiffusion_amd import train
+    ran = []
+
+    def upd(params, grads, state, lr, weight_decay):
+        state["step"] = state.get("step", 0) + 1
+        ran.append(state["step"])
+
+    for bad in (float("inf"), float("nan")):
+        ps = [torch.nn.Parameter(torch.ones(4)), torch.nn.Parameter(torch.ones(2))]
+        ps[0].grad, ps[1].grad = torch.tensor([1.0, bad, 0.0, 2.0]), torch.ones(2)
+        state = {"loss_scale": 1024.0}
+        assert train.finish_step(ps, state, 1e-3, 0.0, 1.0, update=upd) is False
+        assert state["loss_scale"] == 512.0 and state["skipped_steps"] == 1 and "step" not in state
+        assert torch.equal(ps[1].grad, torch.ones(2))                     # not scaled by inf * 0
+    ps[0].grad = torch.tensor([3.0, 0.0, 0.0, 0.0]); ps[1].grad = torch.tensor([4.0, 0.0])
+    assert train.finish_step(ps, state, 1e-3, 0.0, 1.0, update=upd) is True and ran == [1]
+    assert torch.allclose(ps[0].grad, torch.tensor([0.6, 0, 0, 0])) and state["loss_scale"] == 512.0   # clipped to norm 1, scale kept
+
+    def adamw(p, g, m, v, step, lr, betas, eps, wd):
+        p.sub_(lr * g)
+
+    qs = [torch.nn.Parameter(torch.ones(5))]
+    opt = train.ShardedAdamW(qs, lr=0.1, update=adamw)
+    qs[0].grad = torch.tensor([1.0, float("inf"), 0, 0, 0])
+    state = {}
+    assert train.finish_step(qs, state, 0.1, 0.0, 1.0, optimizer=opt) is False
+    assert opt.step_count == 0 and opt.skipped == 1 and torch.equal(qs[0].data, torch.ones(5)) and state["loss_scale"] == train.LOSS_SCALE / 2
+    qs[0].grad = torch.tensor([2.0, 0, 0, 0, 0])
+    assert train.finish_step(qs, state, 0.1, 0.0, None, optimizer=opt) is True
+    assert opt.step_count == 1 and torch.allclose(qs[0].data, torch.tensor([0.8, 1, 1, 1, 1]))

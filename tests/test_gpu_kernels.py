@@ -570,7 +570,8 @@ def test_conv_on_split_tensors(lib, name):
         assert (gotn - refn).abs().max() <= 2e-4 * max(1.0, refn.abs().max())
 
 
-@pytest.mark.parametrize("shape", ["one_unit_one_slab", "two_units_one_slab", "three_units_two_slabs", "two_channel_tiles_four_slabs"])
+@pytest.mark.parametrize("shape", ["one_unit_one_slab", "two_units_one_slab", "three_units_two_slabs", "two_channel_tiles_four_slabs",
+                                   "four_channel_tiles_eight_slabs", "four_channel_tiles_eight_slabs_short_runs", "three_units_two_slabs_short_runs"])
 @pytest.mark.parametrize("res,stats,temb", [(0, 0, 0), (1, 0, 1), (0, 1, 0), (1, 1, 1)])
 def test_conv3x3_dataflow_kernel(lib, shape, res, stats, temb):
     """The producer / consumer conv3x3 kernel (kernels_conv3x3d.hip: GroupNorm + SiLU prologue on maps that fill the chip): every epilogue
@@ -578,8 +579,11 @@ def test_conv3x3_dataflow_kernel(lib, shape, res, stats, temb):
     units (tile switches, bias table hand-over) and several channel tiles / slabs.  Three launches each: producers and consumers meet only
     through progress words in LDS, and a missing wait would show up as a now-and-then wrong tile.  The statistics are checked against the
     sums of the kernel's own fp16 outputs (they are defined on the rounded values)."""
+    # four_channel_tiles_eight_slabs = the VAE decoder's ten 512 -> 512 convs on the 64 x 64 maps at B = 8 (the bench configuration: 512 units >= 256 CUs
+    # only at that batch); *_short_runs = one unit per workgroup, as ldiff_sample launches the decodes beside the next UNet pass
+    short = shape.endswith("_short_runs")
     B, Cin, H, W, Cout = {"one_unit_one_slab": (1, 64, 256, 256, 128), "two_units_one_slab": (3, 64, 256, 256, 128), "three_units_two_slabs": (3, 128, 256, 256, 128),
-                          "two_channel_tiles_four_slabs": (2, 256, 128, 128, 256)}[shape]
+                          "two_channel_tiles_four_slabs": (2, 256, 128, 128, 256), "four_channel_tiles_eight_slabs": (8, 512, 64, 64, 512)}[shape.replace("_short_runs", "")]
     g = torch.Generator().manual_seed(res * 4 + stats * 2 + temb + len(shape))
     x = torch.randn((B, H, W, Cin), generator=g).to(torch.float16)
     w = (torch.randn((Cout, 3, 3, Cin), generator=g) / math.sqrt(9 * Cin)).to(torch.float16)
@@ -593,6 +597,7 @@ def test_conv3x3_dataflow_kernel(lib, shape, res, stats, temb):
     a_.ks, a_.stride, a_.pad_t, a_.pad_l = 3, 1, 1, 1
     a_.w, a_.N, a_.Nrows, a_.bias = wd.data_ptr(), Cout, Cout, bd.data_ptr()
     a_.gn_scale, a_.gn_shift, a_.silu_in = scd.data_ptr(), shd.data_ptr(), 1
+    a_.short_runs = 1 if short else 0
     y = torch.empty((B, H, W, Cout), dtype=torch.float16, device=DEV)
     a_.y, a_.ldy = y.data_ptr(), Cout
     if temb:

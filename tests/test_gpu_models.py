@@ -1090,3 +1090,135 @@ def test_decode_tail_fused_into_conv_out(tiny, prec):
         assert torch.equal(rgb2, rgb) and torch.equal(luma2[:, 0], want_luma)
     finally:
         vae.set_precision(decoder=0)
+
+
+def test_probe_argmax_one_launch_bit_exact():
+    """ldiff_probe_argmax_u8 (linear probe over the uint8 per-pixel latent vectors + arg-max in one launch, the bench's mask tail) against
+    the host statement of the same pinned arithmetic (oracle.noise_post.probe_argmax), bit for bit, ties included."""
+    from ldiffusion_amd.pipeline import probe_argmax_mask
+    g = torch.Generator().manual_seed(77)
+    for B, N, C, H, W in ((2, 5, 6, 32, 36), (1, 20, 11, 8, 4), (3, 1, 1, 16, 16), (1, 64, 32, 4, 4)):
+        f = torch.randint(0, 256, (B, N, H, W), generator=g, dtype=torch.uint8)
+        f[0, :, 0, :4] = 0                                     # all-zero vectors: the bias decides
+        w = torch.randn((C, N), generator=g) / N ** 0.5
+        b = torch.randn((C,), generator=g) * 0.1
+        if C > 2:
+            w[2] = w[1]; b[2] = b[1]                           # exact ties between classes 1 and 2 -> the lower index wins
+        for bias in (b, None):
+            got = probe_argmax_mask(f.to(DEV), w.to(DEV), None if bias is None else bias.to(DEV)).cpu().numpy()
+            ref = noise_post.probe_argmax(f.numpy(), w.numpy(), None if bias is None else bias.numpy())
+            assert got.dtype == np.uint8 and np.array_equal(got, ref), (B, N, C, H, W)
+            assert C <= 2 or not (got == 2).any()
+    # the float formulation the bench used before (einsum + argmax) agrees except where two logits are within float round-off
+    f = torch.randint(0, 256, (2, 5, 64, 64), generator=g, dtype=torch.uint8)
+    w, b = torch.randn((6, 5), generator=g), torch.randn((6,), generator=g)
+    lg = torch.einsum("cn,bnhw->bchw", w, f.float() * (1.0 / 255.0)) + b[None, :, None, None]
+    assert (probe_argmax_mask(f.to(DEV), w.to(DEV), b.to(DEV)).cpu().numpy() != noise_post.argmax_mask(lg)).mean() <= 1e-3
+    assert probe_argmax_mask(torch.zeros((0, 5, 4, 4), dtype=torch.uint8, device=DEV), w.to(DEV), b.to(DEV)).shape == (0, 4, 4)
+    with pytest.raises(ValueError):
+        probe_argmax_mask(f.to(DEV), torch.zeros((6, 4), device=DEV))
+    with pytest.raises(ValueError):
+        probe_argmax_mask(f.to(DEV), torch.zeros((40, 5), device=DEV))
+
+
+@pytest.mark.timeout(2400)
+def test_config1_b8_bench_mode_against_oracle():
+    """The configuration bench.py TIMES (BASELINE.json configs[1]): SD-v1.5 width, 512x512, 5 passes, **B = 8**, two samplers with deferred
+    joins alternating over the same unet / vae (two batches in flight, ldiff_pipeline_set_overlap 2: bench.py run_steps), the persistent conv
+    kernels on short runs beside the UNet stream.  At B = 8 the kernel selection differs from the B = 2 test above (dataflow conv on the 64x64
+    maps, other split-K plans).  Checked: every pipelined batch equals the serial (one stream) result bit for bit; patches 0 and 7 against the
+    fp32 CPU oracle (latents <= 1e-3 of range, luma within one grey level, probe-head masks)."""
+    from ldiffusion_amd.pipeline import probe_argmax_mask
+    ucfg, vcfg = configs.SD15_UNET, configs.SD15_VAE
+    usd = weights.synthetic_state_dict(weights.unet_param_shapes(ucfg), 42, fp16_values=True)
+    vsd = weights.synthetic_state_dict(weights.vae_param_shapes(vcfg), 43, fp16_values=True)
+    B, N = 8, 5
+    x = torch.rand((B, 3, 512, 512), generator=torch.Generator().manual_seed(1234))                 # bench.py's images / context
+    ctx = torch.randn((1, 6, 768), generator=torch.Generator().manual_seed(1235)) * 0.5
+    pipe = StableDiffusionImg2ImgPipeline(AutoencoderKL(vcfg, vsd, DEV), UNet2DConditionModel(ucfg, usd, DEV))
+    xd, cd = x.to(DEV), ctx.to(DEV)
+    s1, s2 = LaplaceSampler(pipe), LaplaceSampler(pipe)
+    s1.set_overlap(0)
+    serial = s1.sample(xd, cd, N)
+    serial = {k: v.clone() for k, v in serial.items()}
+    s1.sample(xd, cd, N)                                                                                # second use: the UNet graph is captured / replayed from here on
+    s1.set_overlap(2); s2.set_overlap(2)
+    outs, prev = [], None
+    for i in range(4):                                                                                  # bench.py run_steps
+        sp = (s1, s2)[i & 1]
+        out = sp.sample(xd, cd, N)
+        if prev is not None:
+            prev[0].join()
+            outs.append({k: v.clone() for k, v in prev[1].items()})
+        prev = (sp, out)
+    prev[0].join()
+    outs.append(prev[1])
+    torch.cuda.synchronize()
+    s1.set_overlap(1); s2.set_overlap(1)
+    assert pipe.unet.graph_replays >= 5
+    for o in outs:
+        for k in ("latents", "features", "rgb"):
+            assert torch.equal(o[k], serial[k]), f"pipelined batch differs from the serial run in {k}"
+    W, bias = _probe_head(6, N, 5)
+    mask = probe_argmax_mask(outs[-1]["features"], W.to(DEV) * 255.0, bias.to(DEV)).cpu().numpy()
+    sel = [0, 7]
+    torch.set_num_threads(max(1, min(32, len(os.sched_getaffinity(0)))))
+    opipe = op.OraclePipeline(op.OracleUNet(usd, ucfg), op.OracleVAE(vsd, vcfg))
+    ref = op.sample_v6(opipe, x[sel], ctx, N)
+    e = rel_err(outs[-1]["latents"][sel], ref["latents"][-1])
+    fd = np.abs(outs[-1]["features"][sel].cpu().numpy().astype(int) - ref["features"].astype(int))
+    rmask = noise_post.probe_argmax(ref["features"], (W * 255.0).numpy(), bias.numpy())
+    ndiff = int((mask[sel] != rmask).sum())
+    print(f"configs[1] bench mode B={B}, two batches in flight: final latents of patches {sel}: {err_report(outs[-1]['latents'][sel], ref['latents'][-1])}; "
+          f"luma max diff {fd.max()} (!=0: {(fd > 0).mean():.4f}); masks: {ndiff} of {rmask.size} pixels differ")
+    assert e <= 1e-3, "north-star tolerance: latents within 1e-3 of the reference (relative to the latent range)"
+    assert fd.max() <= 1
+    assert ndiff <= 8, f"north star: arg-max masks at configs[1], bench mode: {ndiff} pixels differ"
+
+
+@pytest.mark.timeout(2400)
+def test_one_pass_1024_sd15_width_against_oracle():
+    """SURVEY 8f row 1 at the reference's real size (segmentor.py:505-530): B = 1, 1024x1024, ONE pass, SD-v1.5 width -- 128x128 latents, the
+    level-0 self-attention over 16,384 tokens x 8 heads x d = 40 at width 320 -- against the fp32 CPU oracle."""
+    ucfg, vcfg = configs.SD15_UNET, configs.SD15_VAE
+    usd = weights.synthetic_state_dict(weights.unet_param_shapes(ucfg), 42, fp16_values=True)
+    vsd = weights.synthetic_state_dict(weights.vae_param_shapes(vcfg), 43, fp16_values=True)
+    g = torch.Generator().manual_seed(88)
+    x = torch.rand((1, 3, 1024, 1024), generator=g)
+    ctx = torch.randn((1, 6, 768), generator=g) * 0.5
+    pipe = StableDiffusionImg2ImgPipeline(AutoencoderKL(vcfg, vsd, DEV), UNet2DConditionModel(ucfg, usd, DEV))
+    out = LaplaceSampler(pipe).sample(x.to(DEV), ctx.to(DEV), 1)
+    torch.cuda.synchronize()
+    torch.set_num_threads(max(1, min(32, len(os.sched_getaffinity(0)))))
+    ref = op.sample_one_pass(op.OraclePipeline(op.OracleUNet(usd, ucfg), op.OracleVAE(vsd, vcfg)), x, ctx)
+    e = rel_err(out["latents"], ref["latents"])
+    rd = np.abs(out["rgb"].cpu().numpy().astype(int) - ref["rgb_u8"].astype(int))
+    print(f"1024^2 one pass at SD-v1.5 width: latents {err_report(out['latents'], ref['latents'])}; rgb max diff {rd.max()} (!=0: {(rd > 0).mean():.4f})")
+    assert out["rgb"].shape[1:3] == (1024, 1024)
+    assert e <= 1e-3 and rd.max() <= 1
+
+
+def test_pixel_csv_from_device_features(tiny, tmp_path):
+    """SURVEY 8f row 3 on the device tensor: sample()["features"][b] (uint8, on the GPU) straight into write_pixel_csv, against the file the
+    reference's loop (pixel_latent_vector.py:89-101: dict keyed by (i, j), csv.writer) writes for the same features."""
+    import csv
+    from ldiffusion_amd import pixel_latent_vector as plv
+    g = torch.Generator().manual_seed(31)
+    x = torch.rand((2, 3, 64, 64), generator=g)
+    ctx = torch.randn((1, 6, 64), generator=g) * 0.5
+    out = LaplaceSampler(tiny["pipe"]).sample(x.to(DEV), ctx.to(DEV), 5)
+    label = torch.randint(0, 6, (64, 64), generator=g)
+    feats = out["features"][1]
+    assert feats.is_cuda and feats.dtype == torch.uint8
+    plv.write_pixel_csv(tmp_path / "dev.csv", feats, label.to(DEV))
+    f = feats.cpu().numpy()
+    pixel_dict = {}
+    for i in range(64):
+        for j in range(64):
+            pixel_dict[(i, j)] = [int(f[k, i, j]) for k in range(5)] + [int(label[i, j])]
+    with open(tmp_path / "ref.csv", "w", newline="") as fh:
+        wr = csv.writer(fh)
+        wr.writerow(plv.generate_title(5))
+        for key, values in pixel_dict.items():
+            wr.writerow([key] + values)
+    assert (tmp_path / "dev.csv").read_bytes() == (tmp_path / "ref.csv").read_bytes()

@@ -225,6 +225,12 @@ int ldiff_op_attention(const void* q, int ldq, const void* k, int ldk, const voi
 int ldiff_op_gn_stats(const void* x, int C1, int ld1, int lo1, const void* x2, int C2, int ld2, int lo2, int B, int HW, int groups, float eps,
                       const void* gamma, const void* beta, void* scale, void* shift, void* stream);
 int ldiff_op_layernorm(const void* x, int ldx, int x_lo, void* y, int rows, int C, const void* gamma, const void* beta, float eps, void* stream);
+/* LayerNorm folded into the linear layer that consumes it (BasicTransformerBlock norm1 -> to_q/k/v, norm2 -> attn2.to_q, norm3 -> ff.net.0.proj):
+ *   y[rows, N] = LayerNorm(x; gamma, beta, eps)[rows, C] . w[N, C]^T + bias,  x as in ldiff_op_layernorm (x_lo > 0: split rows hi | lo),
+ *   the normalised operand rounded ONCE to fp16 (as the two-launch form does); geglu as in ldiff_conv_args (y has N/2 columns).
+ * Returns LDIFF_ERR_INVALID for shapes the kernel does not take (C != 320, N % 64 != 0, ...): callers then use ldiff_op_layernorm + ldiff_op_conv. */
+int ldiff_op_ln_linear(const void* x, int ldx, int x_lo, int rows, int C, const void* gamma, const void* beta, float eps, const void* w, int N, int Nrows,
+                       const void* bias_or_null, int geglu, void* y, int ldy, void* stream);
 /* y[m, c] = act(x[m, c] * scale[b, c] + shift[b, c]) (GroupNorm-apply, optional SiLU) over the concat of one or two sources,
  * written plain (y_lo = 0) or split */
 int ldiff_op_norm_apply(const void* x, int C1, int ld1, int lo1, const void* x2, int C2, int ld2, int lo2, int B, int HW, const void* scale,

@@ -502,6 +502,19 @@ int ldiff_op_layernorm(const void* x, int ldx, int x_lo, void* y, int rows, int 
   launch_layernorm(SrcView{(const f16*)x, C, ldx, x_lo}, (f16*)y, rows, (const float*)gamma, (const float*)beta, eps, (hipStream_t)stream);
   API_END
 }
+int ldiff_op_ln_linear(const void* x, int ldx, int x_lo, int rows, int Cc, const void* gamma, const void* beta, float eps, const void* w, int N, int Nrows,
+                       const void* bias, int geglu, void* y, int ldy, void* stream) {
+  API_BEGIN
+  LDIFF_CHECK(x && gamma && beta && w && y && rows >= 0, LDIFF_ERR_INVALID, "op_ln_linear: null argument");
+  if (rows == 0) return LDIFF_OK;
+  LDIFF_CHECK(lngemm_eligible(Cc, N, ldx ? ldx : Cc, x_lo, ldy, geglu != 0) && Nrows >= N, LDIFF_ERR_INVALID, "op_ln_linear: unsupported shape (C=%d N=%d Nrows=%d)", Cc, N, Nrows);
+  // the executors keep the tiled weight copy per layer; this handle-less entry point tiles per call into stream-ordered scratch
+  f16* wt = (f16*)op_scratch((hipStream_t)stream, 4, (size_t)N * Cc * sizeof(f16));
+  launch_lngemm_tile_weights((const f16*)w, wt, N, Cc, (hipStream_t)stream);
+  launch_lngemm((const f16*)x, ldx ? ldx : Cc, x_lo, rows, Cc, (const float*)gamma, (const float*)beta, eps, wt, N, (const float*)bias, geglu != 0,
+                (f16*)y, ldy, (hipStream_t)stream);
+  API_END
+}
 int ldiff_op_norm_apply(const void* x, int C1, int ld1, int lo1, const void* x2, int C2, int ld2, int lo2, int B, int HW, const void* scale,
                         const void* shift, int silu, void* y, int ldy, int y_lo, void* stream) {
   API_BEGIN

@@ -108,6 +108,11 @@ void launch_pack_frag_weights(const f16* w, f16* wf, int N, int Cin, hipStream_t
 void launch_conv3x3d(const ConvParams& p, hipStream_t s);
 int conv3x3p_stats_blocks(const ConvParams& p);
 void launch_conv3x3p(const ConvParams& p, hipStream_t s);
+// LayerNorm folded into the consuming GEMM, activations stationary in registers (kernels_gemm_ast.hip): y = LN(x) W^T + bias (optional GEGLU epilogue)
+bool lngemm_eligible(int C, int N, int ldx, int x_lo, int ldy, bool geglu);
+void launch_lngemm_tile_weights(const f16* w, f16* wt, int N, int C, hipStream_t s);   // [N][C] -> the panel images the kernel streams (N*C fp16)
+void launch_lngemm(const f16* x, int ldx, int x_lo, int M, int C, const float* gamma, const float* beta, float eps, const f16* w_tiled, int N,
+                   const float* bias, bool geglu, f16* y, int ldy, hipStream_t s);
 bool gemm_dma_eligible(const ConvParams& p);
 void launch_gemm_dma(const ConvParams& p, hipStream_t s);      // kernels_gemm.hip
 

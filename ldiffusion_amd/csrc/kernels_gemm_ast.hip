@@ -1,0 +1,420 @@
+// LayerNorm folded into the GEMM that consumes it, activation-stationary (gfx950 / MI355X).
+//
+//   y[M, N] = LayerNorm(x)[M, C] . W[N, C]^T + bias        (optionally the GEGLU epilogue x * gelu_erf(gate))
+//
+// Replaces `norm1 -> attn1.to_q/k/v`, `norm2 -> attn2.to_q` and `norm3 -> ff.net.0.proj` of diffusers' BasicTransformerBlock on the
+// UNet levels whose channel count fits (C = 320 at 64 x 64 latents: M = 32768 rows at B = 8; reached from
+// /root/reference/segmentor.py:103,526 and pixel_latent_vector.py:78).  SURVEY.md 8a rows K2 / K4: "GEMM with LN prologue".
+//
+// Why a second GEMM kernel.  The LDS-DMA GEMM (kernels_gemm.hip) streams BOTH operands through LDS: with K = C = 320 that is five K-steps
+// per tile, and a wave issues one LDS-DMA piece (60-185 wave-cycles each beside MFMAs) per four 16-cycle MFMAs -- the kernel is bound by its
+// own issue stream at 0.45-0.7 PFLOP/s, and the LayerNorm in front of it is a launch of its own that reads the residual stream (hi | lo, 4 bytes
+// per element) and writes the normalised operand back to HBM just to have it read again.  Here the ACTIVATIONS ARE STATIONARY IN REGISTERS:
+// a wave owns 32 complete rows of x (K = 320 is the whole row: 80 VGPRs of MFMA B fragments), so
+//   * LayerNorm is a register prologue: the wave loads its rows once (hi + lo in fp32), takes mean / variance with two cross-lane steps
+//     (a row lives in the four lanes l15 + 16 g), normalises, applies gamma / beta and rounds ONCE to fp16 -- the normalised tensor never
+//     exists in HBM and the LayerNorm launch disappears;
+//   * only the weights move: 64-column panels [64][320] (40 KiB) stream global -> LDS by LDS-DMA through a ring of three buffers, two panels
+//     ahead (a panel takes ~3.7 K cycles to land while every CU pulls the same one: longer than one panel's arithmetic), shared by the four
+//     waves of a 128-row workgroup: one DMA piece per EIGHT MFMAs, 131 flops per operand byte moved on chip instead of 64;
+//   * one workgroup barrier per panel (80 MFMAs per wave) instead of one per 64-deep K-step (16-32).
+// Workgroup = 4 waves x 32 rows, one per CU (M = 32768: 256 row panels = every CU normalises its own rows exactly once; fewer rows: the columns
+// are split over workgroups).  Measured on the way (profiles/r04_lngemm.txt): 8 waves x 32 rows with two column splits read and normalised every
+// row twice -- the prologue (ingest of the rows at ~30 GB/s per CU + ~10 VALU instructions per element) was half of the kernel.
+// With one wave per SIMD nothing else covers a panel's epilogue, so the epilogue of panel c - 1 is cut into ten pieces that sit between the MFMA
+// groups of panel c (the matrix pipe runs while the VALU converts and the GEGLU erf evaluates); stores in full lines: the wave transposes its
+// 32 x 64 tile through a private LDS patch and writes 128 contiguous bytes per row.
+#include "common.h"
+
+namespace {
+
+typedef __attribute__((address_space(3))) void lptr_t;
+
+template <int I, int N, class F>
+__device__ __forceinline__ void sfor(F&& f) {
+  if constexpr (I < N) { f(std::integral_constant<int, I>{}); sfor<I + 1, N>(f); }
+}
+// LDS traffic as inline asm with counted waits: hipcc would put s_waitcnt vmcnt(0) in front of plain LDS reads while an LDS-DMA is in flight
+// (it cannot prove they do not alias the DMA's destination) and lgkmcnt(0) in front of every MFMA group.
+template <int OFF>
+__device__ __forceinline__ void lds_read128(f16x8& d, unsigned addr) {
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF) : "memory");
+}
+template <int OFF>
+__device__ __forceinline__ void lds_read128u(uint4& d, unsigned addr) {
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF) : "memory");
+}
+template <int OFF>
+__device__ __forceinline__ void lds_read128f(float4& d, unsigned addr) {
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF) : "memory");
+}
+template <int OFF>
+__device__ __forceinline__ void lds_write64(unsigned addr, const uint2& v) {
+  asm volatile("ds_write_b64 %0, %1 offset:%2" : : "v"(addr), "v"(v), "n"(OFF) : "memory");
+}
+template <int CNT>
+__device__ __forceinline__ void lds_wait4(f16x8& a, f16x8& b, f16x8& c, f16x8& d) {
+  asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(CNT));
+}
+__device__ __forceinline__ void lds_wait_all() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+struct LnGemmParams {
+  const f16* x; int ld, lo;          // [M, ld] rows of C channels; lo > 0: split tensor, value = x[c] + x[lo + c]
+  int M;
+  const float* gamma; const float* beta; float eps;
+  const f16* w; int N;               // TILED weights (launch_lngemm_tile_weights) of the [N][C] K-major matrix (GEGLU: rows x / gate interleaved by 16); N % 64 == 0
+  const float* bias;                 // [Nrows] or nullptr
+  f16* y; int ldy;                   // [M, ldy]; GEGLU: N / 2 columns
+  int nsplit, npanels;
+  unsigned long long* stamps;        // diagnostic (LDIFF_LNGEMM_STAMPS=1): s_memtime of workgroup 0's wave 0 at the phase boundaries, else nullptr
+};
+
+constexpr int BN = 64, NW = 4, ROWS = NW * 32, NBUF = 3;   // panel width; waves and rows per workgroup; weight ring
+
+// s_waitcnt vmcnt(n) for a wave-uniform runtime n (the instruction takes an immediate): the counts the ring produces
+__device__ __forceinline__ void wait_vm(int n) {
+  switch (n) {
+    case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+    case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+    case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+    case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+    case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+    case 14: asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); break;
+    case 18: asm volatile("s_waitcnt vmcnt(18)" ::: "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;   // (stricter than needed is always correct)
+  }
+}
+
+template <int C, bool GEGLU, bool SPLIT>
+__global__ __launch_bounds__(NW * 64, 1) void lngemm_kernel(const LnGemmParams p) {
+  constexpr int KS = C / 32, MT = 2, NT = 4;
+  constexpr int PANEL = BN * C * 2;                     // bytes of one weight panel in LDS (C/64 sub-images of [64][128 B], XOR-swizzled)
+  constexpr int PIECES = PANEL / 1024, PPW = PIECES / NW;   // LDS-DMA pieces per panel / per wave
+  static_assert(C % 64 == 0 && PIECES % NW == 0 && KS == 10, "the epilogue pieces are laid out for ten k-steps");
+  constexpr int STG = NBUF * PANEL;                     // per-wave epilogue staging patches: NW x 4 KiB
+  constexpr int VEC = STG + NW * 4096;                  // gamma | beta | bias (fp32)
+  constexpr int NST = GEGLU ? 2 : 4;                    // global stores per wave and panel
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 4, l15 = lane & 15;
+  // workgroup -> (row panel, column split).  Blocks b and b + 8 share an XCD: the nsplit workgroups of one row panel are made XCD
+  // neighbours (its rows come from HBM once, the other splits hit that L2); speed only.
+  int panel, split;
+  {
+    const int id = blockIdx.x;
+    if ((p.npanels & 7) == 0) { const int xcd = id & 7, j = id >> 3; panel = (j / p.nsplit) * 8 + xcd; split = j % p.nsplit; }
+    else { panel = id / p.nsplit; split = id % p.nsplit; }
+  }
+  const int nchunks = p.N / BN;
+  const int c0 = split * nchunks / p.nsplit, c1 = (split + 1) * nchunks / p.nsplit;
+  const int m0 = panel * ROWS + wave * 32;
+  const unsigned lds0 = (unsigned)(size_t)(lptr_t*)smem;
+  int nstamp = 0;
+  auto stamp = [&]() { if (p.stamps && blockIdx.x == 0 && tid == 0 && nstamp < 32) p.stamps[nstamp++] = __builtin_amdgcn_s_memtime(); };
+  stamp();
+
+  // ---- weight panel by LDS-DMA: piece q = kt * 8 + i8 -> 8 rows x 128 B of sub-image kt; lane -> (row i8*8 + lane/8, 16-byte slot lane%8), the
+  // XOR swizzle baked into the tiled copy (lngemm_tile_weights_kernel).  Per-lane offsets are fixed; a panel moves the scalar offset.
+  // (p.w is the TILED copy: panel c = the 40 KiB LDS image itself, so that a piece is ONE contiguous KiB of global memory -- fetched as eight
+  // 128-byte row segments a panel took 3.7 K cycles to land on every CU at once, 22 GB/s per CU, and the kernel was bound by it)
+  const int w_voff = (wave * PPW) * 1024 + lane * 16;
+  const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, (int)((long long)p.N * C * 2), 0x00020000);
+  auto issue_piece = [&](int chunk, int buf, auto jc) {   // piece j of this wave's PPW pieces of panel `chunk`
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int j = decltype(jc)::value;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lptr_t*)(smem + buf * PANEL + wave * (PPW * 1024) + j * 1024), 16, w_voff + j * 1024, chunk * (BN * C * 2), 0, 0);
+#endif
+  };
+  auto issue_w = [&](int chunk, int buf) { sfor<0, PPW>([&](auto jc) { issue_piece(chunk, buf, jc); }); };
+  // ---- gamma / beta / this split's bias -> LDS (plain stores, then a barrier with no LDS-DMA in flight yet) ----
+  float* vec = reinterpret_cast<float*>(smem + VEC);
+  for (int i = tid; i < C; i += NW * 64) { vec[i] = p.gamma[i]; vec[C + i] = p.beta[i]; }
+  for (int i = tid; i < (c1 - c0) * BN; i += NW * 64) vec[2 * C + i] = p.bias ? p.bias[c0 * BN + i] : 0.f;
+  __syncthreads();
+  stamp();
+  if (c0 < c1) issue_w(c0, 0);       // the first two panels fly under the LayerNorm prologue
+  if (c0 + 1 < c1) issue_w(c0 + 1, 1);
+
+  // ---- LayerNorm prologue: rows m0 + mt*16 + l15; the lane holds channels ks*32 + g*8 .. +7 of every k-step = its MFMA B fragments ----
+  f16x8 af[MT][KS];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    int row = m0 + mt * 16 + l15;
+    row = row < p.M ? row : p.M - 1;
+    const f16* xr = p.x + (long long)row * p.ld + g * 8;
+    float v[KS][8];
+    float sum = 0.f;
+    {
+      uint4 hi[KS], lo[KS];
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        hi[ks] = *reinterpret_cast<const uint4*>(xr + ks * 32);
+        if constexpr (SPLIT) lo[ks] = *reinterpret_cast<const uint4*>(xr + p.lo + ks * 32);
+      }
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const f16x8 h = __builtin_bit_cast(f16x8, hi[ks]);
+        if constexpr (SPLIT) {
+          const f16x8 l = __builtin_bit_cast(f16x8, lo[ks]);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[ks][j] = (float)h[j] + (float)l[j];
+        } else {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[ks][j] = (float)h[j];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) sum += v[ks][j];
+      }
+    }
+    sum += __shfl_xor(sum, 16);
+    sum += __shfl_xor(sum, 32);
+    const float mean = sum * (1.0f / C);
+    float var = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { const float d = v[ks][j] - mean; var += d * d; }
+    var += __shfl_xor(var, 16);
+    var += __shfl_xor(var, 32);
+    const float rstd = rsqrtf(var * (1.0f / C) + p.eps);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const float4 g0 = *reinterpret_cast<const float4*>(vec + ks * 32 + g * 8), g1 = *reinterpret_cast<const float4*>(vec + ks * 32 + g * 8 + 4);
+      const float4 b0 = *reinterpret_cast<const float4*>(vec + C + ks * 32 + g * 8), b1 = *reinterpret_cast<const float4*>(vec + C + ks * 32 + g * 8 + 4);
+      const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w}, bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+      f16x8 o;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = (f16)((v[ks][j] - mean) * rstd * gg[j] + bb[j]);
+      af[mt][ks] = o;
+    }
+  }
+  stamp();
+
+  // ---- main loop over this split's weight panels ----
+  f32x4 acc[NT][MT], prev[NT][MT];
+  const unsigned wa0 = lds0 + (unsigned)(l15 * 128 + ((g ^ ((l15 >> 1) & 7)) << 4));   // + buf * PANEL + kt * 8192 + a * 2048; k-half 1: ^ 64
+  const unsigned stg = lds0 + STG + wave * 4096;
+
+  // Epilogue of one panel, as ten pieces (EPI: interleaved between the MFMA groups of the next panel; the data dependencies between pieces run
+  // through LDS and are covered by the in-order LDS queue plus the k-loop's own lgkmcnt waits, which are stricter with these operations in
+  // the stream).  prev[a][m][r] = y[row m*16 + l15][col a*16 + g*4 + r] of panel `chunk`.  The wave writes its 32 x 64 (GEGLU: 32 x 32) fp16
+  // tile into its LDS patch (8-byte units, 16-byte slots XOR-swizzled by the row pair) and reads it back row-contiguous: one 128-byte (64-byte)
+  // line per row and store.
+  float4 bq[NT];
+  uint4 tq[4];
+  f16x4 og[MT][NT / 2];
+  auto epi_piece = [&](auto sc, int chunk) {
+    constexpr int s = decltype(sc)::value;
+    if constexpr (s == 0) {
+      const unsigned bva = lds0 + VEC + (unsigned)(2 * C + (chunk - c0) * BN + g * 4) * 4;   // this lane's bias columns
+      sfor<0, NT>([&](auto ac) { constexpr int a = decltype(ac)::value; lds_read128f<a * 64>(bq[a], bva); });
+    } else if constexpr (!GEGLU) {
+      if constexpr (s >= 1 && s <= 4) {                   // two 16 x 16 tiles per piece
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int t = 2 * (s - 1) + h, m = t >> 2, a = t & 3, r = m * 16 + l15;
+          const float4 b4 = bq[a];
+          const f16x4 o = {(f16)(prev[a][m][0] + b4.x), (f16)(prev[a][m][1] + b4.y), (f16)(prev[a][m][2] + b4.z), (f16)(prev[a][m][3] + b4.w)};
+          const int unit = a * 4 + g;                                       // 8-byte unit of the 128-byte row
+          lds_write64<0>(stg + r * 128 + ((((unit >> 1) ^ ((r >> 1) & 7)) << 4) | ((unit & 1) << 3)), __builtin_bit_cast(uint2, o));
+        }
+      } else if constexpr (s == 5) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int r = i * 8 + (lane >> 3);
+          lds_read128u<0>(tq[i], stg + r * 128 + (((lane & 7) ^ ((r >> 1) & 7)) << 4));
+        }
+      } else if constexpr (s == 9) {                      // (the k-loop's wait of step 6 has retired the reads of piece 5; last: behind this iteration's DMA pieces)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int r = i * 8 + (lane >> 3), row = m0 + r;
+          if (row < p.M) *reinterpret_cast<uint4*>(p.y + (long long)row * p.ldy + chunk * BN + (lane & 7) * 8) = tq[i];
+        }
+      }
+    } else {
+      if constexpr (s >= 1 && s <= 8) {                   // two of the sixteen x * gelu(gate) values per piece
+        constexpr int t = (s - 1) >> 1, hf = (s - 1) & 1, m = t >> 1, q = t & 1;
+        const float4 bx = bq[2 * q], bg = bq[2 * q + 1];
+        const float bxs[4] = {bx.x, bx.y, bx.z, bx.w}, bgs[4] = {bg.x, bg.y, bg.z, bg.w};
+#pragma unroll
+        for (int e = 2 * hf; e < 2 * hf + 2; ++e) og[m][q][e] = (f16)((prev[2 * q][m][e] + bxs[e]) * gelu_erf(prev[2 * q + 1][m][e] + bgs[e]));
+        if constexpr (hf == 1) {
+          const int r = m * 16 + l15, unit = q * 4 + g;                     // 8-byte unit of the 64-byte row
+          lds_write64<0>(stg + r * 64 + ((((unit >> 1) ^ ((r >> 1) & 3)) << 4) | ((unit & 1) << 3)), __builtin_bit_cast(uint2, og[m][q]));
+        }
+      } else if constexpr (s == 9) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const int r = i * 16 + (lane >> 2);
+          lds_read128u<0>(tq[i], stg + r * 64 + (((lane & 3) ^ ((r >> 1) & 3)) << 4));
+        }
+      }
+    }
+  };
+  auto epi_tail = [&](int chunk) {      // GEGLU: the stores behind the last piece's reads (plain: done in piece 9)
+    if constexpr (GEGLU) {
+      lds_wait_all();
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int r = i * 16 + (lane >> 2), row = m0 + r;
+        if (row < p.M) *reinterpret_cast<uint4*>(p.y + (long long)row * p.ldy + chunk * (BN / 2) + (lane & 3) * 8) = tq[i];
+      }
+    }
+  };
+
+  // The MFMAs of one panel.  Between them, one piece per k-step each: the LDS-DMA of panel `dma_chunk` (a piece costs the wave ~100 issue cycles:
+  // ten in a row behind the barrier were 30 % of an iteration) and -- EPI -- the epilogue of the previous panel (in `prev`).  sched_group_barrier
+  // asks for the VALU work to sit in the MFMAs' issue shadows (an MFMA holds the vector issue port for 8 of its 16 cycles) instead of behind them.
+  auto mfma_panel = [&](int buf, auto epic, int chunk_prev, auto dmac, int dma_chunk, int dma_buf) {
+    constexpr bool EPI = decltype(epic)::value, DMA = decltype(dmac)::value;   // (compile time: a runtime branch inside a k-step would cut the scheduling region)
+#pragma unroll
+    for (int a = 0; a < NT; ++a)
+#pragma unroll
+      for (int m = 0; m < MT; ++m) acc[a][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const unsigned wa = wa0 + buf * PANEL, wb = wa ^ 64u;
+    f16x8 wf[2][NT];
+    sfor<0, NT>([&](auto ac) { constexpr int a = decltype(ac)::value; lds_read128<a * 2048>(wf[0][a], wa); });
+    sfor<0, KS>([&](auto sc) {
+      constexpr int s = decltype(sc)::value, cur = s & 1, nxt = cur ^ 1;
+      if constexpr (s + 1 < KS) {
+        constexpr int kt = (s + 1) >> 1;
+        if constexpr (((s + 1) & 1) == 0) sfor<0, NT>([&](auto ac) { constexpr int a = decltype(ac)::value; lds_read128<kt * 8192 + a * 2048>(wf[nxt][a], wa); });
+        else sfor<0, NT>([&](auto ac) { constexpr int a = decltype(ac)::value; lds_read128<kt * 8192 + a * 2048>(wf[nxt][a], wb); });
+        lds_wait4<NT>(wf[cur][0], wf[cur][1], wf[cur][2], wf[cur][3]);   // everything but the NT reads just issued (the previous piece's LDS traffic included)
+      } else {
+        lds_wait4<0>(wf[cur][0], wf[cur][1], wf[cur][2], wf[cur][3]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int a = 0; a < NT; ++a)
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acc[a][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[cur][a], af[m][s], acc[a][m], 0, 0, 0);
+      if constexpr (DMA) issue_piece(dma_chunk, dma_buf, sc);
+      if constexpr (EPI) epi_piece(sc, chunk_prev);
+      if constexpr (EPI) {
+#pragma unroll
+        for (int k = 0; k < NT * MT; ++k) {
+          __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);                    // one MFMA
+          __builtin_amdgcn_sched_group_barrier(0x2, GEGLU ? 10 : 4, 0);       // ... and the VALU work that fits its shadow
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    });
+    if constexpr (EPI) epi_tail(chunk_prev);
+  };
+
+  for (int c = c0; c < c1; ++c) {
+    const int i = c - c0, buf = i % NBUF;
+    // panel c has landed for this wave's pieces: everything issued after them may still be in flight -- the stores of panel c - 3 (same
+    // iteration as the DMA of c), the DMA of panel c + 1 and the stores of panel c - 2 (the iteration after) -- then a barrier for every wave's pieces
+    // (a wave whose 32 rows are not all inside M may issue fewer stores than NST: it counts none, which only makes its wait stricter)
+    const int nst = m0 + 32 <= p.M ? NST : 0;
+    wait_vm((i >= 3 ? nst : 0) + (c + 1 < c1 ? PPW : 0) + (i >= 2 ? nst : 0));
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    stamp();
+    // the DMA of panel c + 2 goes into the buffer of panel c - 1: every wave is past its reads of it (the barrier above)
+    const int db = (i + 2) % NBUF;
+    if (c + 2 < c1) { if (i == 0) mfma_panel(buf, std::false_type{}, 0, std::true_type{}, c + 2, db); else mfma_panel(buf, std::true_type{}, c - 1, std::true_type{}, c + 2, db); }
+    else { if (i == 0) mfma_panel(buf, std::false_type{}, 0, std::false_type{}, 0, 0); else mfma_panel(buf, std::true_type{}, c - 1, std::false_type{}, 0, 0); }
+#pragma unroll
+    for (int a = 0; a < NT; ++a)
+#pragma unroll
+      for (int m = 0; m < MT; ++m) prev[a][m] = acc[a][m];
+    stamp();
+  }
+  if (c1 > c0) {   // the last panel's epilogue has no matrix work to hide behind
+    sfor<0, KS>([&](auto sc) {
+      epi_piece(sc, c1 - 1);
+      lds_wait_all();
+      __builtin_amdgcn_sched_barrier(0);
+    });
+    epi_tail(c1 - 1);
+  }
+  stamp();
+}
+
+// [N][C] K-major -> per 64-row panel the LDS image the kernel reads: [panel][kt = C/64][8 row blocks][lane = 8 rows x 8 slots][16 B], the slot of
+// row r, k-chunk c at c ^ ((r >> 1) & 7) (conflict-free ds_read_b128, kernels_gemm.hip)
+__global__ void lngemm_tile_weights_kernel(const f16* __restrict__ w, f16* __restrict__ wt, int N, int C) {
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;   // one 16-byte chunk each
+  const int KT = C >> 6;
+  if (t >= (long long)(N >> 6) * KT * 512) return;
+  const int lane = (int)(t & 63), i8 = (int)((t >> 6) & 7);
+  const long long f = t >> 9;
+  const int kt = (int)(f % KT), panel = (int)(f / KT);
+  const int r = i8 * 8 + (lane >> 3), pos = lane & 7;
+  *reinterpret_cast<uint4*>(wt + t * 8) = *reinterpret_cast<const uint4*>(w + ((long long)panel * 64 + r) * C + kt * 64 + ((pos ^ ((r >> 1) & 7)) << 3));
+}
+
+template <int C, bool GEGLU, bool SPLIT>
+void launch_t(const LnGemmParams& p, hipStream_t s) {
+  const size_t smem = (size_t)NBUF * BN * C * 2 + NW * 4096 + (size_t)(2 * C + p.N) * 4;
+  auto kern = lngemm_kernel<C, GEGLU, SPLIT>;
+  ensure_dyn_smem(reinterpret_cast<const void*>(kern), (int)smem);
+  hipLaunchKernelGGL(kern, dim3(p.npanels * p.nsplit), dim3(NW * 64), smem, s, p);
+  HIP_CHECK(hipGetLastError());
+}
+
+int num_cus() {   // of the current device (the library keeps no process-wide device state: looked up per call, a cheap attribute read)
+  int dev = 0, n = 0;
+  HIP_CHECK(hipGetDevice(&dev));
+  HIP_CHECK(hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev));
+  return n > 0 ? n : 256;
+}
+
+}  // namespace
+
+// LDIFF_LNGEMM: 1 (default) on where eligible, 0 off (the LayerNorm launch + LDS-DMA GEMM of round 3: A/B timing)
+bool lngemm_eligible(int C, int N, int ldx, int x_lo, int ldy, bool geglu) {
+  static const int mode = [] { const char* e = getenv("LDIFF_LNGEMM"); return e ? atoi(e) : 1; }();
+  if (mode == 0) return false;
+  // (N <= 2560: gamma, beta and the bias of a column split live in LDS beside the three weight buffers)
+  return C == 320 && N % BN == 0 && N >= BN && N <= 2560 && ldx % 8 == 0 && x_lo % 8 == 0 && ldy % 8 == 0 && (!geglu || N % 128 == 0);
+}
+
+void launch_lngemm_tile_weights(const f16* w, f16* wt, int N, int C, hipStream_t s) {
+  LDIFF_CHECK(N % BN == 0 && C % 64 == 0, LDIFF_ERR_INVALID, "ln_linear: weight tiling needs N %% 64 == 0 and C %% 64 == 0");
+  const long long n = (long long)N * C / 8;
+  hipLaunchKernelGGL(lngemm_tile_weights_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, w, wt, N, C);
+  HIP_CHECK(hipGetLastError());
+}
+
+void launch_lngemm(const f16* x, int ldx, int x_lo, int M, int C, const float* gamma, const float* beta, float eps, const f16* w_tiled, int N,
+                   const float* bias, bool geglu, f16* y, int ldy, hipStream_t s) {
+  LDIFF_CHECK(lngemm_eligible(C, N, ldx, x_lo, ldy, geglu) && M > 0, LDIFF_ERR_INVALID, "ln_linear: unsupported shape (C=%d N=%d M=%d)", C, N, M);
+  LDIFF_CHECK((long long)M * ldx * 2 < (1LL << 40) && (long long)N * C * 2 < (1LL << 31), LDIFF_ERR_INVALID, "ln_linear: operand too large");
+  LnGemmParams p;
+  p.x = x; p.ld = ldx; p.lo = x_lo; p.M = M; p.gamma = gamma; p.beta = beta; p.eps = eps;
+  p.w = w_tiled; p.N = N; p.bias = bias; p.y = y; p.ldy = ldy;
+  // The rows are cut as finely as a workgroup goes (128); the columns are split only when that leaves CUs without a row panel (every split
+  // reads and normalises its rows again).  LDIFF_LNGEMM_NSPLIT: diagnostic.
+  static const int ns_env = [] { const char* e = getenv("LDIFF_LNGEMM_NSPLIT"); return e ? atoi(e) : 0; }();
+  const int nchunks = N / BN, cus = num_cus();
+  p.npanels = (M + ROWS - 1) / ROWS;
+  int ns = ns_env ? ns_env : cus / p.npanels;
+  ns = ns < 1 ? 1 : ns;
+  if (ns > nchunks / 2) ns = nchunks / 2 > 0 ? nchunks / 2 : 1;
+  p.nsplit = ns;
+  static const std::string pname = "lngemm<320>", pname_g = "lngemm<320,geglu>";
+  const double bytes = (double)M * C * (x_lo ? 4.0 : 2.0) + (double)N * C * 2.0 + (double)M * (geglu ? N / 2 : N) * 2.0;
+  ProfScope prof(geglu ? pname_g.c_str() : pname.c_str(), 2.0 * M * (double)N * C, bytes, s);
+  static const bool stamps = getenv("LDIFF_LNGEMM_STAMPS") != nullptr;   // diagnostic
+  p.stamps = nullptr;
+  if (stamps) { HIP_CHECK(hipMalloc(&p.stamps, 32 * 8)); HIP_CHECK(hipMemset(p.stamps, 0, 32 * 8)); }
+  if (geglu) { if (x_lo) launch_t<320, true, true>(p, s); else launch_t<320, true, false>(p, s); }
+  else { if (x_lo) launch_t<320, false, true>(p, s); else launch_t<320, false, false>(p, s); }
+  if (stamps) {
+    unsigned long long h[32];
+    HIP_CHECK(hipStreamSynchronize(s));
+    HIP_CHECK(hipMemcpy(h, p.stamps, sizeof(h), hipMemcpyDeviceToHost));
+    HIP_CHECK(hipFree(p.stamps));
+    fprintf(stderr, "[lngemm stamps] N=%d geglu=%d nsplit=%d workgroup 0 wave 0 (ticks since its first stamp):", N, (int)geglu, p.nsplit);
+    for (int i = 1; i < 32 && h[i]; ++i) fprintf(stderr, " %llu", h[i] - h[0]);
+    fprintf(stderr, "\n");
+  }
+}

@@ -42,6 +42,7 @@ struct MatW {   // [Nrows][K] fp16 K-major + fp32 bias
   mutable Derived dup;            //   split operand: [Nrows][taps][2*Cin] (same weights against the hi and the lo half); key = C1 of a concat
   mutable Derived dup_par;        //   parity weights of the duplicated matrix
   mutable Derived frag;           //   MFMA-fragment-packed copy for the dataflow conv3x3 kernel (kernels_conv3x3d.hip)
+  mutable Derived tiled;          //   panel-tiled copy for the LayerNorm-fused GEMM (kernels_gemm_ast.hip)
 };
 struct NormW { float* g = nullptr; float* b = nullptr; int C = 0; };
 struct GNss { float* scale = nullptr; float* shift = nullptr; };
@@ -115,6 +116,7 @@ class Exec {
   const f16* derived_dup(const MatW& w, int C1_logical, int C2_logical);
   const f16* derived_par(const MatW& w, const f16* src, int Cin, Derived& d);
   const f16* derived_frag(const MatW& w, const ConvParams& p);
+  const f16* derived_tiled(const MatW& w, int N);
   Act norm_apply(const Act& x, const Act* x2, const GNss& g, bool silu, bool split_out);
   void release(Act& a);
   template <typename T> T* tmp(size_t n) { return reinterpret_cast<T*>(arena.alloc(n * sizeof(T))); }
@@ -122,6 +124,8 @@ class Exec {
   void release(GNss& g);
   Act conv(const MatW& w, const Act& x, const Act* x2, const ConvOpts& o);
   Act layernorm(const Act& x, const NormW& w);
+  // LayerNorm + linear (+ GEGLU) in one launch where the activation-stationary kernel takes the shape (kernels_gemm_ast.hip), else the two launches
+  Act ln_linear(const MatW& w, const Act& x, const NormW& ln, bool geglu);
   Act geglu(const Act& x);
   // ResnetBlock2D (UNet: with time embedding and optional skip concat; VAE: neither) under storage policy `prec`
   Act resnet(const struct ResnetW& r, const Act& x, const Act* skip, const float* temb, int ld_temb, int groups, float eps, int prec);

@@ -290,6 +290,20 @@ const f16* Exec::derived_frag(const MatW& w, const ConvParams& p) {
   }
   return w.frag.p;
 }
+const f16* Exec::derived_tiled(const MatW& w, int N) {
+  const int gen = weights_gen ? *weights_gen : 0;
+  if (!w.tiled.p) {
+    void* q = nullptr;
+    HIP_CHECK(hipMalloc(&q, (size_t)N * w.K * sizeof(f16)));
+    owned.push_back(q);
+    w.tiled.p = (f16*)q;
+  }
+  if (w.tiled.gen != gen) {   // first use, or the checkpoint was reloaded since
+    launch_lngemm_tile_weights(w.w, w.tiled.p, N, w.K, s);
+    w.tiled.gen = gen;
+  }
+  return w.tiled.p;
+}
 const f16* Exec::derived_par(const MatW& w, const f16* src, int Cin, Derived& d) {
   const int gen = weights_gen ? *weights_gen : 0;
   if (!d.p) {
@@ -411,6 +425,27 @@ Act Exec::norm_apply(const Act& x, const Act* x2, const GNss& g, bool silu, bool
 Act Exec::layernorm(const Act& x, const NormW& w) {
   Act y = new_act(x.B, x.H, x.W, x.C);
   launch_layernorm(x.view(), y.p, (int)x.rows(), w.g, w.b, 1e-5f, s);
+  return y;
+}
+Act Exec::ln_linear(const MatW& w, const Act& x, const NormW& ln, bool geglu) {
+  const int N = roundup(w.N, 4);
+  const bool fused_geglu = geglu && w.geglu;
+  const int Cout = fused_geglu ? N / 2 : N, ldy = roundup(Cout, 8);
+  if (w.ks == 1 && w.K == x.C && w.Nrows >= N && lngemm_eligible(x.C, N, x.ld(), x.lo(), ldy, fused_geglu) && ldy == Cout && (!geglu || fused_geglu)) {
+    Act y = new_act(x.B, x.H, x.W, Cout);
+    launch_lngemm(x.p, x.ld(), x.lo(), (int)x.rows(), x.C, ln.g, ln.b, 1e-5f, derived_tiled(w, N), N, w.b, fused_geglu, y.p, y.ld(), s);
+    return y;
+  }
+  Act n = layernorm(x, ln);
+  ConvOpts o;
+  o.geglu = fused_geglu;
+  Act y = conv(w, n, nullptr, o);
+  release(n);
+  if (geglu && !fused_geglu) {   // channel counts the fused epilogue does not take: projection, then the standalone activation
+    Act gg = this->geglu(y);
+    release(y);
+    return gg;
+  }
   return y;
 }
 Act Exec::geglu(const Act& x) {
@@ -645,9 +680,7 @@ Act ldiff_unet::transformer(const TransformerW& t, const Act& x) {
   }
   ex.release(g);
   // self-attention
-  Act n1 = ex.layernorm(h, t.ln1);
-  Act qkv = ex.conv(t.qkv, n1, nullptr, ConvOpts());
-  ex.release(n1);
+  Act qkv = ex.ln_linear(t.qkv, h, t.ln1, false);
   Act a1 = ex.new_act(x.B, x.H, x.W, C);
   AttnParams ap;
   ap.q = qkv.p; ap.ldq = 3 * C; ap.k = qkv.p + C; ap.ldk = 3 * C; ap.v = qkv.p + 2 * C; ap.ldv = 3 * C;
@@ -662,9 +695,7 @@ Act ldiff_unet::transformer(const TransformerW& t, const Act& x) {
   ex.release(a1);
   ex.release(h);
   // cross-attention (K/V precomputed per prompt)
-  Act n2 = ex.layernorm(h2, t.ln2);
-  Act q2 = ex.conv(t.q2, n2, nullptr, ConvOpts());
-  ex.release(n2);
+  Act q2 = ex.ln_linear(t.q2, h2, t.ln2, false);
   Act a2 = ex.new_act(x.B, x.H, x.W, C);
   ap.q = q2.p; ap.ldq = C; ap.k = t.kv_ctx; ap.ldk = 2 * C; ap.v = t.kv_ctx + C; ap.ldv = 2 * C;
   ap.o = a2.p; ap.Lk = ctx_L; ap.q_bstride = (long long)L * C;
@@ -677,16 +708,7 @@ Act ldiff_unet::transformer(const TransformerW& t, const Act& x) {
   ex.release(a2);
   ex.release(h2);
   // GEGLU feed-forward
-  Act n3 = ex.layernorm(h3, t.ln3);
-  ConvOpts of1;
-  of1.geglu = t.ff1.geglu;
-  Act f1 = ex.conv(t.ff1, n3, nullptr, of1);
-  ex.release(n3);
-  Act gg = f1;
-  if (!t.ff1.geglu) {   // channel counts the DMA GEMM does not take: projection, then the standalone activation
-    gg = ex.geglu(f1);
-    ex.release(f1);
-  }
+  Act gg = ex.ln_linear(t.ff1, h3, t.ln3, true);
   ConvOpts o3;
   o3.res = &h3; o3.split_out = st;
   Act h4 = ex.conv(t.ff2, gg, nullptr, o3);

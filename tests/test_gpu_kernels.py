@@ -780,3 +780,77 @@ def test_layernorm_and_groupnorm_statistics_read_split_tensors(lib):
     ref = F.group_norm(xr.permute(0, 2, 1), 32, gam, bet, 1e-5).permute(0, 2, 1)
     assert (got - ref).abs().max() <= 2e-5 * max(1.0, ref.abs().max())
 
+
+
+# ======================================================================================================================
+# LayerNorm folded into the consuming linear layer (kernels_gemm_ast.hip): activations stationary in registers
+# ======================================================================================================================
+def _geglu_perm(inner):
+    perm = torch.empty(2 * inner, dtype=torch.long)
+    for r in range(2 * inner):
+        q = r if r < inner else r - inner
+        perm[(q // 16) * 32 + (0 if r < inner else 16) + q % 16] = r
+    return perm
+
+
+@pytest.mark.parametrize("M,N,split,geglu", [(512, 960, True, False), (300, 320, True, False), (1024, 2560, True, True), (256, 64, False, False),
+                                             (777, 320, False, False), (33, 256, False, True), (8192, 960, True, False)])
+def test_ln_linear_fused(lib, M, N, split, geglu):
+    """y = LayerNorm(x) W^T + bias (+ GEGLU) in ONE launch (ldiff_op_ln_linear) against torch: LayerNorm of the fp32 value (hi + lo of a split
+    tensor), ONE fp16 rounding of the normalised operand, fp32 accumulation -- the arithmetic of the two-launch form (ldiff_op_layernorm +
+    ldiff_op_conv) it replaces on the C = 320 level of the UNet (norm1 -> to_q/k/v, norm2 -> attn2.to_q, norm3 -> ff.net.0.proj).  Row counts
+    that do not fill the 256-row workgroup, odd panel counts (column splits of unequal length), ragged last rows."""
+    Cc = 320
+    g = torch.Generator().manual_seed(M + N)
+    x = torch.randn((M, Cc), generator=g) * 2 + 0.5
+    x[0] *= 30.0                                                                    # a row far from the others' scale
+    gamma, beta = 1 + 0.1 * torch.randn(Cc, generator=g), 0.1 * torch.randn(Cc, generator=g)
+    w = torch.randn((N, Cc), generator=g) / math.sqrt(Cc)
+    b = torch.randn(N, generator=g) * 0.2
+    xs = to_split(x) if split else x.to(torch.float16)
+    xv = from_split(xs, Cc) if split else xs.float()
+    a16 = r16(F.layer_norm(xv, (Cc,), gamma, beta, 1e-5))
+    proj = a16 @ r16(w).t() + b
+    if geglu:
+        inner = N // 2
+        ref = proj[:, :inner] * F.gelu(proj[:, inner:])
+        perm = _geglu_perm(inner)
+        w, b = w[perm], b[perm]
+    else:
+        ref = proj
+    xd, wd, bd, gd, btd = xs.to(DEV), w.to(torch.float16).contiguous().to(DEV), b.contiguous().to(DEV), gamma.to(DEV), beta.to(DEV)
+    Nout = N // 2 if geglu else N
+    for bias in (bd, None):
+        y = torch.full((M, Nout), float("nan"), dtype=torch.float16, device=DEV)
+        _lib.check(lib.ldiff_op_ln_linear(xd.data_ptr(), 2 * Cc if split else Cc, Cc if split else 0, M, Cc, gd.data_ptr(), btd.data_ptr(), 1e-5, wd.data_ptr(), N, N,
+                                          None if bias is None else bias.data_ptr(), 1 if geglu else 0, y.data_ptr(), Nout, sp()))
+        torch.cuda.synchronize()
+        if bias is None:
+            pr = a16 @ r16(w).t()
+            want = pr[:, :N // 2] * F.gelu(pr[:, N // 2:]) if False else None
+            if geglu:
+                p0 = a16 @ r16(w[torch.argsort(_geglu_perm(N // 2))]).t()
+                want = p0[:, :N // 2] * F.gelu(p0[:, N // 2:])
+            else:
+                want = pr
+        else:
+            want = ref
+        # the normalised operand may round differently in the last fp16 bit where the kernel's fp32 LayerNorm and torch's differ by an ulp
+        assert_close(y, want, f"ln_linear M={M} N={N} split={split} geglu={geglu} bias={bias is not None}", rtol=2e-3, atol_rel=1.5e-3)
+    # equal to the two-launch form to fp32 accumulation order
+    n = torch.empty((M, Cc), dtype=torch.float16, device=DEV)
+    _lib.check(lib.ldiff_op_layernorm(xd.data_ptr(), 2 * Cc if split else Cc, Cc if split else 0, n.data_ptr(), M, Cc, gd.data_ptr(), btd.data_ptr(), 1e-5, sp()))
+    y2 = torch.full((M, Nout), float("nan"), dtype=torch.float16, device=DEV)
+    a = _lib.ConvArgs()
+    a.x, a.C1, a.B, a.Hin, a.Win, a.Hout, a.Wout, a.ks, a.stride = n.data_ptr(), Cc, 1, 1, M, 1, M, 1, 1
+    a.w, a.N, a.Nrows, a.bias, a.y, a.ldy, a.geglu = wd.data_ptr(), N, N, bd.data_ptr(), y2.data_ptr(), Nout, 1 if geglu else 0
+    _lib.check(lib.ldiff_op_conv(C.byref(a), sp()))
+    y1 = torch.empty_like(y2)
+    _lib.check(lib.ldiff_op_ln_linear(xd.data_ptr(), 2 * Cc if split else Cc, Cc if split else 0, M, Cc, gd.data_ptr(), btd.data_ptr(), 1e-5, wd.data_ptr(), N, N,
+                                      bd.data_ptr(), 1 if geglu else 0, y1.data_ptr(), Nout, sp()))
+    torch.cuda.synchronize()
+    d = (y1.float() - y2.float()).abs().max().item()
+    assert d <= 2e-3 * max(1.0, y2.float().abs().max().item()), f"fused vs two launches: {d:.3e}"
+    with pytest.raises(ValueError):     # shapes the kernel does not take are refused, not silently mis-computed
+        _lib.check(lib.ldiff_op_ln_linear(xd.data_ptr(), 2 * Cc if split else Cc, Cc if split else 0, M, Cc, gd.data_ptr(), btd.data_ptr(), 1e-5, wd.data_ptr(), 48, N,
+                                          bd.data_ptr(), 0, y1.data_ptr(), Nout, sp()))

@@ -17,4 +17,4 @@ N = 20
 for _ in range(N):
     unet(lat, 501, ctx)
 torch.cuda.synchronize()
-print(f"wall per pass {(time.perf_counter() - t0) / N * 1e3:.2f} ms over {N} passes ({N + 3} passes in the process)")
+print(f"unet step: wall per pass {(time.perf_counter() - t0) / N * 1e3:.2f} ms over {N} passes ({N + 3} passes in the process)")

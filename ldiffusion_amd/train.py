@@ -402,7 +402,7 @@ def finish_step(params, opt_state, lr, weight_decay, max_grad_norm, optimizer=No
 
 
 def train_step(unet, vae_dec, proj, z0, text_hidden, timesteps, abar, u_list, pairs, opt_state, lr=1e-5, weight_decay=0.01, loss_fn=None,
-               max_grad_norm=None, seed=0, offset=0, loss_scale=None):
+               max_grad_norm=None, seed=0, offset=0, loss_scale=None, optimizer=None):
     """One fine-tuning step (ldiffusion.py:209-255): text projection -> V5 features -> loss -> backward through the VAE decoder and the
     UNet -> gradient all-reduce -> (clipping) -> AdamW on the UNet and projection parameters.
     `proj` = (weight [D, 768], bias [D]) float32 CUDA parameters of the text projection.  `loss_fn(features, last_rgb)` defaults to the
@@ -419,7 +419,7 @@ def train_step(unet, vae_dec, proj, z0, text_hidden, timesteps, abar, u_list, pa
     (loss * loss_scale).backward()
     if loss_scale != 1.0:   # the parameter gradients are float32: unscale before the exchange, the clipping and AdamW
         torch._foreach_mul_([p.grad for p in params if p.grad is not None], 1.0 / loss_scale)
-    finish_step(params, opt_state, lr, weight_decay, max_grad_norm)
+    finish_step(params, opt_state, lr, weight_decay, max_grad_norm, optimizer=optimizer)   # optimizer: a ShardedAdamW over `params` (same collectives as the graphed step's)
     return float(loss.detach())
 
 

@@ -244,3 +244,66 @@ def test_graphed_step_with_the_sharded_optimizer():
     diffs = torch.cat([(a - b).abs().reshape(-1) for a, b in zip(finals[0][0], finals[1][0])])
     print(f"  parameters after two steps: max |difference| {diffs.max().item():.1e} (lr 1e-4), fraction beyond lr / 10: {(diffs > 1e-5).float().mean().item():.1e}")
     assert diffs.max().item() <= 4.1e-4 and (diffs > 1e-5).float().mean().item() <= 0.02
+
+
+_TWO_RANK_WORKER = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, {root!r})
+sys.path.insert(0, os.path.join({root!r}, "tests"))
+import test_gpu_train as T
+from ldiffusion_amd import train
+dist.init_process_group("gloo")                      # two ranks share cuda:0 (one-GPU box): gloo moves the CUDA buffers; on a node it is RCCL
+rank, DEV = dist.get_rank(), "cuda:0"
+ucfg, vcfg, usd, vsd, z0, hidden, proj_w, proj_b, sch, ts, u_list, pairs = T._setup()
+unet = train.TrainableUNet(ucfg, usd, DEV)
+dec = train.FrozenVAEDecoder(vcfg, vsd, DEV)
+proj = (proj_w.to(DEV).requires_grad_(True), proj_b.to(DEV).requires_grad_(True))
+params = unet.parameters() + list(proj)
+opt = train.ShardedAdamW(params, lr=1e-4, weight_decay=0.01)            # before the capture: the parameters move into its flat buffer
+assert opt.world == 2 and opt.m.numel() == (sum(p.numel() for p in params) + 1) // 2
+gstep = train.GraphedStep(unet, dec, proj, z0.shape[0], ts, sch.alphas_cumprod, latent_hw=8, text_len=hidden.shape[1], text_dim=hidden.shape[2],
+                          max_triples=32, num_negatives=64)
+zr = (z0 * (1.0 + 0.3 * rank)).to(DEV)                                   # every rank its own batch
+before = [p.detach().clone() for p in params[:4]]
+state, kinds, losses = {{}}, [], []
+for it in range(3):
+    # step 1: rank 1's batch is all background -- no sample triples: it must still enter the reduce-scatter / all-gather (eager step, zero gradients)
+    pr = [[], []] if (rank == 1 and it == 1) else pairs
+    val, kind = train.run_step(gstep, unet, dec, proj, zr, hidden.to(DEV), ts, sch.alphas_cumprod, pr, state, lr=1e-4, weight_decay=0.01, max_grad_norm=1.0,
+                               seed=rank, offset=it * 1000, optimizer=opt)
+    kinds.append(kind); losses.append(val)
+torch.cuda.synchronize()
+assert kinds == (["graph", "eager", "graph"] if rank == 1 else ["graph"] * 3), (rank, kinds)
+assert opt.step_count == 3 and all(l == l for l in losses)
+assert all(not torch.equal(p.detach(), b) for p, b in zip(params[:4], before))
+flat = opt.flat.detach().to("cpu")
+other = [torch.empty_like(flat) for _ in range(2)]
+dist.all_gather(other, flat)
+assert torch.equal(other[0], other[1]), "the ranks hold different parameters after the all-gather"
+assert torch.isfinite(flat).all()
+dist.barrier()
+dist.destroy_process_group()
+open(os.path.join({out!r}, "train%d.ok" % rank), "w").write(repr(losses))
+"""
+
+
+@pytest.mark.timeout(900)
+def test_graphed_step_and_sharded_adamw_on_two_ranks(tmp_path):
+    """BASELINE configs[4]'s step on TWO ranks: GraphedStep (forward + loss + backward replayed from one HIP graph) + ShardedAdamW (reduce-scatter of
+    the flat gradient bucket, AdamW on the rank's half with half of the moments, all-gather of the parameters) per rank, every rank its own
+    batch, one rank with an all-background batch in the middle (it steps eagerly with zero gradients and must meet the same collectives).  Both
+    ranks share the box's one GPU over gloo (CUDA tensors; probed: profiles/r04_gloo_cuda_probe.txt) -- on a node the same code runs over RCCL.
+    Asserted: no hang, three optimizer steps everywhere, bit-identical parameters on both ranks afterwards."""
+    import os, socket, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    script = tmp_path / "two_rank_worker.py"
+    script.write_text(_TWO_RANK_WORKER.format(root=root, out=str(tmp_path)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)]
+    env = dict(os.environ, OMP_NUM_THREADS="4", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=800, env=env)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert (tmp_path / "train0.ok").exists() and (tmp_path / "train1.ok").exists(), r.stdout[-2000:] + r.stderr[-2000:]
+    print("two-rank losses:", (tmp_path / "train0.ok").read_text(), (tmp_path / "train1.ok").read_text())

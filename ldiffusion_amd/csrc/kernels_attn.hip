@@ -30,6 +30,19 @@ struct VLayout {
   static constexpr int STR_DW = ((DV / 16) % 2 == 1) ? DV / 2 : DV / 2 + 8;  // row stride in dwords, == 8*odd
 };
 
+// max over lane pairs (l, l ^ 16) / (l, l ^ 32): v_permlane16_swap / v_permlane32_swap of the value with itself leave the two partners' values
+// side by side in the two results
+__device__ __forceinline__ float xmax16(float v) {
+  const unsigned u = __builtin_bit_cast(unsigned, v);
+  auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  return fmaxf(__builtin_bit_cast(float, (unsigned)r[0]), __builtin_bit_cast(float, (unsigned)r[1]));
+}
+__device__ __forceinline__ float xmax32(float v) {
+  const unsigned u = __builtin_bit_cast(unsigned, v);
+  auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  return fmaxf(__builtin_bit_cast(float, (unsigned)r[0]), __builtin_bit_cast(float, (unsigned)r[1]));
+}
+
 // MINW = waves per SIMD the register allocation must allow: 2 keeps the whole accumulator file in VGPRs (no
 // v_accvgpr_read/write traffic around the softmax / rescale VALU work); the large-head variants need 1.
 // ONES: the head dim leaves padding columns in the V tile (d < DV, e.g. 40 of 48): column d of V is set to 1, so row d of O^T
@@ -176,14 +189,29 @@ __global__ __launch_bounds__(256, MINW) void attn_kernel(const AttnParams p) {
             if (kv0 + t * 16 + g * 4 + r >= p.Lk) sacc[qt][t][r] = -1e30f;
       }
 #pragma unroll
-      for (int t = 0; t < NT; ++t)
+      for (int t = 0; t < NT; ++t) {   // (a max b) max c: one v_max3_f32 per two scores
+        mx = fmaxf(fmaxf(mx, sacc[qt][t][0]), sacc[qt][t][1]);
+        mx = fmaxf(fmaxf(mx, sacc[qt][t][2]), sacc[qt][t][3]);
+      }
+      mx = xmax16(mx);   // over the four lanes l15 + 16 g of the query (VALU lane swaps: no LDS crossbar round trip in the chain)
+      mx = xmax32(mx);
+      // Deferred rescale: the running maximum only moves when the tile's maximum exceeds it by more than p.rescale_log2 (8) in the exponent's
+      // (log2) units -- until then the probabilities are taken against the OLD maximum and may reach 2^8 instead of 1, which fp16 holds at the
+      // same relative precision and the fp32 accumulators do not notice.  The O-wide multiply, the factor's v_exp_f32 and their dependency
+      // chain then run on the first tile and on real jumps only (wave-uniform branch) instead of on every tile: the kernel is VALU-bound at
+      // d = 40.  Everything at the old scale (O^T, with the row sums in its row d or in lrun) is scaled exactly once, before this tile's P exists.
+      const bool need = (mx - mrun[qt]) * sl2 > p.rescale_log2;
+      float alpha = 1.0f;
+      if (__builtin_amdgcn_ballot_w64(need) != 0) {
+        const float mnew = need ? mx : mrun[qt];
+        alpha = __builtin_amdgcn_exp2f((mrun[qt] - mnew) * sl2);   // 1 where the row keeps its maximum
+        mrun[qt] = mnew;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) mx = fmaxf(mx, sacc[qt][t][r]);
-      mx = fmaxf(mx, __shfl_xor(mx, 16));
-      mx = fmaxf(mx, __shfl_xor(mx, 32));
-      const float mnew = fmaxf(mrun[qt], mx);
-      const float alpha = __builtin_amdgcn_exp2f((mrun[qt] - mnew) * sl2);
-      const float moff = -mnew * sl2;
+        for (int dt = 0; dt < DT; ++dt) {
+          oacc[qt][dt][0] *= alpha; oacc[qt][dt][1] *= alpha; oacc[qt][dt][2] *= alpha; oacc[qt][dt][3] *= alpha;
+        }
+      }
+      const float moff = -mrun[qt] * sl2;
       float rs = 0.f;
 #pragma unroll
       for (int t = 0; t < NT; ++t)
@@ -197,11 +225,6 @@ __global__ __launch_bounds__(256, MINW) void attn_kernel(const AttnParams p) {
         rs += __shfl_xor(rs, 16);
         rs += __shfl_xor(rs, 32);
         lrun[qt] = lrun[qt] * alpha + rs;
-      }
-      mrun[qt] = mnew;
-#pragma unroll
-      for (int dt = 0; dt < DT; ++dt) {
-        oacc[qt][dt][0] *= alpha; oacc[qt][dt][1] *= alpha; oacc[qt][dt][2] *= alpha; oacc[qt][dt][3] *= alpha;
       }
     }
 
@@ -272,7 +295,9 @@ static void launch_attn_cfg2(const AttnParams& p, hipStream_t s) {
   ProfScope prof(pname.c_str(), 4.0 * bh * p.Lq * p.Lk * p.d,
                  2.0 * bh * p.d * (2.0 * p.Lq + 2.0 * p.Lk * (p.kv_bstride ? 1.0 : 1.0 / p.B)), s);
   static const int xcd_mode = [] { const char* e = getenv("LDIFF_ATTN_XCD"); return e ? atoi(e) : 1; }();   // 0: the grid's own order (A/B timing)
+  static const float rescale = [] { const char* e = getenv("LDIFF_ATTN_RESCALE"); return e ? (float)atof(e) : 8.0f; }();   // 0: move the maximum on every growth (A/B, parity of the deferred form)
   AttnParams q = p;
+  q.rescale_log2 = rescale;
   q.xcd_order = xcd_mode && grid.x > 1 && p.Lk >= 256 ? 1 : 0;   // (short K / V, the cross-attention: nothing to share, the remap only costs; measured
                                                                     //  same box: 4096 x 4096, d = 40: 388 -> 378 us, 1024 x 1024, d = 80: 45.9 -> 43.0 us)
   hipLaunchKernelGGL(kern, grid, dim3(256), smem, s, q);

@@ -126,7 +126,7 @@ struct AttnParams {
   int B, heads, Lq, Lk, d;
   long long q_bstride, kv_bstride, o_bstride;  // batch strides in elements (kv_bstride 0 => broadcast)
   float scale;
-  float rescale_log2 = 8.0f;  // set by the launcher: deferred online-softmax rescale threshold in log2 units (kernels_attn.hip; 0 = rescale on every growth)
+  float rescale_log2 = 0.0f;  // set by the launcher: online-softmax rescale threshold in log2 units (kernels_attn.hip; 0 = the maximum moves on every growth)
   int xcd_order = 0;          // set by the launcher: workgroup -> (query tile, head, image) through the XCD-aware remap (kernels_attn.hip)
 };
 void launch_attention(const AttnParams& p, hipStream_t s);

@@ -195,9 +195,9 @@ __global__ __launch_bounds__(256, MINW) void attn_kernel(const AttnParams p) {
       }
       mx = xmax16(mx);   // over the four lanes l15 + 16 g of the query (VALU lane swaps: no LDS crossbar round trip in the chain)
       mx = xmax32(mx);
-      // Deferred rescale: the running maximum only moves when the tile's maximum exceeds it by more than p.rescale_log2 (8) in the exponent's
-      // (log2) units -- until then the probabilities are taken against the OLD maximum and may reach 2^8 instead of 1, which fp16 holds at the
-      // same relative precision and the fp32 accumulators do not notice.  The O-wide multiply, the factor's v_exp_f32 and their dependency
+      // Deferred rescale: the running maximum only moves when the tile's maximum exceeds it by more than p.rescale_log2 in the exponent's
+      // (log2) units -- until then the probabilities are taken against the OLD maximum and may reach 2^threshold instead of 1.  Threshold 0 (the default) is
+      // the classic rule with the rescale skipped, wave-uniformly, on the tiles where no row's maximum grew.  The O-wide multiply, the factor's v_exp_f32 and their dependency
       // chain then run on the first tile and on real jumps only (wave-uniform branch) instead of on every tile: the kernel is VALU-bound at
       // d = 40.  Everything at the old scale (O^T, with the row sums in its row d or in lrun) is scaled exactly once, before this tile's P exists.
       const bool need = (mx - mrun[qt]) * sl2 > p.rescale_log2;
@@ -295,7 +295,8 @@ static void launch_attn_cfg2(const AttnParams& p, hipStream_t s) {
   ProfScope prof(pname.c_str(), 4.0 * bh * p.Lq * p.Lk * p.d,
                  2.0 * bh * p.d * (2.0 * p.Lq + 2.0 * p.Lk * (p.kv_bstride ? 1.0 : 1.0 / p.B)), s);
   static const int xcd_mode = [] { const char* e = getenv("LDIFF_ATTN_XCD"); return e ? atoi(e) : 1; }();   // 0: the grid's own order (A/B timing)
-  static const float rescale = [] { const char* e = getenv("LDIFF_ATTN_RESCALE"); return e ? (float)atof(e) : 8.0f; }();   // 0: move the maximum on every growth (A/B, parity of the deferred form)
+  static const float rescale = [] { const char* e = getenv("LDIFF_ATTN_RESCALE"); return e ? (float)atof(e) : 0.0f; }();   // 0 (default): the maximum moves on every growth; 8: deferred (measured: -0.3 % of a UNet pass, but the
+                                                                                                                   // reduced-width UNet error at precision 2 rose 3.6e-4 -> 6.0e-4: profiles/r04_attention_deferred_rescale.txt)
   AttnParams q = p;
   q.rescale_log2 = rescale;
   q.xcd_order = xcd_mode && grid.x > 1 && p.Lk >= 256 ? 1 : 0;   // (short K / V, the cross-attention: nothing to share, the remap only costs; measured

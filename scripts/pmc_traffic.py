@@ -26,6 +26,8 @@ def bench_name(k):
     if m: return f"conv3x3<{m.group(1)}x{m.group(2)},{m.group(3)}{',gn' if m.group(4) == 'true' else ''}>"
     m = re.search(r"gemm_dma_kernel<(\d+), (\d+)>", k)
     if m: return f"gemm_dma<{m.group(1)},{m.group(2)}>"
+    m = re.search(r"lngemm_kernel<(\d+), (true|false),", k)
+    if m: return f"lngemm<{m.group(1)}{',geglu' if m.group(2) == 'true' else ''}>"
     if "attn_dsplit_kernel" in k: return "attn<512,512>"
     m = re.search(r"attn_kernel<(\d+), (\d+),", k)
     if m: return f"attn<{m.group(1)},{m.group(2)}>"

@@ -1222,3 +1222,35 @@ def test_pixel_csv_from_device_features(tiny, tmp_path):
         for key, values in pixel_dict.items():
             wr.writerow([key] + values)
     assert (tmp_path / "dev.csv").read_bytes() == (tmp_path / "ref.csv").read_bytes()
+
+
+def test_pixel_latent_vector_entry_point_mirror(tiny, tmp_path):
+    """Entry point B (pixel_latent_vector.py:58-102) end to end on the device: a loader of batch-size-1 (image, label) pairs -> N-pass sampler in
+    device batches -> one CSV per image, against the oracle's V6 loop run image by image (features within one grey level; rows, header and
+    label column exact; a batched run and a one-image-at-a-time run -- other split-K plans, i.e. another fp32 summation order -- agree within one
+    grey level)."""
+    import csv
+    from ldiffusion_amd import pixel_latent_vector as plv
+    g = torch.Generator().manual_seed(41)
+    N = 5
+    data = [(torch.rand((1, 3, 64, 64), generator=g), torch.randint(0, 6, (1, 1, 64, 64), generator=g)) for _ in range(5)]
+    ctx = torch.randn((1, 6, 64), generator=g) * 0.5
+    files = plv.pixel_latent_vector(tiny["pipe"], tiny["vae"], tiny["unet"], N, train_loader=data, text_embeddings=ctx, out_dir=str(tmp_path / "a"), batch_size=3)
+    single = plv.pixel_latent_vector(tiny["pipe"], None, None, N, train_loader=data, text_embeddings=ctx, out_dir=str(tmp_path / "b"), batch_size=1)
+    assert [os.path.basename(f) for f in files] == [f"pixel_dict_{i}.csv" for i in range(5)]
+    for fa, fb in zip(files, single):
+        ta, tb = (np.array([[int(v) for v in r[1:]] for r in list(csv.reader(open(f, newline="")))[1:]]) for f in (fa, fb))
+        assert ta.shape == tb.shape and np.abs(ta - tb).max() <= 1 and np.array_equal(ta[:, N], tb[:, N])
+    for i in (0, 4):
+        ref = op.sample_v6(tiny["opipe"], data[i][0], ctx, N)["features"][0]                      # [N, H, W] uint8
+        rows = list(csv.reader(open(files[i], newline="")))
+        assert rows[0] == plv.generate_title(N) and len(rows) == 1 + 64 * 64
+        assert rows[1 + 64 * 3 + 7][0] == "(3, 7)"
+        tab = np.array([[int(v) for v in r[1:]] for r in rows[1:]])
+        assert np.array_equal(tab[:, N], data[i][1][0, 0].numpy().reshape(-1))
+        d = np.abs(tab[:, :N].T.reshape(N, 64, 64) - ref.astype(int))
+        assert d.max() <= 1, f"image {i}: features more than one grey level from the oracle"
+    with pytest.raises(ValueError):
+        plv.pixel_latent_vector(tiny["pipe"], None, None, 2, train_loader=data, text_embeddings=ctx, out_dir=str(tmp_path / "c"))
+    with pytest.raises(RuntimeError):
+        plv.pixel_latent_vector(tiny["pipe"], None, None, 5, train_loader=None, text_embeddings=ctx)

@@ -129,6 +129,10 @@ def load() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    # torch first: it ships its own HIP runtime, and the library must bind to THAT copy -- loaded before torch, libldiff_hip.so pulls in
+    # /opt/rocm's libamdhip64 and the process ends up with two runtimes, of which ours sees no device (seen as "no ROCm-capable device is
+    # detected" from ldiff_vae_create when build() and smoke() ran in one process)
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(
             f"{LIB_PATH} not found: the gfx950 HIP extension is not built. Run `python -c \"import __graft_entry__ as g; g.build()\"` "

@@ -208,8 +208,11 @@ class Conv2dFn(torch.autograd.Function):
                 xcolT[Kc:].zero_()
             _lib.check(lib.ldiff_op_im2col_t(x.data_ptr(), xcolT.data_ptr(), B, H, W, Cx, k, stride, k // 2, ups, Ho, Wo, Mpad, _sp()))
             g = _conv_call(dyT.view(1, 1, Cy, Mpad), xcolT, Kc, 1, 1, 0, out_f32=True)        # [1,1,Cy,Kc] f32
-            dw = torch.empty(weight.shape, dtype=torch.float32, device=x.device)
-            _lib.check(lib.ldiff_op_unpack_wgrad(g.data_ptr(), dw.data_ptr(), Cout, Cin, k, Cx, g.shape[-1], _sp()))
+            if k == 1 and Cx == Cin and Cy == Cout and g.shape[-1] == Cin:
+                dw = g.view(weight.shape)   # 1 x 1 / linear with unpadded channel counts: the GEMM's [Cout][Cin] output IS the weight gradient (no unpack launch)
+            else:
+                dw = torch.empty(weight.shape, dtype=torch.float32, device=x.device)
+                _lib.check(lib.ldiff_op_unpack_wgrad(g.data_ptr(), dw.data_ptr(), Cout, Cin, k, Cx, g.shape[-1], _sp()))
         if has_bias and ctx.needs_input_grad[2]:
             db = torch.empty(Cy, dtype=torch.float32, device=x.device)
             _lib.check(lib.ldiff_op_colsum(dy.data_ptr(), db.data_ptr(), B * Ho * Wo, Cy, Cy, _sp()))

@@ -221,6 +221,11 @@ int ldiff_op_gn_finalize(const void* part1, int R1, int C1, const void* part2, i
                          const void* gamma, const void* beta, void* scale, void* shift, void* stream);
 int ldiff_op_attention(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, void* o, int ldo, int B, int heads,
                        int Lq, int Lk, int d, int64_t q_bstride, int64_t kv_bstride, int64_t o_bstride, float scale, void* stream);
+/* The same with q ALREADY multiplied by scale * log2(e) (the executors do that in the fp32 epilogue of the q/k/v projection, so q is still rounded
+ * once): the kernel then lets the MFMAs subtract the running softmax reference (a 1.0 in K's padding column against -reference in Q's) and skips the
+ * per-score FMA.  Head dims with a free column in the last 32-wide k-step only (d = 40, 80: the UNet's levels 0 and 1); others: LDIFF_ERR_INVALID. */
+int ldiff_op_attention_prescaled(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, void* o, int ldo, int B, int heads,
+                                 int Lq, int Lk, int d, int64_t q_bstride, int64_t kv_bstride, int64_t o_bstride, void* stream);
 /* sources are (pointer, channels C, row pitch ld (0 = C), lo offset (0 = plain, > 0 = split tensor hi|lo)) */
 int ldiff_op_gn_stats(const void* x, int C1, int ld1, int lo1, const void* x2, int C2, int ld2, int lo2, int B, int HW, int groups, float eps,
                       const void* gamma, const void* beta, void* scale, void* shift, void* stream);
@@ -228,9 +233,11 @@ int ldiff_op_layernorm(const void* x, int ldx, int x_lo, void* y, int rows, int 
 /* LayerNorm folded into the linear layer that consumes it (BasicTransformerBlock norm1 -> to_q/k/v, norm2 -> attn2.to_q, norm3 -> ff.net.0.proj):
  *   y[rows, N] = LayerNorm(x; gamma, beta, eps)[rows, C] . w[N, C]^T + bias,  x as in ldiff_op_layernorm (x_lo > 0: split rows hi | lo),
  *   the normalised operand rounded ONCE to fp16 (as the two-launch form does); geglu as in ldiff_conv_args (y has N/2 columns).
+ * qcols > 0 (a multiple of 64, no GEGLU): columns [0, qcols) are multiplied by qscale in fp32 before the rounding (q of a fused q/k/v projection for
+ * ldiff_op_attention_prescaled).
  * Returns LDIFF_ERR_INVALID for shapes the kernel does not take (C != 320, N % 64 != 0, ...): callers then use ldiff_op_layernorm + ldiff_op_conv. */
 int ldiff_op_ln_linear(const void* x, int ldx, int x_lo, int rows, int C, const void* gamma, const void* beta, float eps, const void* w, int N, int Nrows,
-                       const void* bias_or_null, int geglu, void* y, int ldy, void* stream);
+                       const void* bias_or_null, int geglu, void* y, int ldy, int qcols, float qscale, void* stream);
 /* y[m, c] = act(x[m, c] * scale[b, c] + shift[b, c]) (GroupNorm-apply, optional SiLU) over the concat of one or two sources,
  * written plain (y_lo = 0) or split */
 int ldiff_op_norm_apply(const void* x, int C1, int ld1, int lo1, const void* x2, int C2, int ld2, int lo2, int B, int HW, const void* scale,

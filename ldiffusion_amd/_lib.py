@@ -82,9 +82,10 @@ SIGNATURES = {
     "ldiff_op_conv_stats_blocks": (I, [C.POINTER(ConvArgs)]),
     "ldiff_op_gn_finalize": (I, [P, I, I, P, I, I, I, I, I, F, P, P, P, P, P]),
     "ldiff_op_attention": (I, [P, I, P, I, P, I, P, I, I, I, I, I, I, I64, I64, I64, F, P]),
+    "ldiff_op_attention_prescaled": (I, [P, I, P, I, P, I, P, I, I, I, I, I, I, I64, I64, I64, P]),
     "ldiff_op_gn_stats": (I, [P, I, I, I, P, I, I, I, I, I, I, F, P, P, P, P, P]),
     "ldiff_op_layernorm": (I, [P, I, I, P, I, I, P, P, F, P]),
-    "ldiff_op_ln_linear": (I, [P, I, I, I, I, P, P, F, P, I, I, P, I, P, I, P]),
+    "ldiff_op_ln_linear": (I, [P, I, I, I, I, P, P, F, P, I, I, P, I, P, I, I, F, P]),
     "ldiff_op_norm_apply": (I, [P, I, I, I, P, I, I, I, I, I, P, P, I, P, I, I, P]),
     "ldiff_op_dup_weights": (I, [P, P, I, I, I, I, I, I, P]),
     "ldiff_op_geglu": (I, [P, P, I64, I, P]),

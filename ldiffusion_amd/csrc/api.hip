@@ -486,6 +486,18 @@ int ldiff_op_attention(const void* q, int ldq, const void* k, int ldk, const voi
   launch_attention(p, (hipStream_t)stream);
   API_END
 }
+int ldiff_op_attention_prescaled(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, void* o, int ldo, int B, int heads, int Lq,
+                                 int Lk, int d, int64_t q_bstride, int64_t kv_bstride, int64_t o_bstride, void* stream) {
+  API_BEGIN
+  LDIFF_CHECK(q && k && v && o && B >= 1 && heads >= 1, LDIFF_ERR_INVALID, "op_attention_prescaled: bad arguments");
+  LDIFF_CHECK(attention_prescale_supported(d), LDIFF_ERR_INVALID, "op_attention_prescaled: head dim %d has no prescaled kernel (40 and 80 do)", d);
+  AttnParams p;
+  p.q = (const f16*)q; p.ldq = ldq; p.k = (const f16*)k; p.ldk = ldk; p.v = (const f16*)v; p.ldv = ldv; p.o = (f16*)o; p.ldo = ldo;
+  p.B = B; p.heads = heads; p.Lq = Lq; p.Lk = Lk; p.d = d;
+  p.q_bstride = q_bstride; p.kv_bstride = kv_bstride; p.o_bstride = o_bstride; p.scale = 1.0f; p.prescaled = 1;
+  launch_attention(p, (hipStream_t)stream);
+  API_END
+}
 int ldiff_op_gn_stats(const void* x, int C1, int ld1, int lo1, const void* x2, int C2, int ld2, int lo2, int B, int HW, int groups, float eps,
                       const void* gamma, const void* beta, void* scale, void* shift, void* stream) {
   API_BEGIN
@@ -503,7 +515,7 @@ int ldiff_op_layernorm(const void* x, int ldx, int x_lo, void* y, int rows, int 
   API_END
 }
 int ldiff_op_ln_linear(const void* x, int ldx, int x_lo, int rows, int Cc, const void* gamma, const void* beta, float eps, const void* w, int N, int Nrows,
-                       const void* bias, int geglu, void* y, int ldy, void* stream) {
+                       const void* bias, int geglu, void* y, int ldy, int qcols, float qscale, void* stream) {
   API_BEGIN
   LDIFF_CHECK(x && gamma && beta && w && y && rows >= 0, LDIFF_ERR_INVALID, "op_ln_linear: null argument");
   if (rows == 0) return LDIFF_OK;
@@ -512,7 +524,7 @@ int ldiff_op_ln_linear(const void* x, int ldx, int x_lo, int rows, int Cc, const
   f16* wt = (f16*)op_scratch((hipStream_t)stream, 4, (size_t)N * Cc * sizeof(f16));
   launch_lngemm_tile_weights((const f16*)w, wt, N, Cc, (hipStream_t)stream);
   launch_lngemm((const f16*)x, ldx ? ldx : Cc, x_lo, rows, Cc, (const float*)gamma, (const float*)beta, eps, wt, N, (const float*)bias, geglu != 0,
-                (f16*)y, ldy, (hipStream_t)stream);
+                (f16*)y, ldy, (hipStream_t)stream, qcols, qscale);
   API_END
 }
 int ldiff_op_norm_apply(const void* x, int C1, int ld1, int lo1, const void* x2, int C2, int ld2, int lo2, int B, int HW, const void* scale,

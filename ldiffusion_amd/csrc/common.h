@@ -112,7 +112,7 @@ void launch_conv3x3p(const ConvParams& p, hipStream_t s);
 bool lngemm_eligible(int C, int N, int ldx, int x_lo, int ldy, bool geglu);
 void launch_lngemm_tile_weights(const f16* w, f16* wt, int N, int C, hipStream_t s);   // [N][C] -> the panel images the kernel streams (N*C fp16)
 void launch_lngemm(const f16* x, int ldx, int x_lo, int M, int C, const float* gamma, const float* beta, float eps, const f16* w_tiled, int N,
-                   const float* bias, bool geglu, f16* y, int ldy, hipStream_t s);
+                   const float* bias, bool geglu, f16* y, int ldy, hipStream_t s, int qcols = 0, float qscale = 1.0f);   // columns [0, qcols) *= qscale before rounding
 bool gemm_dma_eligible(const ConvParams& p);
 void launch_gemm_dma(const ConvParams& p, hipStream_t s);      // kernels_gemm.hip
 
@@ -126,10 +126,12 @@ struct AttnParams {
   int B, heads, Lq, Lk, d;
   long long q_bstride, kv_bstride, o_bstride;  // batch strides in elements (kv_bstride 0 => broadcast)
   float scale;
+  int prescaled = 0;          // q already holds Q * scale * log2(e) (rounded once, by its producer): kernels_attn.hip PRE; `scale` is then unused
   float rescale_log2 = 0.0f;  // set by the launcher: online-softmax rescale threshold in log2 units (kernels_attn.hip; 0 = the maximum moves on every growth)
   int xcd_order = 0;          // set by the launcher: workgroup -> (query tile, head, image) through the XCD-aware remap (kernels_attn.hip)
 };
 void launch_attention(const AttnParams& p, hipStream_t s);
+bool attention_prescale_supported(int d);
 
 // ---- normalisation (kernels_norm.hip) --------------------------------------------------------
 // GroupNorm statistics over one or two NHWC sources (channel concat) -> per-(b,c) scale/shift (fp32):

@@ -47,7 +47,7 @@ __device__ __forceinline__ float xmax32(float v) {
 // v_accvgpr_read/write traffic around the softmax / rescale VALU work); the large-head variants need 1.
 // ONES: the head dim leaves padding columns in the V tile (d < DV, e.g. 40 of 48): column d of V is set to 1, so row d of O^T
 // accumulates the softmax row sums inside the P.V MFMAs and the per-score adds and cross-lane sums of the (VALU-bound) softmax go.
-template <int DQK, int DV, int BKV, int QT, int MINW, bool ONES>
+template <int DQK, int DV, int BKV, int QT, int MINW, bool ONES, bool PRE>
 __global__ __launch_bounds__(256, MINW) void attn_kernel(const AttnParams p) {
   using KL = KLayout<DQK>;
   constexpr int KS = DQK / 32;        // MFMA k-steps for Q K^T
@@ -94,10 +94,10 @@ __global__ __launch_bounds__(256, MINW) void attn_kernel(const AttnParams p) {
   }
 
   f32x4 oacc[QT][DT];
-  float mrun[QT], lrun[QT];
+  float mrun[QT], lrun[QT], mref[QT];   // mref: PRESCALED form, the running reference (an fp16 value, log2 units)
 #pragma unroll
   for (int qt = 0; qt < QT; ++qt) {
-    mrun[qt] = -1e30f; lrun[qt] = 0.f;
+    mrun[qt] = -1e30f; lrun[qt] = 0.f; mref[qt] = 0.f;
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) oacc[qt][dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
   }
@@ -115,6 +115,7 @@ __global__ __launch_bounds__(256, MINW) void attn_kernel(const AttnParams p) {
       const int c = tid + i * 256, row = c / (DQK / 8), ch = c - row * (DQK / 8);
       uint4 v = make_uint4(0, 0, 0, 0);
       if (c < KCH && kv0 + row < p.Lk && ch * 8 < d) v = *reinterpret_cast<const uint4*>(Kp + (long long)(kv0 + row) * p.ldk + ch * 8);
+      if (PRE && c < KCH && kv0 + row < p.Lk && ch * 8 == d) v.x = 0x3C00u;   // K[key][d] = 1.0: the MFMA then adds Q[q][d] = -reference to every score
       rk[i] = v;
     }
     if (PFV) {
@@ -195,13 +196,44 @@ __global__ __launch_bounds__(256, MINW) void attn_kernel(const AttnParams p) {
       }
       mx = xmax16(mx);   // over the four lanes l15 + 16 g of the query (VALU lane swaps: no LDS crossbar round trip in the chain)
       mx = xmax32(mx);
+      float alpha = 1.0f;
+      float rs = 0.f;
+      if constexpr (PRE) {
+        // PRESCALED form (AttnParams::prescaled): Q arrives multiplied by scale * log2(e) (in the producing GEMM's fp32 epilogue: same number
+        // of roundings), K carries 1.0 in padding column d and Q the NEGATED running reference there, so the MFMAs deliver S' - reference and
+        // the per-score FMA disappears: p = exp2(sacc).  The reference is an fp16 value (it lives in a Q fragment); softmax does not care which
+        // reference is used as long as every probability of the row uses the same one, which the fix-up below guarantees: on a tile where a
+        // row's maximum exceeds its reference (or on the first tile) the new reference is f16(reference + tile maximum), the difference is
+        // exact in fp32, this tile's scores are shifted by it, O^T (with the row sums in its row d or in lrun) is scaled by 2^-difference and
+        // the Q fragment is updated for the tiles to come.  Wave-uniform branch: after the first tiles it is rarely taken.
+        const bool need = kv0 == 0 || mx > p.rescale_log2;
+        if (__builtin_amdgcn_ballot_w64(need) != 0) {
+          const float rnew = need ? (float)(f16)(mref[qt] + mx) : mref[qt];
+          const float delta = rnew - mref[qt];
+          alpha = kv0 == 0 ? 0.f : __builtin_amdgcn_exp2f(-delta);
+          mref[qt] = rnew;
+          if (g == ((d & 31) >> 3)) qf[qt][DQK / 32 - 1][0] = (f16)(-rnew);   // (d % 8 == 0 and d >= DQK - 32: the padding column sits in the last k-step)
+#pragma unroll
+          for (int t = 0; t < NT; ++t) { sacc[qt][t][0] -= delta; sacc[qt][t][1] -= delta; sacc[qt][t][2] -= delta; sacc[qt][t][3] -= delta; }
+#pragma unroll
+          for (int dt = 0; dt < DT; ++dt) {
+            oacc[qt][dt][0] *= alpha; oacc[qt][dt][1] *= alpha; oacc[qt][dt][2] *= alpha; oacc[qt][dt][3] *= alpha;
+          }
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float pv = __builtin_amdgcn_exp2f(sacc[qt][t][r]);
+            if (!ONES) rs += pv;
+            pf[qt][t >> 1][(t & 1) * 4 + r] = (f16)pv;
+          }
+      } else {
       // Deferred rescale: the running maximum only moves when the tile's maximum exceeds it by more than p.rescale_log2 in the exponent's
       // (log2) units -- until then the probabilities are taken against the OLD maximum and may reach 2^threshold instead of 1.  Threshold 0 (the default) is
-      // the classic rule with the rescale skipped, wave-uniformly, on the tiles where no row's maximum grew.  The O-wide multiply, the factor's v_exp_f32 and their dependency
-      // chain then run on the first tile and on real jumps only (wave-uniform branch) instead of on every tile: the kernel is VALU-bound at
-      // d = 40.  Everything at the old scale (O^T, with the row sums in its row d or in lrun) is scaled exactly once, before this tile's P exists.
+      // the classic rule with the rescale skipped, wave-uniformly, on the tiles where no row's maximum grew.  Everything at the old scale (O^T, with
+      // the row sums in its row d or in lrun) is scaled exactly once, before this tile's P exists.
       const bool need = (mx - mrun[qt]) * sl2 > p.rescale_log2;
-      float alpha = 1.0f;
       if (__builtin_amdgcn_ballot_w64(need) != 0) {
         const float mnew = need ? mx : mrun[qt];
         alpha = __builtin_amdgcn_exp2f((mrun[qt] - mnew) * sl2);   // 1 where the row keeps its maximum
@@ -212,7 +244,6 @@ __global__ __launch_bounds__(256, MINW) void attn_kernel(const AttnParams p) {
         }
       }
       const float moff = -mrun[qt] * sl2;
-      float rs = 0.f;
 #pragma unroll
       for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -221,6 +252,7 @@ __global__ __launch_bounds__(256, MINW) void attn_kernel(const AttnParams p) {
           if (!ONES) rs += pv;
           pf[qt][t >> 1][(t & 1) * 4 + r] = (f16)pv;
         }
+      }
       if (!ONES) {
         rs += __shfl_xor(rs, 16);
         rs += __shfl_xor(rs, 32);
@@ -277,17 +309,28 @@ __global__ __launch_bounds__(256, MINW) void attn_kernel(const AttnParams p) {
   }
 }
 
-template <int DQK, int DV, int BKV, int QT, int MINW, bool ONES>
+template <int DQK, int DV, int BKV, int QT, int MINW, bool ONES, bool PRE>
 static void launch_attn_cfg2(const AttnParams& p, hipStream_t s);
 template <int DQK, int DV, int BKV, int QT, int MINW = 2>
 static void launch_attn_cfg(const AttnParams& p, hipStream_t s) {
-  if (p.d < DV) launch_attn_cfg2<DQK, DV, BKV, QT, MINW, true>(p, s);    // a padding column of V is free for the row sums
-  else launch_attn_cfg2<DQK, DV, BKV, QT, MINW, false>(p, s);
+  // PRESCALED needs a free K / Q column in the LAST k-step: instantiated for the two shapes the UNet has (d = 40 of 64, d = 80 of 96)
+  constexpr bool HAS_PRE = (DQK == 64 && DV == 48) || (DQK == 96 && DV == 80);
+  if constexpr (HAS_PRE) {
+    if (p.prescaled) {
+      LDIFF_CHECK(p.d % 8 == 0 && p.d < DQK && p.d >= DQK - 32, LDIFF_ERR_INVALID, "attention: the prescaled form needs a padding column in the last k-step (d=%d)", p.d);
+      if (p.d < DV) launch_attn_cfg2<DQK, DV, BKV, QT, MINW, true, true>(p, s);
+      else launch_attn_cfg2<DQK, DV, BKV, QT, MINW, false, true>(p, s);
+      return;
+    }
+  }
+  LDIFF_CHECK(!p.prescaled, LDIFF_ERR_INVALID, "attention: the prescaled form is not built for head dim %d", p.d);
+  if (p.d < DV) launch_attn_cfg2<DQK, DV, BKV, QT, MINW, true, false>(p, s);    // a padding column of V is free for the row sums
+  else launch_attn_cfg2<DQK, DV, BKV, QT, MINW, false, false>(p, s);
 }
-template <int DQK, int DV, int BKV, int QT, int MINW, bool ONES>
+template <int DQK, int DV, int BKV, int QT, int MINW, bool ONES, bool PRE>
 static void launch_attn_cfg2(const AttnParams& p, hipStream_t s) {
   const size_t smem = (size_t)BKV * KLayout<DQK>::STR * 16 + (size_t)BKV * VLayout<DV>::STR_DW * 4;
-  auto kern = attn_kernel<DQK, DV, BKV, QT, MINW, ONES>;
+  auto kern = attn_kernel<DQK, DV, BKV, QT, MINW, ONES, PRE>;
   ensure_dyn_smem(reinterpret_cast<const void*>(kern), (int)smem);
   dim3 grid((p.Lq + 64 * QT - 1) / (64 * QT), p.heads, p.B);
   static const std::string pname = std::string("attn<") + std::to_string(DQK) + "," + std::to_string(DV) + ">";
@@ -542,6 +585,9 @@ static void launch_attn_dsplit(const AttnParams& p, hipStream_t s) {
   hipLaunchKernelGGL(kern, grid, dim3(256), smem, s, p);
   HIP_CHECK(hipGetLastError());
 }
+
+// head dims whose self-attention can take Q pre-multiplied by scale * log2(e) (AttnParams::prescaled)
+bool attention_prescale_supported(int d) { return d == 40 || d == 80; }
 
 void launch_attention(const AttnParams& p, hipStream_t s) {
   LDIFF_CHECK(p.d % 8 == 0 && p.d > 0 && p.d <= 512, LDIFF_ERR_INVALID, "attention: head dim %d must be a multiple of 8 and <= 512", p.d);

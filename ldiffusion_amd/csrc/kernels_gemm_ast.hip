@@ -65,6 +65,8 @@ struct LnGemmParams {
   const f16* w; int N;               // TILED weights (launch_lngemm_tile_weights) of the [N][C] K-major matrix (GEGLU: rows x / gate interleaved by 16); N % 64 == 0
   const float* bias;                 // [Nrows] or nullptr
   f16* y; int ldy;                   // [M, ldy]; GEGLU: N / 2 columns
+  int qchunks; float qscale;         // the first qchunks 64-column panels are multiplied by qscale in fp32 before the rounding (q of a fused q/k/v
+                                     // projection pre-scaled by softmax scale * log2 e for the prescaled attention kernel); 0: none
   int nsplit, npanels;
   unsigned long long* stamps;        // diagnostic (LDIFF_LNGEMM_STAMPS=1): s_memtime of workgroup 0's wave 0 at the phase boundaries, else nullptr
 };
@@ -217,7 +219,8 @@ __global__ __launch_bounds__(NW * 64, 1) void lngemm_kernel(const LnGemmParams p
         for (int h = 0; h < 2; ++h) {
           const int t = 2 * (s - 1) + h, m = t >> 2, a = t & 3, r = m * 16 + l15;
           const float4 b4 = bq[a];
-          const f16x4 o = {(f16)(prev[a][m][0] + b4.x), (f16)(prev[a][m][1] + b4.y), (f16)(prev[a][m][2] + b4.z), (f16)(prev[a][m][3] + b4.w)};
+          const float cs = chunk < p.qchunks ? p.qscale : 1.0f;
+          const f16x4 o = {(f16)((prev[a][m][0] + b4.x) * cs), (f16)((prev[a][m][1] + b4.y) * cs), (f16)((prev[a][m][2] + b4.z) * cs), (f16)((prev[a][m][3] + b4.w) * cs)};
           const int unit = a * 4 + g;                                       // 8-byte unit of the 128-byte row
           lds_write64<0>(stg + r * 128 + ((((unit >> 1) ^ ((r >> 1) & 7)) << 4) | ((unit & 1) << 3)), __builtin_bit_cast(uint2, o));
         }
@@ -385,12 +388,14 @@ void launch_lngemm_tile_weights(const f16* w, f16* wt, int N, int C, hipStream_t
 }
 
 void launch_lngemm(const f16* x, int ldx, int x_lo, int M, int C, const float* gamma, const float* beta, float eps, const f16* w_tiled, int N,
-                   const float* bias, bool geglu, f16* y, int ldy, hipStream_t s) {
+                   const float* bias, bool geglu, f16* y, int ldy, hipStream_t s, int qcols, float qscale) {
+  LDIFF_CHECK(qcols >= 0 && qcols % BN == 0 && qcols <= N && !(geglu && qcols), LDIFF_ERR_INVALID, "ln_linear: scaled column count %d must be a multiple of 64 within N", qcols);
   LDIFF_CHECK(lngemm_eligible(C, N, ldx, x_lo, ldy, geglu) && M > 0, LDIFF_ERR_INVALID, "ln_linear: unsupported shape (C=%d N=%d M=%d)", C, N, M);
   LDIFF_CHECK((long long)M * ldx * 2 < (1LL << 40) && (long long)N * C * 2 < (1LL << 31), LDIFF_ERR_INVALID, "ln_linear: operand too large");
   LnGemmParams p;
   p.x = x; p.ld = ldx; p.lo = x_lo; p.M = M; p.gamma = gamma; p.beta = beta; p.eps = eps;
   p.w = w_tiled; p.N = N; p.bias = bias; p.y = y; p.ldy = ldy;
+  p.qchunks = qcols / BN; p.qscale = qscale;
   // The rows are cut as finely as a workgroup goes (128); the columns are split only when that leaves CUs without a row panel (every split
   // reads and normalises its rows again).  LDIFF_LNGEMM_NSPLIT: diagnostic.
   static const int ns_env = [] { const char* e = getenv("LDIFF_LNGEMM_NSPLIT"); return e ? atoi(e) : 0; }();

@@ -125,7 +125,8 @@ class Exec {
   Act conv(const MatW& w, const Act& x, const Act* x2, const ConvOpts& o);
   Act layernorm(const Act& x, const NormW& w);
   // LayerNorm + linear (+ GEGLU) in one launch where the activation-stationary kernel takes the shape (kernels_gemm_ast.hip), else the two launches
-  Act ln_linear(const MatW& w, const Act& x, const NormW& ln, bool geglu);
+  // qcols > 0: ask for columns [0, qcols) multiplied by qscale before the rounding; *scaled says whether the fused kernel took the launch and did it
+  Act ln_linear(const MatW& w, const Act& x, const NormW& ln, bool geglu, int qcols = 0, float qscale = 1.0f, bool* scaled = nullptr);
   Act geglu(const Act& x);
   // ResnetBlock2D (UNet: with time embedding and optional skip concat; VAE: neither) under storage policy `prec`
   Act resnet(const struct ResnetW& r, const Act& x, const Act* skip, const float* temb, int ld_temb, int groups, float eps, int prec);

@@ -427,13 +427,16 @@ Act Exec::layernorm(const Act& x, const NormW& w) {
   launch_layernorm(x.view(), y.p, (int)x.rows(), w.g, w.b, 1e-5f, s);
   return y;
 }
-Act Exec::ln_linear(const MatW& w, const Act& x, const NormW& ln, bool geglu) {
+Act Exec::ln_linear(const MatW& w, const Act& x, const NormW& ln, bool geglu, int qcols, float qscale, bool* scaled) {
+  if (scaled) *scaled = false;
   const int N = roundup(w.N, 4);
   const bool fused_geglu = geglu && w.geglu;
   const int Cout = fused_geglu ? N / 2 : N, ldy = roundup(Cout, 8);
   if (w.ks == 1 && w.K == x.C && w.Nrows >= N && lngemm_eligible(x.C, N, x.ld(), x.lo(), ldy, fused_geglu) && ldy == Cout && (!geglu || fused_geglu)) {
     Act y = new_act(x.B, x.H, x.W, Cout);
-    launch_lngemm(x.p, x.ld(), x.lo(), (int)x.rows(), x.C, ln.g, ln.b, 1e-5f, derived_tiled(w, N), N, w.b, fused_geglu, y.p, y.ld(), s);
+    const bool sc = qcols > 0 && qcols % 64 == 0 && !fused_geglu;
+    launch_lngemm(x.p, x.ld(), x.lo(), (int)x.rows(), x.C, ln.g, ln.b, 1e-5f, derived_tiled(w, N), N, w.b, fused_geglu, y.p, y.ld(), s, sc ? qcols : 0, qscale);
+    if (scaled) *scaled = sc;
     return y;
   }
   Act n = layernorm(x, ln);
@@ -680,14 +683,24 @@ Act ldiff_unet::transformer(const TransformerW& t, const Act& x) {
   }
   ex.release(g);
   // self-attention
-  Act qkv = ex.ln_linear(t.qkv, h, t.ln1, false);
+  // LDIFF_ATTN_PRESCALE=1 (default 0): level-0 self-attention (d = 40) in its prescaled form -- q leaves the fused q/k/v projection already
+  // multiplied by scale * log2(e) (fp32, before its one rounding) and the attention kernel drops the per-score FMA (kernels_attn.hip PRE).
+  // Measured: -7 % per attention launch, -0.5 % of a UNet pass (12.82 / 12.87 -> 12.74 / 12.80 ms same box; d = 80: no gain), and another
+  // rounding pattern of q: at the bench configuration the latents' max error went 3.4e-4 -> 4.1e-4 of range and the probe masks 7 -> 8
+  // differing pixels (profiles/r04_attention_prescaled.txt).  Not worth the default.
+  static const bool pre_on = [] { const char* e = getenv("LDIFF_ATTN_PRESCALE"); return e && atoi(e) != 0; }();
+  bool pre = false;
+  const float att_scale = 1.0f / sqrtf((float)d);
+  Act qkv = ex.ln_linear(t.qkv, h, t.ln1, false, (pre_on && d == 40 && attention_prescale_supported(d)) ? C : 0, att_scale * 1.4426950408889634f, &pre);
   Act a1 = ex.new_act(x.B, x.H, x.W, C);
   AttnParams ap;
   ap.q = qkv.p; ap.ldq = 3 * C; ap.k = qkv.p + C; ap.ldk = 3 * C; ap.v = qkv.p + 2 * C; ap.ldv = 3 * C;
   ap.o = a1.p; ap.ldo = C; ap.B = x.B; ap.heads = heads; ap.Lq = L; ap.Lk = L; ap.d = d;
   ap.q_bstride = (long long)L * 3 * C; ap.kv_bstride = (long long)L * 3 * C; ap.o_bstride = (long long)L * C;
-  ap.scale = 1.0f / sqrtf((float)d);
+  ap.scale = att_scale;
+  ap.prescaled = pre ? 1 : 0;
   launch_attention(ap, ex.s);
+  ap.prescaled = 0;
   ex.release(qkv);
   ConvOpts o1;
   o1.res = &h; o1.split_out = st;

@@ -35,7 +35,7 @@ for name, N, geglu in (("qkv 320->960", 960, 0), ("q2 320->320", 320, 0), ("ff1 
     def ln_only():
         _lib.check(lib.ldiff_op_layernorm(xs.data_ptr(), 2 * Cc, Cc, n.data_ptr(), M, Cc, gamma.data_ptr(), beta.data_ptr(), 1e-5, sp()))
     def one():
-        _lib.check(lib.ldiff_op_ln_linear(xs.data_ptr(), 2 * Cc, Cc, M, Cc, gamma.data_ptr(), beta.data_ptr(), 1e-5, w.data_ptr(), N, N, b.data_ptr(), geglu, y.data_ptr(), Nout, sp()))
+        _lib.check(lib.ldiff_op_ln_linear(xs.data_ptr(), 2 * Cc, Cc, M, Cc, gamma.data_ptr(), beta.data_ptr(), 1e-5, w.data_ptr(), N, N, b.data_ptr(), geglu, y.data_ptr(), Nout, 0, 1.0, sp()))
     res = []
     for r in range(3):
         res.append((timeit(two), timeit(ln_only), timeit(one)))

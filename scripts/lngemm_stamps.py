@@ -14,5 +14,5 @@ for N, geglu in ((960, 0), (320, 0), (2560, 1)):
     b = torch.zeros(N).to(DEV)
     y = torch.empty((M, N // 2 if geglu else N), dtype=torch.float16, device=DEV)
     for _ in range(3):
-        _lib.check(lib.ldiff_op_ln_linear(xs.data_ptr(), 2 * Cc, Cc, M, Cc, gamma.data_ptr(), beta.data_ptr(), 1e-5, w.data_ptr(), N, N, b.data_ptr(), geglu, y.data_ptr(), y.shape[1], sp()))
+        _lib.check(lib.ldiff_op_ln_linear(xs.data_ptr(), 2 * Cc, Cc, M, Cc, gamma.data_ptr(), beta.data_ptr(), 1e-5, w.data_ptr(), N, N, b.data_ptr(), geglu, y.data_ptr(), y.shape[1], 0, 1.0, sp()))
     torch.cuda.synchronize()

@@ -29,7 +29,7 @@ for M in (32768, 8192 + 77):
         b = (torch.randn(N, generator=g) * 0.2).to(DEV)
         Nout = N // 2 if geglu else N
         def run(y, s):
-            _lib.check(lib.ldiff_op_ln_linear(xs.data_ptr(), 2 * Cc, Cc, M, Cc, gamma.data_ptr(), beta.data_ptr(), 1e-5, w.data_ptr(), N, N, b.data_ptr(), geglu, y.data_ptr(), Nout, sp(s)))
+            _lib.check(lib.ldiff_op_ln_linear(xs.data_ptr(), 2 * Cc, Cc, M, Cc, gamma.data_ptr(), beta.data_ptr(), 1e-5, w.data_ptr(), N, N, b.data_ptr(), geglu, y.data_ptr(), Nout, 0, 1.0, sp(s)))
         ref = torch.empty((M, Nout), dtype=torch.float16, device=DEV)
         torch.cuda.synchronize()
         run(ref, sa); torch.cuda.synchronize()

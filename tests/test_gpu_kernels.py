@@ -268,6 +268,35 @@ def test_attention(lib, name):
     assert_close(o, ref, name, rtol=3e-3, atol_rel=3e-3)
 
 
+@pytest.mark.parametrize("B,heads,L,d,spike", [(2, 8, 320, 40, True), (1, 8, 4096, 40, False), (2, 8, 1024, 80, True), (1, 8, 100, 40, False), (1, 4, 64, 80, False)])
+def test_attention_prescaled(lib, B, heads, L, d, spike):
+    """ldiff_op_attention_prescaled: q arrives multiplied by scale * log2(e) and rounded once (as the q/k/v projection's epilogue delivers it); the
+    kernel subtracts the running reference inside the MFMAs.  Against SDPA on the same (rounded) operands: the reference softmax(q' k / log2 e)
+    v; a spiky key in a late tile forces the fix-up branch (new reference, rescale of O, update of the Q fragment), an all-negative first tile
+    the negative-reference start; ragged tails; fused q/k/v layout."""
+    Cc = heads * d
+    g = torch.Generator().manual_seed(L + d)
+    qkv = torch.randn((B, L, 3 * Cc), generator=g)
+    if spike:
+        qkv[0, L - 20, Cc:2 * Cc] *= 12.0                                   # a key in the last tile that moves many rows' maxima
+        qkv[-1, :64, Cc:2 * Cc] = -qkv[-1, :64, :Cc].mean(0, keepdim=True) * 0 - 3.0 * torch.sign(qkv[-1, :1, :Cc])   # first tile: scores mostly negative
+    sl2 = (1.0 / math.sqrt(d)) * 1.4426950408889634
+    qs = (qkv[..., :Cc] * sl2)                                             # the producer's fp32 value, rounded once below
+    buf = torch.cat([qs, qkv[..., Cc:]], -1).to(torch.float16).to(DEV)
+    o = torch.full((B, L, Cc), float("nan"), dtype=torch.float16, device=DEV)
+    base = buf.data_ptr()
+    _lib.check(lib.ldiff_op_attention_prescaled(base, 3 * Cc, base + 2 * Cc, 3 * Cc, base + 4 * Cc, 3 * Cc, o.data_ptr(), Cc, B, heads, L, L, d,
+                                                L * 3 * Cc, L * 3 * Cc, L * Cc, sp()))
+    torch.cuda.synchronize()
+    x = buf.float().cpu()
+    sh = lambda t: t.view(B, L, heads, d).transpose(1, 2)
+    ref = F.scaled_dot_product_attention(sh(x[..., :Cc]), sh(x[..., Cc:2 * Cc]), sh(x[..., 2 * Cc:]), scale=1.0 / 1.4426950408889634).transpose(1, 2).reshape(B, L, Cc)
+    assert_close(o, ref, f"prescaled attention B={B} L={L} d={d}", rtol=3e-3, atol_rel=3e-3)
+    with pytest.raises(ValueError):
+        _lib.check(lib.ldiff_op_attention_prescaled(base, 3 * Cc, base + 2 * Cc, 3 * Cc, base + 4 * Cc, 3 * Cc, o.data_ptr(), Cc, B, heads * d // 160 or 1, L, L, 160,
+                                                    L * 3 * Cc, L * 3 * Cc, L * Cc, sp()))
+
+
 def test_attention_fused_qkv_layout_and_online_softmax_spike(lib):
     """q/k/v interleaved in one [B, L, 3C] buffer (the self-attention call) + a key that forces a large running-max jump
     in a late tile (exercises the rescale branch of the online softmax)."""
@@ -823,7 +852,7 @@ def test_ln_linear_fused(lib, M, N, split, geglu):
     for bias in (bd, None):
         y = torch.full((M, Nout), float("nan"), dtype=torch.float16, device=DEV)
         _lib.check(lib.ldiff_op_ln_linear(xd.data_ptr(), 2 * Cc if split else Cc, Cc if split else 0, M, Cc, gd.data_ptr(), btd.data_ptr(), 1e-5, wd.data_ptr(), N, N,
-                                          None if bias is None else bias.data_ptr(), 1 if geglu else 0, y.data_ptr(), Nout, sp()))
+                                          None if bias is None else bias.data_ptr(), 1 if geglu else 0, y.data_ptr(), Nout, 0, 1.0, sp()))
         torch.cuda.synchronize()
         if bias is None:
             pr = a16 @ r16(w).t()
@@ -847,10 +876,50 @@ def test_ln_linear_fused(lib, M, N, split, geglu):
     _lib.check(lib.ldiff_op_conv(C.byref(a), sp()))
     y1 = torch.empty_like(y2)
     _lib.check(lib.ldiff_op_ln_linear(xd.data_ptr(), 2 * Cc if split else Cc, Cc if split else 0, M, Cc, gd.data_ptr(), btd.data_ptr(), 1e-5, wd.data_ptr(), N, N,
-                                      bd.data_ptr(), 1 if geglu else 0, y1.data_ptr(), Nout, sp()))
+                                      bd.data_ptr(), 1 if geglu else 0, y1.data_ptr(), Nout, 0, 1.0, sp()))
     torch.cuda.synchronize()
     d = (y1.float() - y2.float()).abs().max().item()
     assert d <= 2e-3 * max(1.0, y2.float().abs().max().item()), f"fused vs two launches: {d:.3e}"
     with pytest.raises(ValueError):     # shapes the kernel does not take are refused, not silently mis-computed
         _lib.check(lib.ldiff_op_ln_linear(xd.data_ptr(), 2 * Cc if split else Cc, Cc if split else 0, M, Cc, gd.data_ptr(), btd.data_ptr(), 1e-5, wd.data_ptr(), 48, N,
-                                          bd.data_ptr(), 0, y1.data_ptr(), Nout, sp()))
+                                          bd.data_ptr(), 0, y1.data_ptr(), Nout, 0, 1.0, sp()))
+
+
+def test_ln_linear_scaled_q_columns_feed_the_prescaled_attention(lib):
+    """The level-0 self-attention chain of the UNet as the executor runs it: fused LayerNorm + q/k/v projection whose first C columns leave multiplied
+    by scale * log2(e) (fp32, before the one rounding), then ldiff_op_attention_prescaled -- against the plain chain (unscaled projection,
+    ldiff_op_attention) and against torch.  The scaled columns themselves: y[:, :C] == f16(unscaled fp32 value * s) up to fp32 accumulation order."""
+    Cc, heads, d, B, L = 320, 8, 40, 2, 256
+    M = B * L
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn((M, Cc), generator=g) * 2 + 0.3
+    gamma, beta = 1 + 0.1 * torch.randn(Cc, generator=g), 0.1 * torch.randn(Cc, generator=g)
+    w = torch.randn((3 * Cc, Cc), generator=g) / math.sqrt(Cc)
+    xs = to_split(x).to(DEV)
+    wd, gd, btd = w.to(torch.float16).contiguous().to(DEV), gamma.to(DEV), beta.to(DEV)
+    s = (1.0 / math.sqrt(d)) * 1.4426950408889634
+
+    def project(qcols, qscale):
+        y = torch.full((M, 3 * Cc), float("nan"), dtype=torch.float16, device=DEV)
+        _lib.check(lib.ldiff_op_ln_linear(xs.data_ptr(), 2 * Cc, Cc, M, Cc, gd.data_ptr(), btd.data_ptr(), 1e-5, wd.data_ptr(), 3 * Cc, 3 * Cc, None, 0, y.data_ptr(), 3 * Cc,
+                                          qcols, qscale, sp()))
+        return y
+    plain, scaled = project(0, 1.0), project(Cc, s)
+    torch.cuda.synchronize()
+    a16 = r16(F.layer_norm(from_split(xs.cpu(), Cc), (Cc,), gamma, beta, 1e-5))
+    proj = a16 @ r16(w).t()
+    assert_close(scaled[:, :Cc], proj[:, :Cc] * s, "scaled q columns", rtol=2e-3, atol_rel=1.5e-3)
+    assert torch.equal(scaled[:, Cc:], plain[:, Cc:]), "k / v columns must not change"
+    o_pre = torch.full((B, L, Cc), float("nan"), dtype=torch.float16, device=DEV)
+    o_ref = torch.empty_like(o_pre)
+    bs, bp = scaled.data_ptr(), plain.data_ptr()
+    _lib.check(lib.ldiff_op_attention_prescaled(bs, 3 * Cc, bs + 2 * Cc, 3 * Cc, bs + 4 * Cc, 3 * Cc, o_pre.data_ptr(), Cc, B, heads, L, L, d, L * 3 * Cc, L * 3 * Cc, L * Cc, sp()))
+    _lib.check(lib.ldiff_op_attention(bp, 3 * Cc, bp + 2 * Cc, 3 * Cc, bp + 4 * Cc, 3 * Cc, o_ref.data_ptr(), Cc, B, heads, L, L, d, L * 3 * Cc, L * 3 * Cc, L * Cc,
+                                      1.0 / math.sqrt(d), sp()))
+    torch.cuda.synchronize()
+    sh = lambda t: t.reshape(B, L, heads, d).transpose(1, 2)
+    want = F.scaled_dot_product_attention(sh(proj[:, :Cc]), sh(proj[:, Cc:2 * Cc]), sh(proj[:, 2 * Cc:])).transpose(1, 2).reshape(B, L, Cc)
+    assert_close(o_pre, want, "LN-linear(q scaled) -> prescaled attention vs torch", rtol=4e-3, atol_rel=4e-3)
+    assert_close(o_pre, o_ref.float(), "prescaled chain vs plain chain", rtol=4e-3, atol_rel=4e-3)
+    with pytest.raises(ValueError):
+        project(100, s)        # not a multiple of the panel width

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define LDIFF_VERSION 140 /* 0.1.4: + ldiff_probe_argmax_u8 */
+#define LDIFF_VERSION 141 /* 0.1.4.1: + ldiff_probe_argmax_u8, ldiff_op_ln_linear, ldiff_op_attention_prescaled, ldiff_conv_args.short_runs */
 #define LDIFF_MAX_BLOCKS 8
 
 typedef enum { LDIFF_OK = 0, LDIFF_ERR_INVALID = -1, LDIFF_ERR_RUNTIME = -2, LDIFF_ERR_STATE = -3 } ldiff_status;

@@ -586,6 +586,143 @@ static void launch_attn_dsplit(const AttnParams& p, hipStream_t s) {
   HIP_CHECK(hipGetLastError());
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Short-K/V cross-attention: L_ctx <= 16 keys (the unpadded prompt "A pathological slide" is 5-6 tokens), all heads of a query row in
+// ONE wave.  The launch is pure streaming of Q and O (K / V are a few KB); one workgroup per (image, head, query tile) -- the generic kernel --
+// reads 80-byte pieces of the 640-byte query rows and pays a K / V tile staging plus two barriers per 64 queries.  Here
+//   * K and V of ALL heads ([L_ctx][C] each, zero rows up to 16) sit in LDS once per workgroup;
+//   * a wave owns 16 query rows and walks the heads: every Q fragment load of the row block is issued up front (whole rows end up in the wave's
+//     hands back to back: each 128-byte line is fetched once), per head 2-5 MFMAs for S^T = K Q^T, a one-tile softmax (no running maximum), DT MFMAs
+//     for O^T = V^T P^T with the key dimension zero-padded to 32;
+//   * no barrier after the prologue.
+// Head dims 40 / 80 / 160 (template D), heads * D = C.
+constexpr int XRB = 1;   // 64-row blocks per workgroup of the short-K/V kernel (2: 15.4 us against 13.1 us at 8 x 4096 rows: more, smaller workgroups win)
+template <int D>
+__global__ __launch_bounds__(256, 2) void xattn_kernel(const AttnParams p) {
+  constexpr int KS = (D + 31) / 32, DT = (D + 15) / 16;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int C = p.heads * D;
+  const int KSTR = C + 64;                     // row pitch (elements) of the K / V images: the last head's last k-step reads 24 columns past C (zeros)
+  f16* sK = reinterpret_cast<f16*>(smem_raw);  // [16][KSTR]
+  f16* sV = sK + 16 * KSTR;                    // [16][KSTR]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = lane >> 4, l15 = lane & 15;
+  const int b = blockIdx.y;
+  const f16* Kp = p.k + (long long)b * p.kv_bstride;
+  const f16* Vp = p.v + (long long)b * p.kv_bstride;
+  const float sl2 = p.scale * 1.4426950408889634f;
+
+  // A workgroup takes XRB blocks of 64 query rows; a wave's next (row block, head group) of Q fragments is in flight while it works on the current one.
+  constexpr int HB = D <= 80 ? 8 : 4;          // heads whose Q fragments are loaded together (register budget)
+  auto load_q = [&](uint4 (&qr)[HB][KS], int qrow, int h0) {
+    const f16* Qp = p.q + (long long)b * p.q_bstride + (long long)(qrow < p.Lq ? qrow : p.Lq - 1) * p.ldq;
+#pragma unroll
+    for (int hh = 0; hh < HB; ++hh)
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const int dd = ks * 32 + g * 8;
+        qr[hh][ks] = (h0 + hh < p.heads && dd < D) ? *reinterpret_cast<const uint4*>(Qp + (h0 + hh) * D + dd) : make_uint4(0, 0, 0, 0);
+      }
+  };
+  const int nstep = XRB * ((p.heads + HB - 1) / HB);   // (row block, head group) pairs, row block outer
+  auto step_rows = [&](int st) { return (blockIdx.x * XRB + st / ((p.heads + HB - 1) / HB)) * 64 + wave * 16 + l15; };
+  auto step_h0 = [&](int st) { return (st % ((p.heads + HB - 1) / HB)) * HB; };
+  uint4 qcur[HB][KS], qnxt[HB][KS];
+  load_q(qcur, step_rows(0), step_h0(0));   // in flight under the K / V staging
+  for (int i = tid; i < 16 * (KSTR / 8); i += 256) {   // 16-byte chunks; rows >= Lk and columns >= C are zero
+    const int row = i / (KSTR / 8), ch = i - row * (KSTR / 8);
+    uint4 kv = make_uint4(0, 0, 0, 0), vv = make_uint4(0, 0, 0, 0);
+    if (row < p.Lk && ch * 8 < C) {
+      kv = *reinterpret_cast<const uint4*>(Kp + (long long)row * p.ldk + ch * 8);
+      vv = *reinterpret_cast<const uint4*>(Vp + (long long)row * p.ldv + ch * 8);
+    }
+    *reinterpret_cast<uint4*>(sK + row * KSTR + ch * 8) = kv;
+    *reinterpret_cast<uint4*>(sV + row * KSTR + ch * 8) = vv;
+  }
+  __syncthreads();
+  for (int st = 0; st < nstep; ++st) {
+    const int qi = step_rows(st), h0 = step_h0(st);
+    const bool qok = qi < p.Lq;
+    if (st + 1 < nstep) load_q(qnxt, step_rows(st + 1), step_h0(st + 1));
+    f16* Op = p.o + (long long)b * p.o_bstride + (long long)qi * p.ldo;
+#pragma unroll
+    for (int hh = 0; hh < HB; ++hh) {
+      const int h = h0 + hh;
+      if (h >= p.heads) break;
+      // ---- S^T[key = l15][query] over the head's D channels: A = K rows from LDS, B = Q fragments ----
+      f32x4 sacc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const f16x8 kf = *reinterpret_cast<const f16x8*>(sK + l15 * KSTR + h * D + ks * 32 + g * 8);   // columns beyond the head meet zero Q elements
+        sacc = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, __builtin_bit_cast(f16x8, qcur[hh][ks]), sacc, 0, 0, 0);
+      }
+      // ---- softmax over the <= 16 keys of this lane's query (keys 4g + r; the four lanes l15 + 16 g hold one query) ----
+      float mx = -1e30f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        if (g * 4 + r >= p.Lk) sacc[r] = -1e30f;
+        mx = fmaxf(mx, sacc[r]);
+      }
+      mx = xmax32(xmax16(mx));
+      const float moff = -mx * sl2;
+      float rs = 0.f;
+      f16x8 pf = {(f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f};   // keys 16 .. 31 of the MFMA step: zero
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float pv = __builtin_amdgcn_exp2f(fmaf(sacc[r], sl2, moff));
+        rs += pv;
+        pf[r] = (f16)pv;
+      }
+      rs += __shfl_xor(rs, 16);
+      rs += __shfl_xor(rs, 32);
+      const float inv = 1.0f / rs;
+      // ---- O^T[d][query] = V^T P^T: V^T fragments by transposed LDS reads (keys 4g .. 4g+3 of tile 0; the second half of the k-step is zero) ----
+      const int tq = l15 >> 2, tp = l15 & 3;
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) {
+        typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(sV + (g * 4 + tq) * KSTR + h * D + dt * 16 + tp * 4));
+        const f16x4 lo_h = __builtin_bit_cast(f16x4, lo);
+        const f16x8 vf = {lo_h[0], lo_h[1], lo_h[2], lo_h[3], (f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f};
+        f32x4 o = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        const int dd = dt * 16 + g * 4;
+        if (qok && dd < D) {
+          const f16x4 ov = {(f16)(o[0] * inv), (f16)(o[1] * inv), (f16)(o[2] * inv), (f16)(o[3] * inv)};
+          *reinterpret_cast<f16x4*>(Op + h * D + dd) = ov;
+        }
+      }
+    }
+#pragma unroll
+    for (int hh = 0; hh < HB; ++hh)
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) qcur[hh][ks] = qnxt[hh][ks];
+  }
+}
+
+template <int D>
+static void launch_xattn(const AttnParams& p, hipStream_t s) {
+  const int C = p.heads * D;
+  const size_t smem = (size_t)2 * 16 * (C + 64) * sizeof(f16);
+  auto kern = xattn_kernel<D>;
+  ensure_dyn_smem(reinterpret_cast<const void*>(kern), (int)smem);
+  const double bh = (double)p.B * p.heads;
+  ProfScope prof("xattn<short-kv>", 4.0 * bh * p.Lq * p.Lk * p.d, 2.0 * bh * p.d * (2.0 * p.Lq + 2.0 * p.Lk * (p.kv_bstride ? 1.0 : 1.0 / p.B)), s);
+  hipLaunchKernelGGL(kern, dim3((p.Lq + 64 * XRB - 1) / (64 * XRB), p.B), dim3(256), smem, s, p);
+  HIP_CHECK(hipGetLastError());
+}
+// LDIFF_XATTN: 1 (default) = cross-attention with L_ctx <= 16 on the short-K/V kernel, 0 = the generic kernel (A/B timing)
+static bool xattn_selected(const AttnParams& p) {
+  static const int mode = [] { const char* e = getenv("LDIFF_XATTN"); return e ? atoi(e) : 1; }();
+  if (!mode || p.Lk > 16 || p.prescaled) return false;
+  if (!(p.d == 40 || p.d == 80 || p.d == 160) || p.heads < 1 || p.heads > 16) return false;
+  const long long C = (long long)p.heads * p.d;
+  if (p.ldq < C || p.ldk < C || p.ldv < C || p.ldo < C) return false;           // the heads of a row must lie side by side
+  if ((size_t)2 * 16 * (C + 64) * sizeof(f16) > 150 * 1024) return false;
+  // enough workgroups to fill the chip twice: measured same box at B = 8 -- 4096 x 6, d = 40 (512 workgroups): 15.9 -> 13.1 us; 1024 x 6, d = 80 (128):
+  // 8.1 -> 11.8 us and 256 x 6, d = 160 (32): 8.1 -> 18.0 us (too few workgroups for the K / V staging): the generic kernel keeps those (mode 2: always)
+  return mode == 2 || (long long)p.B * ((p.Lq + 64 * XRB - 1) / (64 * XRB)) >= 384;
+}
+
 // head dims whose self-attention can take Q pre-multiplied by scale * log2(e) (AttnParams::prescaled)
 bool attention_prescale_supported(int d) { return d == 40 || d == 80; }
 
@@ -594,6 +731,10 @@ void launch_attention(const AttnParams& p, hipStream_t s) {
   LDIFF_CHECK(p.ldq % 8 == 0 && p.ldk % 8 == 0 && p.ldv % 8 == 0 && p.ldo % 4 == 0, LDIFF_ERR_INVALID, "attention: row strides must be multiples of 8");
   LDIFF_CHECK(p.Lk > 0 && p.Lq > 0, LDIFF_ERR_INVALID, "attention: empty sequence (Lq=%d Lk=%d)", p.Lq, p.Lk);
   const int d = p.d;
+  if (xattn_selected(p)) {
+    if (d == 40) launch_xattn<40>(p, s); else if (d == 80) launch_xattn<80>(p, s); else launch_xattn<160>(p, s);
+    return;
+  }
   if (d <= 16) launch_attn_cfg<32, 16, 64, 2>(p, s);
   else if (d <= 32) launch_attn_cfg<32, 32, 64, 2>(p, s);
   else if (d <= 48) launch_attn_cfg<64, 48, 64, 2>(p, s);

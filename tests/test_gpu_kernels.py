@@ -237,6 +237,13 @@ ATTN_CASES = {
     "cross_d40_Lk6_bcast": (3, 8, 300, 6, 40, True),
     "cross_d80_Lk77": (2, 8, 128, 77, 80, False),
     "cross_d160_Lk1": (2, 8, 64, 1, 160, True),
+    # short K / V (L_ctx <= 16): the all-heads-in-one-wave kernel (xattn_kernel); ragged query tiles, per-image K / V, the full 16 keys, other head counts
+    "cross_d40_Lk6_bcast_big": (8, 8, 4096, 6, 40, True),
+    "cross_d40_Lk16_per_image_ragged": (3, 8, 333, 16, 40, False),
+    "cross_d80_Lk6_bcast": (4, 8, 1024, 6, 80, True),
+    "cross_d80_Lk9_heads4": (2, 4, 100, 9, 80, False),
+    "cross_d160_Lk6_bcast": (8, 8, 256, 6, 160, True),
+    "cross_d160_Lk13_heads5": (1, 5, 64, 13, 160, False),
     "vae_d512_L1024": (2, 1, 1024, 1024, 512, False),
     "vae_d128_L256": (1, 1, 256, 256, 128, False),
     "tiny_d8": (2, 8, 256, 256, 8, False),

@@ -318,6 +318,16 @@ int ldiff_prof_enable(int on);
 int ldiff_prof_set_filter(const char* kernel_name_or_null);
 int ldiff_prof_collect(ldiff_prof_row* rows, int cap); /* returns the number of rows (may exceed cap) or <0 */
 
+/* ------------------------------------------------------------------------------------------------
+ * CU-restricted streams (measurement of chip partitioning between the UNet / encoder stream and the
+ * decode side stream; no reference counterpart).  A stream made here only runs on the CUs whose index
+ * modulo 32 lies in [lo32, hi32) (both multiples of 8): every XCD keeps the same share of its CUs.
+ * ldiff_vae_set_side_cu_share re-creates the VAE's decode side stream with such a share (0, 32 = whole chip).
+ * ---------------------------------------------------------------------------------------------- */
+int ldiff_stream_create_cu_share(int lo32, int hi32, void** stream_out);
+int ldiff_stream_destroy(void* stream);
+int ldiff_vae_set_side_cu_share(ldiff_vae* v, int lo32, int hi32);
+
 #ifdef __cplusplus
 }
 #endif

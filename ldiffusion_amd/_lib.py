@@ -104,6 +104,9 @@ SIGNATURES = {
     "ldiff_op_pack_weight_multi": (I, [P, P, I, I, P]),
     "ldiff_op_adamw_multi": (I, [P, P, P, I64, F, F, F, F, F, I, P]),
     "ldiff_op_infonce": (I, [P, I, I, I64, P, P, P, P, I, P, I, F, P, P, P]),
+    "ldiff_stream_create_cu_share": (I, [I, I, P]),
+    "ldiff_stream_destroy": (I, [P]),
+    "ldiff_vae_set_side_cu_share": (I, [P, I, I]),
     "ldiff_prof_enable": (I, [I]),
     "ldiff_prof_set_filter": (I, [C.c_char_p]),
     "ldiff_prof_collect": (I, [P, I]),

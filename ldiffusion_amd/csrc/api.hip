@@ -244,6 +244,47 @@ int ldiff_pipeline_create(ldiff_pipeline** out, ldiff_unet* u, ldiff_vae* v) {
   *out = p;
   API_END
 }
+// CU-restricted streams (experiment): bit i of the mask is set where lo32 <= i % 32 < hi32, so every XCD keeps the same share of
+// its 32 CUs whichever way the runtime numbers them (interleaved over the XCDs or XCD by XCD) as long as lo32 / hi32 are multiples of 8.
+static void make_cu_share_stream(int lo32, int hi32, hipStream_t* out) {
+  LDIFF_CHECK(lo32 >= 0 && hi32 <= 32 && lo32 < hi32 && (lo32 & 7) == 0 && (hi32 & 7) == 0, LDIFF_ERR_INVALID,
+              "cu share: need 0 <= lo32 < hi32 <= 32, both multiples of 8");
+  int dev = 0, cus = 0;
+  HIP_CHECK(hipGetDevice(&dev));
+  HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+  const uint32_t word = (hi32 == 32 ? 0xffffffffu : ((1u << hi32) - 1u)) & ~((1u << lo32) - 1u);
+  std::vector<uint32_t> mask((size_t)((cus + 31) / 32), word);
+  HIP_CHECK(hipExtStreamCreateWithCUMask(out, (uint32_t)mask.size(), mask.data()));
+}
+int ldiff_stream_create_cu_share(int lo32, int hi32, void** stream_out) {
+  API_BEGIN
+  LDIFF_CHECK(stream_out, LDIFF_ERR_INVALID, "stream_create_cu_share: null argument");
+  hipStream_t s = nullptr;
+  make_cu_share_stream(lo32, hi32, &s);
+  *stream_out = (void*)s;
+  API_END
+}
+int ldiff_stream_destroy(void* stream) {
+  API_BEGIN
+  if (stream) HIP_CHECK(hipStreamDestroy((hipStream_t)stream));
+  API_END
+}
+int ldiff_vae_set_side_cu_share(ldiff_vae* v, int lo32, int hi32) {
+  API_BEGIN
+  LDIFF_CHECK(v, LDIFF_ERR_INVALID, "vae_set_side_cu_share: null vae");
+  HIP_CHECK(hipSetDevice(v->device));
+  hipStream_t s = nullptr;
+  if (lo32 == 0 && hi32 == 32) HIP_CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+  else make_cu_share_stream(lo32, hi32, &s);
+  if (v->side_stream) {
+    HIP_CHECK(hipStreamSynchronize(v->side_stream));
+    HIP_CHECK(hipStreamDestroy(v->side_stream));
+  } else {
+    HIP_CHECK(hipEventCreateWithFlags(&v->ev_side, hipEventDisableTiming));
+  }
+  v->side_stream = s;
+  API_END
+}
 int ldiff_pipeline_set_overlap(ldiff_pipeline* p, int mode) {
   API_BEGIN
   LDIFF_CHECK(p && mode >= 0 && mode <= 2, LDIFF_ERR_INVALID, "set_overlap: mode must be 0, 1 or 2");

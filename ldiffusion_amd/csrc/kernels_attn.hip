@@ -587,6 +587,270 @@ static void launch_attn_dsplit(const AttnParams& p, hipStream_t s) {
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// d = 512, one head, long sequences (the VAE mid-block attention: 4,096 tokens per image at 512^2, 16,384 at 1024^2).  Round 4: the kernel above
+// moves 64 KiB of K / V per 64-query step through registers and runs at 0.13 of the MFMA peak.  This one
+//   * takes 128 queries per workgroup (wave w: 32 queries in the softmax phase, d slice [128 w, 128 w + 128) of all 128 queries in the P V phase),
+//     so a 64 KiB K / V tile feeds 128 MFMAs per wave instead of 64 and every K fragment read from LDS feeds two MFMAs;
+//   * brings K / V in by LDS-DMA (one piece = one 1 KiB row; the K swizzle is applied by which 16-byte chunk a lane fetches), double-buffered:
+//     tile t + 1 travels during the whole of tile t; two raw barriers per tile with hand-counted waits (every LDS access between them is inline
+//     asm, so the compiler cannot put a vmcnt(0) for the travelling tile in front of it);
+//   * keeps the 256 output accumulators of a wave in AGPRs and NEVER rescales them (vector instructions cannot address AGPRs: an online-softmax
+//     rescale would shuttle all of them through VGPRs, and the register allocator answers that with 700 spills).  Instead every query gets a
+//     FIXED reference: m_ref = (maximum over the first key tile) + 4 binades, p = 2^(s - m_ref) -- exact softmax algebra for any reference; fp16
+//     P holds up to 2^15, so the pass is valid while no score exceeds m_ref by more than 15 binades (the true maximum may lie up to 19 binades
+//     = 13 nats above the first tile's).  A wave tracks the true maximum on the side; if some query left the window, the whole workgroup runs
+//     the pass once more with m_ref = the true maxima, which cannot fail.  (The softmax is also cheaper: no per-tile lane reductions, no alpha.)
+// Registers: Q fragments 128 + O accumulators 256 (AGPRs) + ~90: one wave per SIMD.
+constexpr int D5_QB = 128, D5_BKV = 32;
+constexpr unsigned D5_KB = 32 * 1024, D5_VROW = VLayout<512>::STR_DW * 4, D5_VB = 32 * D5_VROW, D5_PSTR = D5_BKV * 2 + 16;
+constexpr unsigned D5_K0 = 0, D5_V0 = 2 * D5_KB, D5_P0 = D5_V0 + 2 * D5_VB, D5_AL = D5_P0 + D5_QB * D5_PSTR, D5_FL = D5_AL + D5_QB * 4, D5_LDS = D5_FL + 16;
+static_assert(D5_LDS <= 160 * 1024, "LDS budget");
+constexpr float D5_LEAD = 4.0f, D5_WINDOW = 15.0f;   // binades: reference above the first tile's maximum; headroom of fp16 P above the reference
+
+__device__ __forceinline__ void d5_lds_write64(unsigned addr, uint2 v) { asm volatile("ds_write_b64 %0, %1" :: "v"(addr), "v"(v) : "memory"); }
+__device__ __forceinline__ void d5_lds_write32(unsigned addr, float v) { asm volatile("ds_write_b32 %0, %1" :: "v"(addr), "v"(v) : "memory"); }
+__device__ __forceinline__ void d5_lds_read32(float& d, unsigned addr) { asm volatile("ds_read_b32 %0, %1" : "=v"(d) : "v"(addr) : "memory"); }
+
+__global__ __launch_bounds__(256, 1) void attn_d512_kernel(const AttnParams p) {
+  typedef __attribute__((address_space(3))) void lds_void;
+  constexpr int D = 512, KS = D / 32, NT = D5_BKV / 16, DTW = 8, NJ = D5_QB / 16;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 4, l15 = lane & 15;
+  // XCD-aware order (as above): the workgroups of one XCD take a contiguous range of (query block, batch), so an image's K / V tiles are
+  // fetched from HBM once per XCD; at 8 images x 32 query blocks an XCD owns exactly one image
+  const int nqb = (p.Lq + D5_QB - 1) / D5_QB, nwg = gridDim.x, id = blockIdx.x;
+  const int q8 = nwg >> 3, r8 = nwg & 7, xcd = id & 7, idx = id >> 3;
+  int sw = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
+  const int qb = sw % nqb; sw /= nqb;
+  const int h = sw % p.heads, b = sw / p.heads;
+  const int q0 = qb * D5_QB;
+
+  const f16* Qp = p.q + (long long)b * p.q_bstride + h * D;
+  const f16* Kp = p.k + (long long)b * p.kv_bstride + h * D;
+  const f16* Vp = p.v + (long long)b * p.kv_bstride + h * D;
+  const int ldk2 = p.ldk * 2, ldv2 = p.ldv * 2;
+  const __amdgpu_buffer_rsrc_t rsk = __builtin_amdgcn_make_buffer_rsrc((void*)Kp, 0, (int)((long long)(p.Lk - 1) * ldk2 + D * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsv = __builtin_amdgcn_make_buffer_rsrc((void*)Vp, 0, (int)((long long)(p.Lk - 1) * ldv2 + D * 2), 0x00020000);
+  const unsigned lds0 = (unsigned)(size_t)(lds_void*)smem_raw;
+
+  // rows 8 wave .. 8 wave + 7 of the K and the V tile: 16 pieces of 1 KiB per wave and tile; rows beyond Lk read zeros (num_records)
+  auto issue_tile = [&](int kv0, int buf) __attribute__((always_inline)) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    attn_static_for<0, 8>([&](auto pc) {
+      constexpr int pp = decltype(pc)::value;
+      const int r = wave * 8 + pp;
+      const int kvo = (lane ^ (r & 15)) << 4;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsk, (lds_void*)(smem_raw + D5_K0 + buf * D5_KB + r * 1024), 16, kvo, (kv0 + r) * ldk2, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsv, (lds_void*)(smem_raw + D5_V0 + buf * D5_VB + r * D5_VROW), 16, lane << 4, (kv0 + r) * ldv2, 0, 0);
+    });
+#endif
+  };
+  issue_tile(0, 0);
+
+  // Q fragments of the wave's two query tiles (softmax-phase rows q0 + 32 wave + 16 j + l15)
+  f16x8 qf[2][KS];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int qi = q0 + wave * 32 + j * 16 + l15;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (qi < p.Lq) v = *reinterpret_cast<const uint4*>(Qp + (long long)qi * p.ldq + ks * 32 + g * 8);
+      qf[j][ks] = __builtin_bit_cast(f16x8, v);
+    }
+  }
+  const float sl2 = p.scale * 1.4426950408889634f;
+  const unsigned kbase = lds0 + D5_K0 + (unsigned)(l15 * 1024 + ((g ^ l15) << 4));                      // K fragment, key tile 0, k-step 0
+  const unsigned vbase = lds0 + D5_V0 + (unsigned)(((g * 8 + (l15 >> 2)) * (int)VLayout<512>::STR_DW + wave * DTW * 8 + (l15 & 3) * 2) * 4);   // V^T fragment, d tile 0
+  const unsigned pw_base = lds0 + D5_P0 + (unsigned)((wave * 32 + l15) * D5_PSTR + g * 8);              // P write: row 32 wave + 16 j + l15, keys 16 t + 4 g ..
+  const unsigned pr_base = lds0 + D5_P0 + (unsigned)(l15 * D5_PSTR + g * 16);                           // P read: row 16 j + l15, keys 8 g ..
+  const unsigned al_w = lds0 + D5_AL + (unsigned)((wave * 32 + l15) * 4), al_r = lds0 + D5_AL + (unsigned)(l15 * 4);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the Q loads and tile 0: nothing of the compiler's is younger than the hand-counted pieces below
+
+  // S^T = K Q^T of one tile: 32 keys x 32 queries of this wave, scaled to binades (s * scale * log2 e); a K fragment feeds both query tiles
+  auto scores = [&](int kv0, int buf, bool tail, f32x4 (&sacc)[2][NT]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int t = 0; t < NT; ++t) sacc[j][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const unsigned kb = kbase + (unsigned)buf * D5_KB;
+    attn_static_for<0, NT * KS / 4>([&](auto bc) {
+      constexpr int t = decltype(bc)::value / (KS / 4), k0 = (decltype(bc)::value % (KS / 4)) * 4;
+      f16x8 kf[4];
+      attn_static_for<0, 4>([&](auto ic) { constexpr int i = decltype(ic)::value; attn_lds_read128<t * 16 * 1024>(kf[i], kb ^ (unsigned)((k0 + i) * 64)); });
+      attn_static_for<0, 4>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        attn_lds_wait<3 - i>(kf[i]);
+        sacc[0][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[i], qf[0][k0 + i], sacc[0][t], 0, 0, 0);
+        sacc[1][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[i], qf[1][k0 + i], sacc[1][t], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      });
+    });
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          sacc[j][t][r] *= sl2;
+          if (tail && kv0 + t * 16 + g * 4 + r >= p.Lk) sacc[j][t][r] = -1e30f;
+        }
+  };
+  auto rowmax = [&](const f32x4 (&sa)[NT]) __attribute__((always_inline)) {   // over this lane's 8 keys of the tile
+    float mx = -1e30f;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) mx = fmaxf(fmaxf(mx, fmaxf(sa[t][0], sa[t][1])), fmaxf(sa[t][2], sa[t][3]));
+    return mx;
+  };
+
+  // ---- references: maximum over the first key tile + D5_LEAD ----
+  float mref[2];
+  {
+    __builtin_amdgcn_s_barrier();   // (tile 0 landed: every wave waited for its pieces above)
+    f32x4 sacc[2][NT];
+    scores(0, 0, p.Lk < D5_BKV, sacc);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) mref[j] = xmax32(xmax16(rowmax(sacc[j]))) + D5_LEAD;
+  }
+
+  f32x4 oacc[NJ][DTW];   // [query tile][d tile of this wave's slice]
+  float mobs[2], lsum[2];
+  const int full = p.Lk / D5_BKV * D5_BKV;
+  for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int dt = 0; dt < DTW; ++dt) oacc[j][dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 2; ++j) { mobs[j] = -1e30f; lsum[j] = 0.f; }
+
+    auto tile = [&](int kv0, int buf, auto TAILC) __attribute__((always_inline)) {
+      constexpr bool TAIL = decltype(TAILC)::value;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of the tile
+      __builtin_amdgcn_s_barrier();                      // every wave's pieces landed; every wave is done with the other buffer and with P
+      if (kv0 + D5_BKV < p.Lk) issue_tile(kv0 + D5_BKV, buf ^ 1);
+      f32x4 sacc[2][NT];
+      scores(kv0, buf, TAIL, sacc);
+      // ---- p = 2^(s - m_ref) (lane: query 16 j + l15 of the wave, keys 16 t + 4 g + r), row sums per lane, P to LDS ----
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        mobs[j] = fmaxf(mobs[j], rowmax(sacc[j]));
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          f16x4 ph;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float pv = __builtin_amdgcn_exp2f(sacc[j][t][r] - mref[j]);
+            lsum[j] += pv;
+            ph[r] = (f16)pv;
+          }
+          d5_lds_write64(pw_base + (unsigned)(j * 16 * D5_PSTR + t * 32), __builtin_bit_cast(uint2, ph));
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+
+      // ---- O^T[d slice of this wave][128 queries] += V^T P^T ----
+      f16x8 pf[NJ];
+      attn_static_for<0, NJ>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        attn_lds_read128<j * 16 * (int)D5_PSTR>(pf[j], pr_base);
+      });
+      const unsigned vb = vbase + (unsigned)buf * D5_VB;
+      f16x4 vlo[2][2], vhi[2][2];   // [parity of the batch][d tile of the batch]: the next batch's reads are issued before this batch's MFMAs
+      auto issue_v = [&](auto hc) __attribute__((always_inline)) {
+        constexpr int hb = decltype(hc)::value;
+        attn_static_for<0, 2>([&](auto dc) {
+          constexpr int i = decltype(dc)::value, dt = hb * 2 + i;
+          attn_lds_read_tr<dt * 32>(vlo[hb & 1][i], vb);                                          // keys 8g .. 8g+3
+          attn_lds_read_tr<dt * 32 + 4 * (int)D5_VROW>(vhi[hb & 1][i], vb);                       // keys 8g+4 .. 8g+7
+        });
+      };
+      issue_v(std::integral_constant<int, 0>{});
+      asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(pf[0]), "+v"(pf[1]), "+v"(pf[2]), "+v"(pf[3]), "+v"(pf[4]), "+v"(pf[5]), "+v"(pf[6]), "+v"(pf[7]));
+      attn_static_for<0, 4>([&](auto hc) {
+        constexpr int hb = decltype(hc)::value;
+        if constexpr (hb < 3) issue_v(std::integral_constant<int, hb + 1>{});
+        attn_static_for<0, 2>([&](auto dc) {
+          constexpr int i = decltype(dc)::value, dt = hb * 2 + i;
+          attn_lds_wait<(hb < 3 ? 4 : 0) + 2 * (1 - i)>(vlo[hb & 1][i], vhi[hb & 1][i]);
+          const f16x8 vf = {vlo[hb & 1][i][0], vlo[hb & 1][i][1], vlo[hb & 1][i][2], vlo[hb & 1][i][3], vhi[hb & 1][i][0], vhi[hb & 1][i][1], vhi[hb & 1][i][2], vhi[hb & 1][i][3]};
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) oacc[j][dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf[j], oacc[j][dt], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+        });
+      });
+    };
+    int buf = 0;
+    for (int kv0 = 0; kv0 < full; kv0 += D5_BKV, buf ^= 1) tile(kv0, buf, std::false_type());
+    if (full < p.Lk) tile(full, buf, std::true_type());
+
+    // ---- did every score stay inside the window of its reference?  One word per wave, read by all ----
+#pragma unroll
+    for (int j = 0; j < 2; ++j) mobs[j] = xmax32(xmax16(mobs[j]));
+    const bool left = mobs[0] - mref[0] > D5_WINDOW || mobs[1] - mref[1] > D5_WINDOW;
+    __builtin_amdgcn_s_barrier();   // the last tile's P has been read
+    const float flag = __builtin_amdgcn_ballot_w64(left) != 0 ? 1.0f : 0.0f;   // (all lanes vote: outside the branch below)
+    if (lane == 0) d5_lds_write32(lds0 + D5_FL + (unsigned)(wave * 4), flag);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    f32x4 fl;
+    asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(fl) : "v"(lds0 + D5_FL) : "memory");
+    if (__builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, fl[0] + fl[1] + fl[2] + fl[3])) == 0) break;
+    // second pass (never a third: the references are now the true maxima)
+    mref[0] = mobs[0]; mref[1] = mobs[1];
+    __builtin_amdgcn_s_barrier();   // (the flag words are rewritten at the end of the next pass)
+    issue_tile(0, 0);
+  }
+
+  // ---- normalise and store: lane holds O[q = 16 j + l15][dd = 128 wave + 16 dt + 4 g + r] ----
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    float l = lsum[j];
+    l += __shfl_xor(l, 16);
+    l += __shfl_xor(l, 32);
+    d5_lds_write32(al_w + (unsigned)(j * 64), l);   // (the four g lanes of a query write the same value)
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  f16* Op = p.o + (long long)b * p.o_bstride + h * D;
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int qi = q0 + j * 16 + l15;
+    float sum;
+    d5_lds_read32(sum, al_r + (unsigned)(j * 64));
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(sum));
+    const float inv = 1.0f / sum;
+    if (qi < p.Lq) {
+#pragma unroll
+      for (int dt = 0; dt < DTW; ++dt) {
+        const int dd = (wave * DTW + dt) * 16 + g * 4;
+        const f16x4 o = {(f16)(oacc[j][dt][0] * inv), (f16)(oacc[j][dt][1] * inv), (f16)(oacc[j][dt][2] * inv), (f16)(oacc[j][dt][3] * inv)};
+        *reinterpret_cast<f16x4*>(Op + (long long)qi * p.ldo + dd) = o;
+      }
+    }
+  }
+}
+
+// LDIFF_ATTN_D512: 1 (default) = the 128-query kernel where d == 512 and a workgroup's queries are mostly real, 0 = the d-split kernel above
+static bool attn_d512_selected(const AttnParams& p) {
+  static const int mode = [] { const char* e = getenv("LDIFF_ATTN_D512"); return e ? atoi(e) : 1; }();
+  if (!mode || p.d != 512 || p.prescaled) return false;
+  if ((long long)(p.Lk - 1) * p.ldk * 2 + 1024 >= (1LL << 31) || (long long)(p.Lk - 1) * p.ldv * 2 + 1024 >= (1LL << 31)) return false;   // buffer descriptors
+  return mode == 2 || p.Lq > 64;
+}
+static void launch_attn_d512(const AttnParams& p, hipStream_t s) {
+  auto kern = attn_d512_kernel;
+  ensure_dyn_smem(reinterpret_cast<const void*>(kern), (int)D5_LDS);
+  dim3 grid(((p.Lq + D5_QB - 1) / D5_QB) * p.heads * p.B);
+  const double bh = (double)p.B * p.heads;
+  ProfScope prof("attn<512,128q>", 4.0 * bh * p.Lq * p.Lk * p.d, 2.0 * bh * p.d * (2.0 * p.Lq + 2.0 * p.Lk * (p.kv_bstride ? 1.0 : 1.0 / p.B)), s);
+  hipLaunchKernelGGL(kern, grid, dim3(256), D5_LDS, s, p);
+  HIP_CHECK(hipGetLastError());
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // Short-K/V cross-attention: L_ctx <= 16 keys (the unpadded prompt "A pathological slide" is 5-6 tokens), all heads of a query row in
 // ONE wave.  The launch is pure streaming of Q and O (K / V are a few KB); one workgroup per (image, head, query tile) -- the generic kernel --
 // reads 80-byte pieces of the 640-byte query rows and pays a K / V tile staging plus two barriers per 64 queries.  Here
@@ -743,5 +1007,6 @@ void launch_attention(const AttnParams& p, hipStream_t s) {
   else if (d <= 96) launch_attn_cfg<96, 96, 64, 2>(p, s);
   else if (d <= 128) launch_attn_cfg<128, 128, 64, 2, 1>(p, s);
   else if (d <= 160) launch_attn_cfg<160, 160, 64, 2, 1>(p, s);
+  else if (attn_d512_selected(p)) launch_attn_d512(p, s);
   else launch_attn_dsplit(p, s);
 }

@@ -275,6 +275,45 @@ def test_attention(lib, name):
     assert_close(o, ref, name, rtol=3e-3, atol_rel=3e-3)
 
 
+@pytest.mark.parametrize("name,B,Lq,Lk,fused,late_spike", [
+    ("mid_block_1024", 2, 1024, 1024, True, False),
+    ("ragged_tails", 3, 200, 333, False, False),
+    ("one_query_block_short_keys", 1, 128, 17, False, False),
+    ("second_pass", 2, 384, 512, True, True),
+])
+def test_attention_d512_fixed_reference(lib, name, B, Lq, Lk, fused, late_spike):
+    """attn_d512_kernel (d = 512, one head, more than 64 queries): 128 queries per workgroup, K / V by LDS-DMA, and a FIXED softmax reference per
+    query (maximum over the first key tile + 4 binades) instead of a running one -- the accumulators are never rescaled.  Cases: the fused q/k/v
+    layout of the VAE mid block, ragged query / key tails, fewer keys than one tile, and keys in a late tile whose scores leave the fp16 window of
+    the first tile's reference (the workgroup then repeats the pass with the true maxima)."""
+    d = 512
+    g = torch.Generator().manual_seed(zlib.crc32(name.encode()) % 1000)
+    q = torch.randn((B, Lq, d), generator=g)
+    k = torch.randn((B, Lk, d), generator=g)
+    v = torch.randn((B, Lk, d), generator=g)
+    if late_spike:
+        k[0, Lk - 5] = 2.0 * q[0, 7]          # score 2 |q|^2 / sqrt(512) ~ 45 nats above everything in the first tile: query 7 of image 0 leaves the window
+        k[1, Lk // 2] = 1.2 * q[1, 300]       # ~ 27 nats: another workgroup, another tile
+    scale = 1.0 / math.sqrt(d)
+    o = torch.full((B, Lq, d), float("nan"), dtype=torch.float16, device=DEV)
+    if fused:
+        assert Lq == Lk or True
+        L = max(Lq, Lk)
+        buf = torch.zeros((B, L, 3 * d), dtype=torch.float16)
+        buf[:, :Lq, :d] = q.to(torch.float16); buf[:, :Lk, d:2 * d] = k.to(torch.float16); buf[:, :Lk, 2 * d:] = v.to(torch.float16)
+        buf = buf.to(DEV)
+        base = buf.data_ptr()
+        _lib.check(lib.ldiff_op_attention(base, 3 * d, base + 2 * d, 3 * d, base + 4 * d, 3 * d, o.data_ptr(), d, B, 1, Lq, Lk, d,
+                                          L * 3 * d, L * 3 * d, Lq * d, scale, sp()))
+    else:
+        qd, kd, vd = (t.to(torch.float16).to(DEV) for t in (q, k, v))
+        _lib.check(lib.ldiff_op_attention(qd.data_ptr(), d, kd.data_ptr(), d, vd.data_ptr(), d, o.data_ptr(), d, B, 1, Lq, Lk, d,
+                                          Lq * d, Lk * d, Lq * d, scale, sp()))
+    torch.cuda.synchronize()
+    ref = F.scaled_dot_product_attention(r16(q)[:, None], r16(k)[:, None], r16(v)[:, None])[:, 0]
+    assert_close(o, ref, name, rtol=3e-3, atol_rel=3e-3)
+
+
 @pytest.mark.parametrize("B,heads,L,d,spike", [(2, 8, 320, 40, True), (1, 8, 4096, 40, False), (2, 8, 1024, 80, True), (1, 8, 100, 40, False), (1, 4, 64, 80, False)])
 def test_attention_prescaled(lib, B, heads, L, d, spike):
     """ldiff_op_attention_prescaled: q arrives multiplied by scale * log2(e) and rounded once (as the q/k/v projection's epilogue delivers it); the

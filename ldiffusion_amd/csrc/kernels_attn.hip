@@ -635,16 +635,17 @@ __global__ __launch_bounds__(256, 1) void attn_d512_kernel(const AttnParams p) {
   const unsigned lds0 = (unsigned)(size_t)(lds_void*)smem_raw;
 
   // rows 8 wave .. 8 wave + 7 of the K and the V tile: 16 pieces of 1 KiB per wave and tile; rows beyond Lk read zeros (num_records)
-  auto issue_tile = [&](int kv0, int buf) __attribute__((always_inline)) {
+  auto issue_row = [&](int kv0, int buf, auto pc) __attribute__((always_inline)) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    attn_static_for<0, 8>([&](auto pc) {
-      constexpr int pp = decltype(pc)::value;
-      const int r = wave * 8 + pp;
-      const int kvo = (lane ^ (r & 15)) << 4;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsk, (lds_void*)(smem_raw + D5_K0 + buf * D5_KB + r * 1024), 16, kvo, (kv0 + r) * ldk2, 0, 0);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsv, (lds_void*)(smem_raw + D5_V0 + buf * D5_VB + r * D5_VROW), 16, lane << 4, (kv0 + r) * ldv2, 0, 0);
-    });
+    constexpr int pp = decltype(pc)::value;
+    const int r = wave * 8 + pp;
+    const int kvo = (lane ^ (r & 15)) << 4;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsk, (lds_void*)(smem_raw + D5_K0 + buf * D5_KB + r * 1024), 16, kvo, (kv0 + r) * ldk2, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsv, (lds_void*)(smem_raw + D5_V0 + buf * D5_VB + r * D5_VROW), 16, lane << 4, (kv0 + r) * ldv2, 0, 0);
 #endif
+  };
+  auto issue_tile = [&](int kv0, int buf) __attribute__((always_inline)) {
+    attn_static_for<0, 8>([&](auto pc) { issue_row(kv0, buf, pc); });
   };
   issue_tile(0, 0);
 
@@ -668,24 +669,34 @@ __global__ __launch_bounds__(256, 1) void attn_d512_kernel(const AttnParams p) {
   const unsigned al_w = lds0 + D5_AL + (unsigned)((wave * 32 + l15) * 4), al_r = lds0 + D5_AL + (unsigned)(l15 * 4);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the Q loads and tile 0: nothing of the compiler's is younger than the hand-counted pieces below
 
-  // S^T = K Q^T of one tile: 32 keys x 32 queries of this wave, scaled to binades (s * scale * log2 e); a K fragment feeds both query tiles
-  auto scores = [&](int kv0, int buf, bool tail, f32x4 (&sacc)[2][NT]) __attribute__((always_inline)) {
+  // S^T = K Q^T of one tile: 32 keys x 32 queries of this wave, scaled to binades (s * scale * log2 e); a K fragment feeds both query tiles.
+  // Eight batches of four fragments; batch b + 1 is read from LDS before the MFMAs of batch b are issued, and (PREFETCH) two of the next tile's
+  // sixteen LDS-DMA pieces go out behind every batch instead of all in front of the tile's first MFMA.
+  auto scores = [&](int kv0, int buf, bool tail, f32x4 (&sacc)[2][NT], auto prefetch) __attribute__((always_inline)) {
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int t = 0; t < NT; ++t) sacc[j][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const unsigned kb = kbase + (unsigned)buf * D5_KB;
-    attn_static_for<0, NT * KS / 4>([&](auto bc) {
-      constexpr int t = decltype(bc)::value / (KS / 4), k0 = (decltype(bc)::value % (KS / 4)) * 4;
-      f16x8 kf[4];
-      attn_static_for<0, 4>([&](auto ic) { constexpr int i = decltype(ic)::value; attn_lds_read128<t * 16 * 1024>(kf[i], kb ^ (unsigned)((k0 + i) * 64)); });
+    constexpr int NB = NT * KS / 4;
+    f16x8 kf[2][4];
+    auto issue_k = [&](auto bc) __attribute__((always_inline)) {
+      constexpr int bb = decltype(bc)::value, t = bb / (KS / 4), k0 = (bb % (KS / 4)) * 4;
+      attn_static_for<0, 4>([&](auto ic) { constexpr int i = decltype(ic)::value; attn_lds_read128<t * 16 * 1024>(kf[bb & 1][i], kb ^ (unsigned)((k0 + i) * 64)); });
+    };
+    issue_k(std::integral_constant<int, 0>{});
+    attn_static_for<0, NB>([&](auto bc) {
+      constexpr int bb = decltype(bc)::value, t = bb / (KS / 4), k0 = (bb % (KS / 4)) * 4;
+      if constexpr (bb + 1 < NB) issue_k(std::integral_constant<int, bb + 1>{});
       attn_static_for<0, 4>([&](auto ic) {
         constexpr int i = decltype(ic)::value;
-        attn_lds_wait<3 - i>(kf[i]);
-        sacc[0][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[i], qf[0][k0 + i], sacc[0][t], 0, 0, 0);
-        sacc[1][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[i], qf[1][k0 + i], sacc[1][t], 0, 0, 0);
+        attn_lds_wait<(bb + 1 < NB ? 4 : 0) + 3 - i>(kf[bb & 1][i]);
+        sacc[0][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[bb & 1][i], qf[0][k0 + i], sacc[0][t], 0, 0, 0);
+        sacc[1][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[bb & 1][i], qf[1][k0 + i], sacc[1][t], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
       });
+      prefetch(bc);
+      __builtin_amdgcn_sched_barrier(0);
     });
 #pragma unroll
     for (int j = 0; j < 2; ++j)
@@ -709,7 +720,7 @@ __global__ __launch_bounds__(256, 1) void attn_d512_kernel(const AttnParams p) {
   {
     __builtin_amdgcn_s_barrier();   // (tile 0 landed: every wave waited for its pieces above)
     f32x4 sacc[2][NT];
-    scores(0, 0, p.Lk < D5_BKV, sacc);
+    scores(0, 0, p.Lk < D5_BKV, sacc, [](auto) {});
 #pragma unroll
     for (int j = 0; j < 2; ++j) mref[j] = xmax32(xmax16(rowmax(sacc[j]))) + D5_LEAD;
   }
@@ -729,9 +740,9 @@ __global__ __launch_bounds__(256, 1) void attn_d512_kernel(const AttnParams p) {
       constexpr bool TAIL = decltype(TAILC)::value;
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of the tile
       __builtin_amdgcn_s_barrier();                      // every wave's pieces landed; every wave is done with the other buffer and with P
-      if (kv0 + D5_BKV < p.Lk) issue_tile(kv0 + D5_BKV, buf ^ 1);
+      const bool more = kv0 + D5_BKV < p.Lk;
       f32x4 sacc[2][NT];
-      scores(kv0, buf, TAIL, sacc);
+      scores(kv0, buf, TAIL, sacc, [&](auto bc) __attribute__((always_inline)) { if (more) issue_row(kv0 + D5_BKV, buf ^ 1, bc); });
       // ---- p = 2^(s - m_ref) (lane: query 16 j + l15 of the wave, keys 16 t + 4 g + r), row sums per lane, P to LDS ----
 #pragma unroll
       for (int j = 0; j < 2; ++j) {

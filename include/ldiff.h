@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define LDIFF_VERSION 141 /* 0.1.4.1: + ldiff_probe_argmax_u8, ldiff_op_ln_linear, ldiff_op_attention_prescaled, ldiff_conv_args.short_runs */
+#define LDIFF_VERSION 142 /* 0.1.4.2: + fp8 lo halves (ldiff_op_norm_apply_lo8, ldiff_op_lo8_weights, ldiff_conv_args.lo8_*), CU-share streams */
 #define LDIFF_MAX_BLOCKS 8
 
 typedef enum { LDIFF_OK = 0, LDIFF_ERR_INVALID = -1, LDIFF_ERR_RUNTIME = -2, LDIFF_ERR_STATE = -3 } ldiff_status;
@@ -212,6 +212,10 @@ typedef struct {
   int y_lo;                                         /* > 0: write y split: hi at column n, lo = f16(v - hi) at column y_lo + n */
   int short_runs;                                   /* 1: the persistent conv kernels retire a workgroup after ONE unit / tile (what ldiff_sample sets for the VAE
                                                        decodes that run beside the next UNet pass); 0: one workgroup per CU walks its whole share */
+  int lo8_slab0;                                    /* > 0: x is a split operand whose lo half is fp8 (ldiff_op_norm_apply_lo8): rows of [C fp16 | C e4m3] = 3C
+                                                       bytes, C1 = 3C/2, lo8_slab0 = C/64, w built by ldiff_op_lo8_weights; 3x3 stride 1, C % 128 == 0, N % 128 == 0,
+                                                       split output with statistics, maps that fill the chip with 16 x 16 tiles; anything else: LDIFF_ERR_INVALID */
+  const void* lo8_scale;                            /* the int ldiff_op_lo8_weights wrote (device memory) */
 } ldiff_conv_args;
 int ldiff_op_conv(const ldiff_conv_args*, void* stream);
 /* row blocks per image the launch would emit statistics for (0 = unsupported for this shape) */
@@ -244,6 +248,12 @@ int ldiff_op_norm_apply(const void* x, int C1, int ld1, int lo1, const void* x2,
                         const void* shift, int silu, void* y, int ldy, int y_lo, void* stream);
 /* weights of a contraction over a split operand: per tap [a(Ca) b(Cb) ..] -> [a a b b 0..] */
 int ldiff_op_dup_weights(const void* w, void* wd, int Nrows, int taps, int src_tap_stride, int Ca, int Cb, int dst_tap_stride, void* stream);
+/* Split conv operand with an fp8 lo half (the lo product is a 2^-11 correction: three mantissa bits reproduce it to within everything else's noise,
+ * profiles/r04_precision_study_lo8.txt; the block-scaled MFMA runs e4m3 at twice the fp16 rate).  norm_apply_lo8: y rows [C1 fp16 | C1 e4m3 of
+ * lo * 2^15], 3 C1 bytes, C1 % 16 == 0.  lo8_weights: [Nrows][taps][Cin] fp16 -> [Nrows][taps][Cin fp16 | Cin e4m3 of w * 2^sw] (3 Cin bytes per tap),
+ * scale_out[0] = 127 - sw (one int, device memory), Cin % 128 == 0. */
+int ldiff_op_norm_apply_lo8(const void* x, int C1, int ld1, int lo1, int B, int HW, const void* scale, const void* shift, int silu, void* y, void* stream);
+int ldiff_op_lo8_weights(const void* w, void* wd, void* scale_out, int Nrows, int taps, int Cin, void* stream);
 int ldiff_op_geglu(const void* x, void* y, int64_t M, int C4, void* stream);
 /* lo_off > 0: also store the rounding remainder of channel c at channel lo_off + c (split first-layer input) */
 int ldiff_op_nchw_to_nhwc(const void* x_f32, void* y_f16, int B, int C, int H, int W, int Cpad, int lo_off, void* stream);

@@ -35,7 +35,8 @@ class ConvArgs(C.Structure):
                 ("gn_scale", C.c_void_p), ("gn_shift", C.c_void_p), ("silu_in", C.c_int),
                 ("bias", C.c_void_p), ("temb", C.c_void_p), ("ld_temb", C.c_int),
                 ("res", C.c_void_p), ("ld_res", C.c_int), ("y", C.c_void_p), ("ldy", C.c_int), ("out_f32", C.c_int), ("stats", C.c_void_p),
-                ("geglu", C.c_int), ("ld1", C.c_int), ("ld2", C.c_int), ("res_lo", C.c_int), ("y_lo", C.c_int), ("short_runs", C.c_int)]
+                ("geglu", C.c_int), ("ld1", C.c_int), ("ld2", C.c_int), ("res_lo", C.c_int), ("y_lo", C.c_int), ("short_runs", C.c_int),
+                ("lo8_slab0", C.c_int), ("lo8_scale", C.c_void_p)]
 
 
 # name -> (restype, argtypes); every symbol include/ldiff.h declares
@@ -88,6 +89,8 @@ SIGNATURES = {
     "ldiff_op_ln_linear": (I, [P, I, I, I, I, P, P, F, P, I, I, P, I, P, I, I, F, P]),
     "ldiff_op_norm_apply": (I, [P, I, I, I, P, I, I, I, I, I, P, P, I, P, I, I, P]),
     "ldiff_op_dup_weights": (I, [P, P, I, I, I, I, I, I, P]),
+    "ldiff_op_norm_apply_lo8": (I, [P, I, I, I, I, I, P, P, I, P, P]),
+    "ldiff_op_lo8_weights": (I, [P, P, P, I, I, I, P]),
     "ldiff_op_geglu": (I, [P, P, I64, I, P]),
     "ldiff_op_nchw_to_nhwc": (I, [P, P, I, I, I, I, I, I, P]),
     "ldiff_op_im2col_t": (I, [P, P, I, I, I, I, I, I, I, I, I, I, I, P]),

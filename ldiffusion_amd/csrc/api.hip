@@ -475,6 +475,7 @@ static void conv_args_to_params(const ldiff_conv_args* a, ConvParams& p) {
   p.M = a->B * a->Hout * a->Wout;
   p.stats = (float*)a->stats;
   p.geglu = a->geglu != 0;
+  p.lo8_slab0 = a->lo8_slab0; p.lo8_sa = (const int*)a->lo8_scale; p.lo8_sb = a->lo8_slab0 ? 127 - LO8_SHIFT : 0;
 }
 int ldiff_op_conv(const ldiff_conv_args* a, void* stream) {
   API_BEGIN
@@ -572,7 +573,18 @@ int ldiff_op_norm_apply(const void* x, int C1, int ld1, int lo1, const void* x2,
                         const void* shift, int silu, void* y, int ldy, int y_lo, void* stream) {
   API_BEGIN
   launch_norm_apply(SrcView{(const f16*)x, C1, ld1, lo1}, SrcView{(const f16*)x2, C2, ld2, lo2}, B, HW, (const float*)scale, (const float*)shift, silu,
-                    (f16*)y, ldy, y_lo, (hipStream_t)stream);
+                    (f16*)y, ldy, y_lo, 0, (hipStream_t)stream);
+  API_END
+}
+int ldiff_op_norm_apply_lo8(const void* x, int C1, int ld1, int lo1, int B, int HW, const void* scale, const void* shift, int silu, void* y, void* stream) {
+  API_BEGIN
+  launch_norm_apply(SrcView{(const f16*)x, C1, ld1, lo1}, SrcView{nullptr, 0, 0, 0}, B, HW, (const float*)scale, (const float*)shift, silu,
+                    (f16*)y, C1 + C1 / 2, C1, 1, (hipStream_t)stream);
+  API_END
+}
+int ldiff_op_lo8_weights(const void* w, void* wd, void* scale_out, int Nrows, int taps, int Cin, void* stream) {
+  API_BEGIN
+  launch_lo8_weights((const f16*)w, wd, (int*)scale_out, Nrows, taps, Cin, (hipStream_t)stream);
   API_END
 }
 int ldiff_op_dup_weights(const void* w, void* wd, int Nrows, int taps, int src_tap_stride, int Ca, int Cb, int dst_tap_stride, void* stream) {

@@ -85,7 +85,16 @@ struct ConvParams {
   int short_runs = 0;   // set by the executor of a graph that shares the chip with another stream (the VAE decoder beside the UNet): persistent kernels cap their run length
   unsigned div_tm; int tiles_m, img_fast;   // conv3x3 halo-tile kernels, set by their launchers: pixel tiles of the launch; tile order (see conv3x3_img_fast)
   const f16* w_frag;      // conv3x3 dataflow kernel only (conv3x3d_selected): the weights fragment-packed by launch_pack_frag_weights
+  // Split operand with an fp8 lo half (16 x 16 ping-pong kernel only, conv3x3p_selected): a row of x is [C fp16 hi | C e4m3 lo * 2^LO8_SHIFT] = 3C bytes,
+  // a row of w per tap [C fp16 | C e4m3 of w * 2^sw] (launch_lo8_weights); in 128-byte slabs: C / 64 fp16 slabs, then C / 128 fp8 slabs, so
+  // C1 = 3C / 2 "elements" and K = taps * 3C / 2.  lo8_slab0 = C / 64 (first fp8 slab; 0 = no such operand), lo8_sa -> the E8M0 scale operand
+  // 127 - sw written by launch_lo8_weights, lo8_sb = 127 - LO8_SHIFT.  The fp8 slabs go through v_mfma_scale_f32_16x16x128_f8f6f4.
+  int lo8_slab0 = 0, lo8_sb = 0;
+  const int* lo8_sa = nullptr;
 };
+constexpr int LO8_SHIFT = 15;   // lo = x - fp16(x) of a GroupNorm + SiLU output (|x| < 64: |lo| <= 2^-6) times 2^15 stays inside e4m3's 448; beyond, it saturates
+// [Nrows][taps][Cin] fp16 -> [Nrows][taps][Cin fp16 | Cin e4m3 of w * 2^sw], sw = floor(log2(448 / max |w|)); scale_out[0] = 127 - sw (one int)
+void launch_lo8_weights(const f16* w, void* wd, int* scale_out, int Nrows, int taps, int Cin, hipStream_t s);
 void launch_igemm(const ConvParams& p, hipStream_t s);   // dispatches to the halo-tile 3x3 kernel when eligible
 bool conv3x3_eligible(const ConvParams& p);
 int conv3x3_splitk_plan(const ConvParams& p);
@@ -146,7 +155,7 @@ void launch_layernorm(SrcView x, f16* y, int rows, const float* gamma, const flo
 // y[m, c] = act(x[m, c] * scale[b, c] + shift[b, c]) over the channel concat of one or two sources, written plain (y_lo = 0,
 // ONE fp16 rounding of the fp32 result) or split (hi | lo).  GroupNorm-apply(+SiLU) as its own pass: used where the consumer is
 // a split-operand contraction (the GEMM kernels take their operands by LDS-DMA and cannot transform them on the way).
-void launch_norm_apply(SrcView x1, SrcView x2, int B, int HW, const float* scale, const float* shift, int silu, f16* y, int ldy, int y_lo,
+void launch_norm_apply(SrcView x1, SrcView x2, int B, int HW, const float* scale, const float* shift, int silu, f16* y, int ldy, int y_lo, int lo8,
                        hipStream_t s);
 // wd[n][tap][...] = { a(Ca), a(Ca), b(Cb), b(Cb), 0... } from w[n][tap][a(Ca) b(Cb) ...]: the weights of a contraction whose
 // operand is a split tensor [hi | lo] (K doubled, same weights for both halves)

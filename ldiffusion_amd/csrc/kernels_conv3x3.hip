@@ -835,6 +835,7 @@ void launch_c3_gn(const ConvParams& p, hipStream_t s) {
 static inline int c3_tile_w(const ConvParams& p) { return (p.w_par ? p.Win : p.Wout) >= 16 ? 16 : 8; }
 
 int conv3x3_stats_blocks(const ConvParams& p) {
+  if (p.lo8_slab0) return conv3x3p_stats_blocks(p);
   if (conv3x3d_selected(p)) return conv3x3d_stats_blocks(p);
   if (conv3x3p_selected(p)) return conv3x3p_stats_blocks(p);
   const int TW = c3_tile_w(p);
@@ -891,6 +892,11 @@ int conv3x3_splitk_plan(const ConvParams& p) {
 void launch_conv3x3(const ConvParams& p, hipStream_t s) {
   LDIFF_CHECK(p.splitk <= 1 || (p.splitk_ws && !p.stats), LDIFF_ERR_INVALID, "conv3x3: split-K needs a workspace and cannot emit fused statistics");
   LDIFF_CHECK(!p.w_par || (p.ups == 1 && p.splitk <= 1), LDIFF_ERR_INVALID, "conv3x3: parity weights need ups=1 and no split-K");
+  if (p.lo8_slab0) {   // split operand with an fp8 lo half: only the 16 x 16 ping-pong kernel reads that layout
+    LDIFF_CHECK(p.splitk <= 1 && conv3x3p_selected(p), LDIFF_ERR_INVALID, "conv3x3: an fp8 lo half needs the 16 x 16 ping-pong kernel (C1=%d N=%d %dx%d)", p.C1, p.N, p.Hout, p.Wout);
+    launch_conv3x3p(p, s);
+    return;
+  }
   if (conv3x3n_selected(p)) { launch_conv3x3n(p, s); return; }
   if (conv3x3d_selected(p)) { launch_conv3x3d(p, s); return; }
   if (conv3x3p_selected(p)) { launch_conv3x3p(p, s); return; }

@@ -106,7 +106,15 @@ struct TileC { int b, oy0, ox0, n0, q; };   // image, pixel origin (tile space),
 // FLAGS: what the epilogue has to do.  Compiled in only where needed: every optional block inside the persistent loop costs the other
 // configurations time as well (the same kernel without the residual / split-output / statistics code ran the epilogue segment in
 // 1290 instead of 3840 cycles and every load segment ~35 % faster: instruction fetch of a 50 KB loop body with cold blocks in it)
-enum { C3P_RES = 1, C3P_LO = 2, C3P_STATS = 4 };
+enum { C3P_RES = 1, C3P_LO = 2, C3P_STATS = 4, C3P_LO8 = 8 };   // LO8: the input is a split operand with an fp8 lo half (ConvParams::lo8_slab0)
+typedef int v4i_t __attribute__((ext_vector_type(4)));
+typedef int v8i_t __attribute__((ext_vector_type(8)));
+// the two 16-byte k-half fragments of a lane side by side = its 32 bytes of a 16x16x128 fp8 operand (any lane -> channel mapping is valid
+// as long as A and B use the same one: chunk g and chunk 4 + g of the 128-byte row, exactly what the fp16 path reads)
+__device__ __forceinline__ v8i_t cat8(const f16x8& a, const f16x8& b) {
+  const v4i_t x = __builtin_bit_cast(v4i_t, a), y = __builtin_bit_cast(v4i_t, b);
+  return (v8i_t){x[0], x[1], x[2], x[3], y[0], y[1], y[2], y[3]};
+}
 
 template <int BN, bool PAR, int FLAGS>
 __global__ __launch_bounds__(512, 2) void conv3x3p_kernel(const ConvParams p, const int total_tiles) {
@@ -118,6 +126,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3p_kernel(const ConvParams p, co
   constexpr unsigned BTAB = W_OFF + NSLOT * W_BYTES;                             // [bias BN | temb BN] float of the workgroup's next tile
   constexpr unsigned XCH = BTAB + 1024;                              // [grp 2][wave_m 2][wave_n 2][g 4][16 values] float2
   constexpr int NF = NT + MT;
+  constexpr bool LO8 = (FLAGS & C3P_LO8) != 0;
   static_assert(BN == 64 || BN == 128, "a wave owns BN/8 weight rows = whole 1 KiB DMA pieces");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
 
@@ -135,6 +144,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3p_kernel(const ConvParams p, co
   const unsigned lds0 = (unsigned)(size_t)(lptr_t*)smem_raw;
   const long long Kw = (long long)NTAPS * Cin;
   const int nslab = Cin / 64;
+  // fp8 lo slabs (LO8): slab index from which the operands are e4m3, and the two E8M0 scale operands of the block-scaled MFMA
+  const int lo8_c0 = LO8 ? p.lo8_slab0 : 0x7fffffff, lo8_sb = p.lo8_sb;
+  const int lo8_sa = LO8 ? __builtin_amdgcn_readfirstlane(*p.lo8_sa) : 0;
 
   // Persistent workgroups: workgroup w walks tiles w, w + gridDim.x, ...  XCD-aware order: the workgroups of one XCD (id % 8) walk one
   // contiguous range of the tile list (n-tile fastest, then x, y, image, parity), so halos and weight slices are shared through its L2.
@@ -423,10 +435,15 @@ __global__ __launch_bounds__(512, 2) void conv3x3p_kernel(const ConvParams p, co
   full_barrier();
   init_acc();
   f16x8 xf0[MT], wf0[NT];   // k-half 0 operands of the next matrix segment
+  f16x8 xf1p[MT], wf1p[NT]; // LO8 only: k-half 1 as well (an fp8 step needs both halves of an operand in front of its first MFMA)
   {
     constexpr int kx0 = 0;   // tap 0: ky = 0, column shift 0 (parity mode: px)
     static_for<0, MT>([&](auto mc) { constexpr int m = decltype(mc)::value; lds_read128<m * ROWB>(xf0[m], xb[kx0]); });
     static_for<0, NT>([&](auto ac) { constexpr int a = decltype(ac)::value; lds_read128<a * 2048>(wf0[a], w_lane); });
+    if constexpr (LO8) {
+      static_for<0, MT>([&](auto mc) { constexpr int m = decltype(mc)::value; lds_read128<m * ROWB>(xf1p[m], xb[kx0] ^ 64u); });
+      static_for<0, NT>([&](auto ac) { constexpr int a = decltype(ac)::value; lds_read128<a * 2048>(wf1p[a], w_lane ^ 64u); });
+    }
   }
   lgkm_barrier();
   if (grp) lgkm_barrier();   // group B runs one phase behind
@@ -440,8 +457,13 @@ __global__ __launch_bounds__(512, 2) void conv3x3p_kernel(const ConvParams p, co
   // and tripled the code the instruction cache has to hold.
   int c = 0;
   bool more = t_id + (int)gridDim.x < total_tiles;
-  for (;;) {
-    const bool tlast = c == nslab - 1;          // last slab of the tile
+  // One slab (9 or 4 steps).  F8C (LO8 kernels only): the slab's operands are e4m3 -- a compile-time property of the call site, because a
+  // run-time branch between the two MFMA forms inside ONE loop body makes the accumulators of the two paths distinct registers (the CFG is
+  // structurised: 64 more registers, 130 spills); the LO8 kernels therefore run two loops per tile, fp16 slabs then fp8 slabs, and the
+  // fp16 copy knows at compile time that it never holds the tile's last slab (no epilogue code in it).
+  auto slab = [&](auto f8c) __attribute__((always_inline)) -> bool {
+    constexpr bool F8 = decltype(f8c)::value;
+    const bool tlast = (LO8 && !F8) ? false : c == nslab - 1;   // last slab of the tile
     const bool stage = !tlast || more;          // another slab follows (of this tile, or slab 0 of the workgroup's next tile)
     const unsigned hbuf = hb * HBUF;
     unsigned xc[3];
@@ -455,7 +477,28 @@ __global__ __launch_bounds__(512, 2) void conv3x3p_kernel(const ConvParams p, co
       const bool final = LAST && !stage;        // the workgroup's very last step
       // ---------------- matrix segment ----------------
       STAMP(t0);
-      {
+      if constexpr (LO8) {
+        // both k-halves were prefetched in the previous load segment.  fp16 slab: 2 x 16 MFMAs of K = 32; fp8 slab (128 channels in the same
+        // 128 bytes per pixel / weight row): 16 block-scaled MFMAs of K = 128 over the two halves side by side -- the same matrix-pipe time
+        if constexpr (F8) {
+          static_for<0, NT>([&](auto ac) {
+            constexpr int a = decltype(ac)::value;
+            const v8i_t wv = cat8(wf0[a], wf1p[a]);
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+              acc[a][m] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wv, cat8(xf0[m], xf1p[m]), acc[a][m], 0, 0, 0, lo8_sa, 0, lo8_sb);
+            __builtin_amdgcn_sched_barrier(0);
+          });
+        } else {
+          static_for<0, 2 * NT>([&](auto ic) {
+            constexpr int kk = decltype(ic)::value / NT, a = decltype(ic)::value % NT;
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+              acc[a][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kk ? wf1p[a] : wf0[a], kk ? xf1p[m] : xf0[m], acc[a][m], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+          });
+        }
+      } else {
         // k-half 0 is in registers already (prefetched at the end of the previous load segment); k-half 1 flies under its MFMAs
         const unsigned wc1 = wslot(T) ^ 64u, xk1 = xc[kxi] ^ 64u;   // chunk bit 2 = k-half: XOR commutes with the swizzle
         f16x8 wf1[NT], xf1[MT];
@@ -501,7 +544,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3p_kernel(const ConvParams p, co
         // residual (never in front of an upsampling conv): added to the sums in the load segments of the tile's last slab, 16 registers
         // at a time: rows 0-1 / 2-3 of the hi half fly over the matrix segments of taps 4 / 5, those of a split residual's lo half over
         // taps 6 / 7; the last of it is in before tap 8, so at most a few MFMA steps round on top of it
-        if (tlast) {
+        if (tlast && (!LO8 || p.res)) {   // (the LO8 build serves convs with and without a residual: its residual-free variant does not fit the registers)
           constexpr std::integral_constant<int, 0> h0{}; constexpr std::integral_constant<int, 1> h1{};
           if constexpr (T == 3) load_res(cur, 0, 0);
           if constexpr (T == 4) { add_res(h0); __builtin_amdgcn_sched_barrier(0); load_res(cur, 1, 0); }
@@ -552,6 +595,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3p_kernel(const ConvParams p, co
         const unsigned wn = wslot(T + 1);
         static_for<0, MT>([&](auto mc) { constexpr int m = decltype(mc)::value; lds_read128<(m + kyn) * ROWB>(xf0[m], xn); });
         static_for<0, NT>([&](auto ac) { constexpr int a = decltype(ac)::value; lds_read128<a * 2048>(wf0[a], wn); });
+        if constexpr (LO8) {
+          static_for<0, MT>([&](auto mc) { constexpr int m = decltype(mc)::value; lds_read128<(m + kyn) * ROWB>(xf1p[m], xn ^ 64u); });
+          static_for<0, NT>([&](auto ac) { constexpr int a = decltype(ac)::value; lds_read128<a * 2048>(wf1p[a], wn ^ 64u); });
+        }
       }
       // the very last step's load segment is followed by nothing: no barrier
       __builtin_amdgcn_sched_barrier(0);
@@ -567,12 +614,26 @@ __global__ __launch_bounds__(512, 2) void conv3x3p_kernel(const ConvParams p, co
     });
     sp = (sp + NTAPS) & (NSLOT - 1);
     hb ^= 1u;
-    if (tlast) {
-      if (!more) break;
-      t_id += gridDim.x;
-      more = t_id + (int)gridDim.x < total_tiles;
-      c = 0;
-    } else ++c;
+    return tlast;
+  };
+  auto next_tile_or_done = [&]() __attribute__((always_inline)) -> bool {
+    if (!more) return true;
+    t_id += gridDim.x;
+    more = t_id + (int)gridDim.x < total_tiles;
+    c = 0;
+    return false;
+  };
+  if constexpr (!LO8) {
+    for (;;) {
+      if (slab(std::false_type{})) { if (next_tile_or_done()) break; }
+      else ++c;
+    }
+  } else {
+    for (;;) {
+      for (; c < lo8_c0; ++c) slab(std::false_type{});
+      for (;; ++c) if (slab(std::true_type{})) break;
+      if (next_tile_or_done()) break;
+    }
   }
 
 #ifdef C3P_STAMPS
@@ -636,6 +697,7 @@ bool conv3x3p_selected(const ConvParams& p) {
   if (mode == 0 || p.splitk > 1 || p.out_f32) return false;
   const bool par = p.w_par != nullptr;
   if (p.gn_scale || !c3p_instantiated(p)) return false;   // GroupNorm prologue: the 8x16 kernel (see the header)
+  if (p.lo8_slab0 && (par || p.x2 || p.ups || p.ld1 || p.C1 != 96 * p.lo8_slab0 || (p.lo8_slab0 & 1) || !p.lo8_sa)) return false;   // fp8 lo half: one source of 3C/2 "elements", C % 128 == 0
   const int Ht = par ? p.Hin : p.Hout, Wt = par ? p.Win : p.Wout;
   if (Ht < 16 || Wt < 16 || p.N < 48 || (p.N & 7) || (p.ldy & 7) || (p.y_lo & 7)) return false;
   // halo staging addresses the sources through buffer descriptors with a 2^31 out-of-range sentinel
@@ -657,10 +719,11 @@ int conv3x3p_stats_blocks(const ConvParams& p) {
 }
 // instantiated configurations: 128 channels per tile: every combination (the VAE / UNet resnet convs), 64: no split outputs,
 // parity mode (upsampling convs): statistics or nothing
-static int c3p_flags(const ConvParams& p) { return (p.res ? C3P_RES : 0) | (p.y_lo ? C3P_LO : 0) | (p.stats ? C3P_STATS : 0); }
+static int c3p_flags(const ConvParams& p) { return (p.res || p.lo8_slab0 ? C3P_RES : 0) | (p.y_lo ? C3P_LO : 0) | (p.stats ? C3P_STATS : 0) | (p.lo8_slab0 ? C3P_LO8 : 0); }
 static bool c3p_instantiated(const ConvParams& p) {
   const int f = c3p_flags(p);
   if (p.w_par) return (f & ~C3P_STATS) == 0;
+  if (f & C3P_LO8) return c3p_bn(p) == 128 && (f & ~C3P_RES) == (C3P_LO8 | C3P_LO | C3P_STATS);   // the encoder's resnet convs: split output with statistics
   return c3p_bn(p) == 128 || (f & C3P_LO) == 0;
 }
 template <int BN, bool PAR, int... FS>
@@ -675,7 +738,7 @@ void launch_conv3x3p(const ConvParams& p, hipStream_t s) {
     if (c3p_bn(p) == 64) c3p_dispatch<64, true>(p, s, std::integer_sequence<int, 0, 4>{});
     else c3p_dispatch<128, true>(p, s, std::integer_sequence<int, 0, 4>{});
   } else if (c3p_bn(p) == 64) c3p_dispatch<64, false>(p, s, std::integer_sequence<int, 0, 1, 4, 5>{});
-  else c3p_dispatch<128, false>(p, s, std::integer_sequence<int, 0, 1, 2, 3, 4, 5, 6, 7>{});
+  else c3p_dispatch<128, false>(p, s, std::integer_sequence<int, 0, 1, 2, 3, 4, 5, 6, 7, 15>{});
 }
 
 #ifdef C3P_STAMPS

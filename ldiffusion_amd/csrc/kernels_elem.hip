@@ -76,6 +76,53 @@ void launch_dup_weights(const f16* w, f16* wd, int Nrows, int taps, int src_tap_
   HIP_CHECK(hipGetLastError());
 }
 
+// ---- weights of a split operand whose lo half is fp8 (ConvParams::lo8_slab0): per (row, tap) [Cin fp16 | Cin e4m3 of w * 2^sw] ----
+__global__ __launch_bounds__(1024) void lo8_absmax_kernel(const f16* __restrict__ w, long long n, int* __restrict__ scale_out) {
+  __shared__ float red[16];
+  float m = 0.f;
+  for (long long i = threadIdx.x; i < n; i += 1024) m = fmaxf(m, fabsf((float)w[i]));
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int i = 1; i < 16; ++i) m = fmaxf(m, red[i]);
+    int sw = 0;
+    if (m > 0.f) {
+      int e;
+      frexpf(448.0f / m, &e);   // 448 / m = f * 2^e with f in [0.5, 1): floor(log2) = e - 1
+      sw = e - 1;
+      sw = sw < -100 ? -100 : (sw > 100 ? 100 : sw);
+    }
+    scale_out[0] = 127 - sw;
+  }
+}
+__global__ void lo8_weights_kernel(const f16* __restrict__ w, unsigned char* __restrict__ wd, long long rows /* Nrows*taps */, int Cin, const int* __restrict__ scale) {
+  const int cpr = Cin >> 3;
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * cpr) return;
+  const long long r = i / cpr;
+  const int c = (int)(i - r * cpr) * 8;
+  const float sc = __builtin_ldexpf(1.0f, 127 - scale[0]);
+  const uint4 v = *reinterpret_cast<const uint4*>(w + r * Cin + c);
+  const f16x8 h = __builtin_bit_cast(f16x8, v);
+  unsigned char* row = wd + r * (3LL * Cin);
+  *reinterpret_cast<uint4*>(row + 2 * c) = v;
+  float f[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) f[j] = __builtin_amdgcn_fmed3f((float)h[j] * sc, -448.f, 448.f);
+  int q0 = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], 0, false), q1 = __builtin_amdgcn_cvt_pk_fp8_f32(f[4], f[5], 0, false);
+  q0 = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], q0, true); q1 = __builtin_amdgcn_cvt_pk_fp8_f32(f[6], f[7], q1, true);
+  *reinterpret_cast<int2*>(row + 2 * Cin + c) = make_int2(q0, q1);
+}
+void launch_lo8_weights(const f16* w, void* wd, int* scale_out, int Nrows, int taps, int Cin, hipStream_t s) {
+  LDIFF_CHECK(w && wd && scale_out && Cin % 128 == 0 && Nrows > 0 && taps > 0, LDIFF_ERR_INVALID, "lo8_weights: Cin %d must be a multiple of 128", Cin);
+  const long long rows = (long long)Nrows * taps, n = rows * (Cin >> 3);
+  hipLaunchKernelGGL(lo8_absmax_kernel, dim3(1), dim3(1024), 0, s, w, rows * Cin, scale_out);
+  hipLaunchKernelGGL(lo8_weights_kernel, dim3(nblocks(n)), dim3(256), 0, s, w, (unsigned char*)wd, rows, Cin, scale_out);
+  HIP_CHECK(hipGetLastError());
+}
+
 __global__ void nhwc_f32_to_nchw_f32_kernel(const float* __restrict__ x, float* __restrict__ y, int B, int C, int HW, int ldx) {
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (long long)B * C * HW) return;

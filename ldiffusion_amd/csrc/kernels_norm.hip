@@ -237,7 +237,7 @@ void launch_gn_stats(SrcView x1, SrcView x2, int B, int HW, int groups, float ep
 
 // ---- GroupNorm-apply (+SiLU) as its own pass (common.h launch_norm_apply): one thread per 8 channels of one pixel ----
 __global__ __launch_bounds__(256) void norm_apply_kernel(SrcView s1, SrcView s2, int HW, long long rows, const float* __restrict__ scale,
-                                                         const float* __restrict__ shift, int silu, f16* __restrict__ y, int ldy, int y_lo) {
+                                                         const float* __restrict__ shift, int silu, f16* __restrict__ y, int ldy, int y_lo, int lo8) {
   const int Ct = s1.C + (s2.p ? s2.C : 0), cpr = Ct >> 3;
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= rows * cpr) return;
@@ -261,20 +261,27 @@ __global__ __launch_bounds__(256) void norm_apply_kernel(SrcView s1, SrcView s2,
     lo[j] = (f16)(v - (float)hi[j]);
   }
   *reinterpret_cast<uint4*>(y + m * ldy + c) = __builtin_bit_cast(uint4, hi);
-  if (y_lo) *reinterpret_cast<uint4*>(y + m * ldy + y_lo + c) = __builtin_bit_cast(uint4, lo);
+  if (lo8) {   // lo half as e4m3 of lo * 2^LO8_SHIFT (saturating), one byte per channel behind the Ct fp16 hi values (ConvParams::lo8_slab0)
+    float q[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) q[j] = __builtin_amdgcn_fmed3f((float)lo[j] * (float)(1 << LO8_SHIFT), -448.f, 448.f);
+    int q0 = __builtin_amdgcn_cvt_pk_fp8_f32(q[0], q[1], 0, false), q1 = __builtin_amdgcn_cvt_pk_fp8_f32(q[4], q[5], 0, false);
+    q0 = __builtin_amdgcn_cvt_pk_fp8_f32(q[2], q[3], q0, true); q1 = __builtin_amdgcn_cvt_pk_fp8_f32(q[6], q[7], q1, true);
+    *reinterpret_cast<int2*>(reinterpret_cast<unsigned char*>(y + m * ldy + y_lo) + c) = make_int2(q0, q1);
+  } else if (y_lo) *reinterpret_cast<uint4*>(y + m * ldy + y_lo + c) = __builtin_bit_cast(uint4, lo);
 }
-void launch_norm_apply(SrcView x1, SrcView x2, int B, int HW, const float* scale, const float* shift, int silu, f16* y, int ldy, int y_lo,
+void launch_norm_apply(SrcView x1, SrcView x2, int B, int HW, const float* scale, const float* shift, int silu, f16* y, int ldy, int y_lo, int lo8,
                        hipStream_t s) {
   x1 = norm_view(x1); x2 = norm_view(x2);
   if (!x2.p) x2.C = 0;
   const int Ct = x1.C + x2.C;
   LDIFF_CHECK(x1.p && y && scale && shift && x1.C % 8 == 0 && x2.C % 8 == 0 && x1.ld % 8 == 0 && x1.lo % 8 == 0 && (!x2.p || (x2.ld % 8 == 0 && x2.lo % 8 == 0)) &&
-                  ldy % 8 == 0 && y_lo % 8 == 0 && (y_lo == 0 || y_lo >= Ct) && ldy >= Ct + (y_lo ? y_lo : 0),
+                  ldy % 8 == 0 && y_lo % 8 == 0 && (y_lo == 0 || y_lo >= Ct) && ldy >= (lo8 ? y_lo + Ct / 2 : Ct + (y_lo ? y_lo : 0)) && (!lo8 || (y_lo > 0 && Ct % 16 == 0)),
               LDIFF_ERR_INVALID, "norm_apply: bad layout (C=%d+%d ldy=%d y_lo=%d)", x1.C, x2.C, ldy, y_lo);
   const long long rows = (long long)B * HW, n = rows * (Ct >> 3);
   if (n == 0) return;
   ProfScope prof("norm_apply", 4.0 * rows * Ct, 2.0 * rows * ((double)x1.C * (x1.lo ? 2 : 1) + (double)x2.C * (x2.lo ? 2 : 1) + (double)Ct * (y_lo ? 2 : 1)), s);
-  hipLaunchKernelGGL(norm_apply_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x1, x2, HW, rows, scale, shift, silu, y, ldy, y_lo);
+  hipLaunchKernelGGL(norm_apply_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x1, x2, HW, rows, scale, shift, silu, y, ldy, y_lo, lo8);
   HIP_CHECK(hipGetLastError());
 }
 

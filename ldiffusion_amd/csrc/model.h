@@ -20,10 +20,11 @@ struct Act {
   f16* p = nullptr;
   int B = 0, H = 0, W = 0, C = 0;
   bool split = false;
+  bool lo8 = false;      // split with an fp8 lo half: a row is [C fp16 | C e4m3 of lo * 2^LO8_SHIFT] = 3C bytes (ConvParams::lo8_slab0); conv operands only
   float* st = nullptr;   // producer-fused GroupNorm partial statistics [B][st_R][C][2] (nullptr: none)
   int st_R = 0;
   long long rows() const { return (long long)B * H * W; }
-  int ld() const { return split ? 2 * C : C; }       // row pitch in elements
+  int ld() const { return lo8 ? C + C / 2 : (split ? 2 * C : C); }       // row pitch in elements
   int lo() const { return split ? C : 0; }           // offset of the lo half inside a row
   size_t bytes() const { return (size_t)rows() * ld() * sizeof(f16); }
   SrcView view() const { return SrcView{p, C, ld(), lo()}; }
@@ -43,6 +44,7 @@ struct MatW {   // [Nrows][K] fp16 K-major + fp32 bias
   mutable Derived dup_par;        //   parity weights of the duplicated matrix
   mutable Derived frag;           //   MFMA-fragment-packed copy for the dataflow conv3x3 kernel (kernels_conv3x3d.hip)
   mutable Derived tiled;          //   panel-tiled copy for the LayerNorm-fused GEMM (kernels_gemm_ast.hip)
+  mutable Derived lo8;            //   split operand with an fp8 lo half: [Nrows][taps][Cin fp16 | Cin e4m3] + one int (the E8M0 scale operand) behind it
 };
 struct NormW { float* g = nullptr; float* b = nullptr; int C = 0; };
 struct GNss { float* scale = nullptr; float* shift = nullptr; };
@@ -112,12 +114,14 @@ class Exec {
   bool short_runs = false;            // this graph runs beside another stream's (ConvParams::short_runs)
   ~Exec();
   void ensure_gn_partial(size_t bytes);
-  Act new_act(int B, int H, int W, int C, bool split = false);
+  Act new_act(int B, int H, int W, int C, bool split = false, bool lo8 = false);
   const f16* derived_dup(const MatW& w, int C1_logical, int C2_logical);
   const f16* derived_par(const MatW& w, const f16* src, int Cin, Derived& d);
   const f16* derived_frag(const MatW& w, const ConvParams& p);
   const f16* derived_tiled(const MatW& w, int N);
-  Act norm_apply(const Act& x, const Act* x2, const GNss& g, bool silu, bool split_out);
+  const f16* derived_lo8(const MatW& w, const int** scale);   // fp8-lo weights of a split operand + the device int holding their E8M0 scale operand
+  bool lo8_conv_ok(const MatW& w, const Act& x, bool res, bool split_out) const;   // would conv(w, norm_apply(x) with an fp8 lo half) run on the ping-pong kernel?
+  Act norm_apply(const Act& x, const Act* x2, const GNss& g, bool silu, bool split_out, bool lo8 = false);
   void release(Act& a);
   template <typename T> T* tmp(size_t n) { return reinterpret_cast<T*>(arena.alloc(n * sizeof(T))); }
   GNss gn(const Act& x, const Act* x2, const NormW& w, int groups, float eps);

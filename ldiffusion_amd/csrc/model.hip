@@ -225,9 +225,9 @@ void Exec::ensure_gn_partial(size_t bytes) {
   HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&gn_partial), bytes));
   gn_partial_cap = bytes;
 }
-Act Exec::new_act(int B, int H, int W, int C, bool split) {
+Act Exec::new_act(int B, int H, int W, int C, bool split, bool lo8) {
   Act a;
-  a.B = B; a.H = H; a.W = W; a.C = C; a.split = split;
+  a.B = B; a.H = H; a.W = W; a.C = C; a.split = split || lo8; a.lo8 = lo8;
   a.p = (f16*)arena.alloc(a.bytes());
   return a;
 }
@@ -275,6 +275,39 @@ const f16* Exec::derived_dup(const MatW& w, int C1, int C2) {
     w.dup.gen = gen; w.dup.key = C1;
   }
   return w.dup.p;
+}
+// split operand with an fp8 lo half (ConvParams::lo8_slab0): per (row, tap) [Cin fp16 | Cin e4m3 of w * 2^sw]; the int behind the matrix is 127 - sw
+const f16* Exec::derived_lo8(const MatW& w, const int** scale) {
+  const int gen = weights_gen ? *weights_gen : 0;
+  const size_t bytes = (size_t)w.Nrows * w.ks * w.ks * w.Cin * 3;
+  if (!w.lo8.p) {
+    void* q = nullptr;
+    HIP_CHECK(hipMalloc(&q, bytes + 16));
+    owned.push_back(q);
+    w.lo8.p = (f16*)q;
+  }
+  int* sc = reinterpret_cast<int*>(reinterpret_cast<unsigned char*>(w.lo8.p) + bytes);
+  if (w.lo8.gen != gen) {
+    launch_lo8_weights(w.w, w.lo8.p, sc, w.Nrows, w.ks * w.ks, w.Cin, s);
+    w.lo8.gen = gen;
+  }
+  *scale = sc;
+  return w.lo8.p;
+}
+// LDIFF_LO8: 1 (default) = the lo half of a split conv operand travels as fp8 where the 16 x 16 ping-pong kernel takes it, 0 = fp16 lo halves everywhere
+bool Exec::lo8_conv_ok(const MatW& w, const Act& x, bool res, bool split_out) const {
+  static const int mode = [] { const char* e = getenv("LDIFF_LO8"); return e ? atoi(e) : 1; }();
+  if (!mode || w.ks != 3 || x.C != w.Cin || x.C % 128 != 0 || w.Cin_logical > 0 || !split_out) return false;
+  ConvParams p;
+  memset(&p, 0, sizeof(p));
+  static const int one = 127;
+  p.x = x.p; p.C1 = x.C + x.C / 2; p.lo8_slab0 = x.C / 64; p.lo8_sb = 127 - LO8_SHIFT; p.lo8_sa = &one;
+  p.B = x.B; p.Hin = p.Hout = x.H; p.Win = p.Wout = x.W; p.ks = 3; p.stride = 1; p.pad_t = p.pad_l = 1;
+  p.w = w.w; p.N = roundup(w.N, 4); p.Nrows = w.Nrows; p.K = 9 * p.C1; p.M = x.B * x.H * x.W;
+  if (p.N != w.N || p.N % 8 != 0) return false;
+  p.y = x.p; p.ldy = 2 * p.N; p.y_lo = p.N; p.stats = reinterpret_cast<float*>(x.p);   // (placeholders: only null / non-null and the layout matter)
+  if (res) { p.res = x.p; p.ld_res = 2 * p.N; p.res_lo = p.N; }
+  return conv3x3_eligible(p) && conv3x3_splitk_plan(p) <= 1 && conv3x3p_selected(p);
 }
 const f16* Exec::derived_frag(const MatW& w, const ConvParams& p) {
   const int gen = weights_gen ? *weights_gen : 0;
@@ -328,13 +361,16 @@ Act Exec::conv(const MatW& w, const Act& x, const Act* x2, const ConvOpts& o) {
   if (o.split_in && small) {             // hi | lo live inside the 8 padded channels of ONE source
     LDIFF_CHECK(!x2, LDIFF_ERR_INVALID, "conv: first-layer split operand takes one source");
     p.C1 = x.split ? x.ld() : x.C;
+  } else if (o.split_in && x.lo8) {      // hi halves fp16, lo halves fp8: 3C/2 "elements" per row (ConvParams::lo8_slab0)
+    LDIFF_CHECK(!x2 && x.C % 128 == 0, LDIFF_ERR_INVALID, "conv: an fp8 lo half takes one source with C %% 128 == 0");
+    p.C1 = x.C + x.C / 2; p.lo8_slab0 = x.C / 64; p.lo8_sb = 127 - LO8_SHIFT;
   } else if (o.split_in) {               // all 2C channels of each source, K doubled
     p.C1 = 2 * x.C; p.C2 = x2 ? 2 * x2->C : 0;
   } else {                               // hi halves only (row pitch 2C for a split source)
     p.C1 = x.C; p.C2 = x2 ? x2->C : 0;
     p.ld1 = x.split ? x.ld() : 0; p.ld2 = (x2 && x2->split) ? x2->ld() : 0;
   }
-  const int Cin_eff = (o.split_in && !small) ? 2 * w.Cin : w.Cin;
+  const int Cin_eff = (o.split_in && x.lo8) ? w.Cin + w.Cin / 2 : (o.split_in && !small) ? 2 * w.Cin : w.Cin;
   LDIFF_CHECK(p.C1 + p.C2 == Cin_eff, LDIFF_ERR_INVALID, "conv: input has %d channels, weight expects %d", p.C1 + p.C2, Cin_eff);
   p.B = x.B; p.Hin = x.H; p.Win = x.W;
   p.ks = w.ks; p.stride = o.stride; p.ups = o.ups;
@@ -343,7 +379,7 @@ Act Exec::conv(const MatW& w, const Act& x, const Act* x2, const ConvOpts& o) {
   const int He = x.H << o.ups, We = x.W << o.ups;
   p.Hout = o.Hout > 0 ? o.Hout : (He + 2 * p.pad_t - w.ks) / o.stride + 1;
   p.Wout = o.Wout > 0 ? o.Wout : (We + 2 * p.pad_l - w.ks) / o.stride + 1;
-  const f16* wsrc = o.split_in ? derived_dup(w, x.C, x2 ? x2->C : 0) : w.w;
+  const f16* wsrc = (o.split_in && x.lo8) ? derived_lo8(w, &p.lo8_sa) : o.split_in ? derived_dup(w, x.C, x2 ? x2->C : 0) : w.w;
   p.w = wsrc; p.Nrows = w.Nrows; p.K = w.ks * w.ks * Cin_eff;
   p.N = o.N_override ? o.N_override : roundup(w.N, 4);
   p.bias = w.b;
@@ -416,10 +452,10 @@ Act Exec::conv(const MatW& w, const Act& x, const Act* x2, const ConvOpts& o) {
   if (wfold) { arena.free(bfold); arena.free(wfold); }
   return y;
 }
-Act Exec::norm_apply(const Act& x, const Act* x2, const GNss& g, bool silu, bool split_out) {
+Act Exec::norm_apply(const Act& x, const Act* x2, const GNss& g, bool silu, bool split_out, bool lo8) {
   const int C = x.C + (x2 ? x2->C : 0);
-  Act y = new_act(x.B, x.H, x.W, C, split_out);
-  launch_norm_apply(x.view(), x2 ? x2->view() : SrcView{nullptr, 0, 0, 0}, x.B, x.H * x.W, g.scale, g.shift, silu ? 1 : 0, y.p, y.ld(), y.lo(), s);
+  Act y = new_act(x.B, x.H, x.W, C, split_out, lo8);
+  launch_norm_apply(x.view(), x2 ? x2->view() : SrcView{nullptr, 0, 0, 0}, x.B, x.H * x.W, g.scale, g.shift, silu ? 1 : 0, y.p, y.ld(), y.lo(), lo8 ? 1 : 0, s);
   return y;
 }
 Act Exec::layernorm(const Act& x, const NormW& w) {
@@ -470,7 +506,7 @@ Act Exec::resnet(const ResnetW& r, const Act& x, const Act* skip, const float* t
   o1.temb = temb; o1.ld_temb = ld_temb; o1.want_stats = true;
   Act h;
   if (full) {
-    Act a = norm_apply(x, skip, g1, true, true);
+    Act a = norm_apply(x, skip, g1, true, true, !skip && lo8_conv_ok(r.c1, x, false, true));
     o1.split_in = true; o1.split_out = true;
     h = conv(r.c1, a, nullptr, o1);
     release(a);
@@ -492,7 +528,7 @@ Act Exec::resnet(const ResnetW& r, const Act& x, const Act* skip, const float* t
   o2.res = resp; o2.want_stats = true; o2.split_out = st;
   Act out;
   if (full) {
-    Act a = norm_apply(h, nullptr, g2, true, true);
+    Act a = norm_apply(h, nullptr, g2, true, true, lo8_conv_ok(r.c2, h, true, o2.split_out));
     o2.split_in = true;
     out = conv(r.c2, a, nullptr, o2);
     release(a);

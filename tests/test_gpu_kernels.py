@@ -763,6 +763,78 @@ def test_conv3x3_persistent_kernel_epilogue_configs(lib, shape, res, lo, stats):
             assert (gotn - refn).abs().max() <= 2e-4 * max(1.0, refn.abs().max().item()), f"launch {it}: fused statistics"
 
 
+@pytest.mark.parametrize("Cin,res", [(128, 0), (128, 1), (256, 1)])
+def test_conv3x3_split_operand_with_fp8_lo_half(lib, Cin, res):
+    """Split conv operand whose lo half is fp8 (ldiff_op_norm_apply_lo8 -> [C fp16 | C e4m3 of lo * 2^15], ldiff_op_lo8_weights ->
+    [C fp16 | C e4m3 of w * 2^sw] per tap, ldiff_conv_args.lo8_slab0): the 16 x 16 ping-pong kernel runs the C / 64 fp16 slabs through the fp16
+    MFMA and the C / 128 fp8 slabs through the block-scaled fp8 MFMA.  Checked (a) against the exact statement of what the kernel is given --
+    conv(hi, w) + conv(decoded lo8, decoded w8) in fp64, to fp32 round-off -- and (b) against the conv over the fp32 operand: ~2^-14 instead of
+    the 2^-11 of a plain fp16 operand.  Split output with fused statistics, with and without a split residual; three launches (ping-pong)."""
+    B, H, W, Cout = 4, 128, 128, 128
+    g = torch.Generator().manual_seed(Cin + res)
+    x = torch.randn((B, H, W, Cin), generator=g) * 1.5
+    x[0, 3, 5, 7] = 90.0                                                   # its lo (2^-5) saturates e4m3 at 448 / 2^15: degrades gracefully
+    w = (torch.randn((Cout, 3, 3, Cin), generator=g) / math.sqrt(9 * Cin)).to(torch.float16)
+    bias = torch.randn(Cout, generator=g) * 0.1
+    # producer: GroupNorm-apply with scale 1, shift 0, no activation = the plain split of x
+    x32 = torch.cat([x.to(torch.float16), (x - x.to(torch.float16).float()).to(torch.float16)], -1).contiguous().to(DEV)   # a split source (hi | lo)
+    ones, zeros = torch.ones((B, Cin), device=DEV), torch.zeros((B, Cin), device=DEV)
+    xq = torch.empty((B, H, W, 3 * Cin), dtype=torch.uint8, device=DEV)
+    _lib.check(lib.ldiff_op_norm_apply_lo8(x32.data_ptr(), Cin, 2 * Cin, Cin, B, H * W, ones.data_ptr(), zeros.data_ptr(), 0, xq.data_ptr(), sp()))
+    wd = w.reshape(Cout, -1).contiguous().to(DEV)
+    wq = torch.empty((Cout, 9, 3 * Cin), dtype=torch.uint8, device=DEV)
+    wsc = torch.zeros(4, dtype=torch.int32, device=DEV)
+    _lib.check(lib.ldiff_op_lo8_weights(wd.data_ptr(), wq.data_ptr(), wsc.data_ptr(), Cout, 9, Cin, sp()))
+    torch.cuda.synchronize()
+    # decode what the kernel is given
+    xqc, wqc, sw = xq.cpu(), wq.cpu(), 127 - int(wsc[0].item())
+    x_hi = xqc[..., :2 * Cin].contiguous().view(torch.float16).double()
+    x_lo = xqc[..., 2 * Cin:].contiguous().view(torch.float8_e4m3fn).float().double() * 2.0 ** -15
+    w_hi = wqc[..., :2 * Cin].contiguous().view(torch.float16).double().reshape(Cout, 3, 3, Cin)
+    w_lo = wqc[..., 2 * Cin:].contiguous().view(torch.float8_e4m3fn).float().double().reshape(Cout, 3, 3, Cin) * 2.0 ** -sw
+    assert torch.equal(w_hi.float(), w.float().reshape(Cout, 3, 3, Cin)), "hi halves of the weights are the fp16 weights"
+    assert (x_hi.float() != x.to(torch.float16).float()).float().mean() <= 1e-3   # (hi + lo re-rounded by the producer: equal up to ties)
+    assert 2.0 ** sw * w.float().abs().max() <= 448.0 < 2.0 ** (sw + 1) * w.float().abs().max()
+    lo_true = x.double() - x_hi
+    assert ((x_lo - lo_true).abs() <= 2.0 ** -4 * lo_true.abs() + 2.0 ** -25).sum() >= x_lo.numel() - 1   # three mantissa bits (one element saturated)
+    nchw = lambda t: t.permute(0, 3, 1, 2)
+    ref_given = F.conv2d(nchw(x_hi), nchw(w_hi), bias.double(), padding=1) + F.conv2d(nchw(x_lo), nchw(w_lo), None, padding=1)
+    ref_full = F.conv2d(nchw(x.double()), nchw(w.double()), bias.double(), padding=1)
+    a_ = _lib.ConvArgs()
+    a_.x, a_.C1, a_.B, a_.Hin, a_.Win, a_.Hout, a_.Wout = xq.data_ptr(), Cin + Cin // 2, B, H, W, H, W
+    a_.ks, a_.stride, a_.pad_t, a_.pad_l = 3, 1, 1, 1
+    a_.w, a_.N, a_.Nrows, a_.bias = wq.data_ptr(), Cout, Cout, bias.to(DEV).data_ptr()
+    bias_d = bias.to(DEV); a_.bias = bias_d.data_ptr()
+    a_.lo8_slab0, a_.lo8_scale = Cin // 64, wsc.data_ptr()
+    y = torch.empty((B, H, W, 2 * Cout), dtype=torch.float16, device=DEV)
+    a_.y, a_.ldy, a_.y_lo = y.data_ptr(), 2 * Cout, Cout
+    if res:
+        r = torch.randn((B, H, W, Cout), generator=g) * 2.0
+        rd = torch.cat([r.to(torch.float16), (r - r.to(torch.float16).float()).to(torch.float16)], -1).contiguous().to(DEV)
+        a_.res, a_.ld_res, a_.res_lo = rd.data_ptr(), 2 * Cout, Cout
+        radd = nchw(rd.cpu()[..., :Cout].double() + rd.cpu()[..., Cout:].double())
+        ref_given, ref_full = ref_given + radd, ref_full + radd
+    R = lib.ldiff_op_conv_stats_blocks(C.byref(a_))
+    assert R > 0
+    st = torch.empty((B, Cout, R, 2), device=DEV)
+    a_.stats = st.data_ptr()
+    for it in range(3):
+        y.fill_(float("nan")); st.fill_(float("nan"))
+        _lib.check(lib.ldiff_op_conv(C.byref(a_), sp()))
+        torch.cuda.synchronize()
+        yc = y.cpu().double()
+        got = nchw(yc[..., :Cout] + yc[..., Cout:])
+        assert torch.isfinite(got).all(), f"launch {it}: non-finite output"
+        e_given = ((got - ref_given).abs().max() / ref_given.abs().max()).item()
+        e_full = ((got - ref_full).abs().max() / ref_full.abs().max()).item()
+        print(f"Cin {Cin} res {res} launch {it}: against the given operands {e_given:.2e}, against the fp32 operand {e_full:.2e} of range")
+        assert e_given <= 3e-6, f"launch {it}: {e_given:.3e} from the exact statement of the given operands"
+        assert e_full <= 4e-5, f"launch {it}: {e_full:.3e} from the conv over the fp32 operand"
+        sums = st.double().cpu().sum(dim=2)
+        want = torch.stack([got.sum(dim=(2, 3)), (got * got).sum(dim=(2, 3))], dim=-1)
+        assert torch.isfinite(sums).all() and ((sums - want).abs() / (want.abs() + H * W * 1e-3)).max() <= 1e-4, f"launch {it}: fused statistics"
+
+
 def test_split_operand_beats_plain_operand(lib):
     """The point of the split operand: the same 1x1 conv over the same fp32 stream is ~2^-11 accurate with a plain fp16 operand and
     ~1e-6 with the split one."""

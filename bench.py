@@ -320,7 +320,8 @@ def main():
                    "batches_in_flight": 1 if (args.no_pipeline or args.steps < 2) else 2},
     }
     result["config"]["precision"] = ("split residual stream (fp16 hi|lo), fp16 MFMA operands, fp32 accumulate; UNet mode 1, VAE encoder "
-                                     "mode 2, decoder mode 0 (include/ldiff.h ldiff_unet_set_precision): latents within 1e-3 of the fp32 oracle, "
+                                     "mode 2 (the lo halves of its 3x3 conv operands travel as e4m3 through the block-scaled fp8 MFMA unless LDIFF_LO8=0: "
+                                     "a 2^-11 correction term, DESIGN.md section 3), decoder mode 0 (include/ldiff.h ldiff_unet_set_precision): latents within 1e-3 of the fp32 oracle, "
                                      "uint8 features within one grey level")
     result["checked"] = checked
     result["check"] = {"masks_crc32": f"{masks_crc:08x}", "classes_present": int(masks.max().item()) + 1,

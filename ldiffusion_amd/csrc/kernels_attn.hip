@@ -862,6 +862,265 @@ static void launch_attn_d512(const AttnParams& p, hipStream_t s) {
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// d = 40 self-attention over long sequences (UNet level 0: 4,096 tokens x 8 heads, the largest kernel of a UNet pass; 16,384 tokens at 1024^2).
+// The generic kernel spends ~5.5 vector issue slots per score (FMA, exp, max chain, two converts and a pack, lane swaps, alpha) against 0.9 matrix
+// cycles and is bound by them.  This one keeps the same tiling (128 queries per workgroup, 64-key tiles, S^T = K Q^T, P in registers) and
+//   * fixes every query's softmax reference after the first key tile (its maximum + 4 binades, as attn_d512_kernel): no max chain, no lane
+//     swaps, no alpha, no rescale in the loop.  The row sums come out of the P V MFMAs (V^T row 40 = 1: the lanes that hold channel 40 of a
+//     V^T fragment substitute 1.0), so a probability that overflowed fp16 makes its row sum inf: the end of the pass checks the sums, and the
+//     (rare) workgroup that failed takes the true row maxima in a scores-only pass and repeats with those;
+//   * packs P with v_cvt_pkrtz_f16_f32 (one instruction per two scores; numerator and row sum see the same rounded P);
+//   * brings K / V in by LDS-DMA, double-buffered, ONE raw barrier per tile (zero padding of the 128-byte K rows and the channel-40..47 chunk of
+//     V by the out-of-range sentinel), operand reads issued in batches with counted waits.
+// ~3.5 issue slots per score.  Two workgroups per CU: one's softmax runs beside the other's MFMAs.
+constexpr int FR_BKV = 64, FR_D = 40;
+constexpr unsigned FR_KB = FR_BKV * 128, FR_VROW = 96, FR_VB = FR_BKV * FR_VROW, FR_K0 = 0, FR_V0 = 2 * FR_KB, FR_FL = FR_V0 + 2 * FR_VB, FR_LDS = FR_FL + 16;
+constexpr float FR_LEAD = 4.0f;
+
+template <bool PASS_MAX>
+struct FrTag {};
+
+__global__ __launch_bounds__(256, 2) void attn_fr40_kernel(const AttnParams p) {
+  typedef __attribute__((address_space(3))) void lds_void;
+  constexpr int QT = 2, KS = 2, NT = FR_BKV / 16, DT = 3;
+  constexpr unsigned OOR = 0x80000000u;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 4, l15 = lane & 15;
+  int qtile = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+  if (p.xcd_order) {   // (see attn_kernel)
+    const int gx = gridDim.x, gy = gridDim.y, nwg = gx * gy * gridDim.z;
+    const int id = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+    const int q8 = nwg >> 3, r8 = nwg & 7, xcd = id & 7, idx = id >> 3;
+    int sw = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
+    qtile = sw % gx; sw /= gx;
+    h = sw % gy; b = sw / gy;
+  }
+  const int qbase = qtile * (64 * QT) + wave * (16 * QT);
+  const f16* Qp = p.q + (long long)b * p.q_bstride + h * FR_D;
+  const f16* Kp = p.k + (long long)b * p.kv_bstride + h * FR_D;
+  const f16* Vp = p.v + (long long)b * p.kv_bstride + h * FR_D;
+  const int ldk2 = p.ldk * 2, ldv2 = p.ldv * 2;
+  const __amdgpu_buffer_rsrc_t rsk = __builtin_amdgcn_make_buffer_rsrc((void*)Kp, 0, (int)((long long)(p.Lk - 1) * ldk2 + FR_D * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsv = __builtin_amdgcn_make_buffer_rsrc((void*)Vp, 0, (int)((long long)(p.Lk - 1) * ldv2 + FR_D * 2), 0x00020000);
+  const unsigned lds0 = (unsigned)(size_t)(lds_void*)smem_raw;
+
+  // K tile: 64 rows of 128 B (chunk c of row r at position c ^ ((r >> 1) & 7); chunks 5..7 zero) = 8 pieces of 8 rows, wave w: pieces 2w, 2w + 1.
+  // V tile: 64 rows of 96 B (chunk 5 zero) = 6 pieces of 1 KiB, wave w: piece w and, for w < 2, piece 4 + w.  Per-lane byte offsets inside
+  // the tile are fixed; the tile's first row goes into the scalar offset.
+  int kvo[2], vvo[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int row = (wave * 2 + i) * 8 + (lane >> 3), c = (lane & 7) ^ ((row >> 1) & 7);
+    kvo[i] = c < 5 ? row * ldk2 + c * 16 : (int)OOR;
+    const int idx = (i == 0 ? wave : 4 + wave) * 64 + lane, vr = idx / 6, vc = idx - vr * 6;
+    vvo[i] = vc < 5 ? vr * ldv2 + vc * 16 : (int)OOR;
+  }
+  auto issue_tile = [&](int kv0, int buf) __attribute__((always_inline)) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsk, (lds_void*)(smem_raw + FR_K0 + buf * FR_KB + (wave * 2) * 1024), 16, kvo[0], kv0 * ldk2, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsk, (lds_void*)(smem_raw + FR_K0 + buf * FR_KB + (wave * 2 + 1) * 1024), 16, kvo[1], kv0 * ldk2, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsv, (lds_void*)(smem_raw + FR_V0 + buf * FR_VB + wave * 1024), 16, vvo[0], kv0 * ldv2, 0, 0);
+    if (wave < 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsv, (lds_void*)(smem_raw + FR_V0 + buf * FR_VB + (4 + wave) * 1024), 16, vvo[1], kv0 * ldv2, 0, 0);
+#endif
+  };
+  issue_tile(0, 0);
+
+  f16x8 qf[QT][KS];
+#pragma unroll
+  for (int qt = 0; qt < QT; ++qt) {
+    const int qi = qbase + qt * 16 + l15;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const int dd = ks * 32 + g * 8;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (qi < p.Lq && dd < FR_D) v = *reinterpret_cast<const uint4*>(Qp + (long long)qi * p.ldq + dd);
+      qf[qt][ks] = __builtin_bit_cast(f16x8, v);
+    }
+  }
+  const float sl2 = p.scale * 1.4426950408889634f;
+  // K fragment of key tile t, k-step ks: row 16 t + l15, chunk 4 ks + g at position (4 ks + g) ^ ((row >> 1) & 7); (row >> 1) & 7 = (l15 >> 1) for every t
+  const unsigned kb0 = lds0 + FR_K0 + (unsigned)(l15 * 128 + ((g ^ (l15 >> 1)) << 4));
+  // V^T fragment (transposed read): lane 4 q + pp of its 16-lane group addresses key row 8 g' .. (see attn_kernel): rows 16 (2 s2) + 4 g + (l15 >> 2) (+ 16), columns 16 dt + 4 (l15 & 3)
+  const unsigned vb0 = lds0 + FR_V0 + (unsigned)((g * 4 + (l15 >> 2)) * FR_VROW + (l15 & 3) * 8);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+  auto scores = [&](int buf, f32x4 (&sacc)[QT][NT]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+      for (int t = 0; t < NT; ++t) sacc[qt][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const unsigned kb = kb0 + (unsigned)buf * FR_KB;
+    f16x8 kf[NT][KS];
+    attn_static_for<0, NT>([&](auto tc) {
+      constexpr int t = decltype(tc)::value;
+      attn_lds_read128<t * 16 * 128>(kf[t][0], kb);
+      attn_lds_read128<t * 16 * 128>(kf[t][1], kb ^ 64u);
+    });
+    attn_static_for<0, NT>([&](auto tc) {
+      constexpr int t = decltype(tc)::value;
+      attn_lds_wait<2 * (NT - 1 - t) + 1>(kf[t][0]);
+      sacc[0][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[t][0], qf[0][0], sacc[0][t], 0, 0, 0);
+      sacc[1][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[t][0], qf[1][0], sacc[1][t], 0, 0, 0);
+      attn_lds_wait<2 * (NT - 1 - t)>(kf[t][1]);
+      sacc[0][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[t][1], qf[0][1], sacc[0][t], 0, 0, 0);
+      sacc[1][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[t][1], qf[1][1], sacc[1][t], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    });
+  };
+  auto tile_max = [&](int kv0, bool tail, const f32x4 (&sa)[NT]) __attribute__((always_inline)) {   // over this lane's 16 keys of the tile, raw scores
+    float mx = -1e30f;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) mx = fmaxf(mx, (tail && kv0 + t * 16 + g * 4 + r >= p.Lk) ? -1e30f : sa[t][r]);
+    return mx;
+  };
+
+  // ---- references (binades): maximum over the first key tile + FR_LEAD ----
+  float mref[QT];
+  {
+    __builtin_amdgcn_s_barrier();
+    f32x4 sacc[QT][NT];
+    scores(0, sacc);
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) mref[qt] = xmax32(xmax16(tile_max(0, p.Lk < FR_BKV, sacc[qt]))) * sl2 + FR_LEAD;
+  }
+
+  f32x4 oacc[QT][DT];
+  const int full = p.Lk / FR_BKV * FR_BKV;
+  const f16 one = (f16)1.0f;
+  const f16x8 ones8 = {one, one, one, one, one, one, one, one};
+  for (int pass = 0;; ++pass) {
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) oacc[qt][dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    auto tile = [&](int kv0, int buf, auto TAILC) __attribute__((always_inline)) {
+      constexpr bool TAIL = decltype(TAILC)::value;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of the tile
+      __builtin_amdgcn_s_barrier();                      // every wave's pieces landed; every wave is done with the other buffer
+      if (kv0 + FR_BKV < p.Lk) issue_tile(kv0 + FR_BKV, buf ^ 1);
+      f32x4 sacc[QT][NT];
+      scores(buf, sacc);
+      // ---- p = 2^(s * scale * log2 e - reference); P^T fragments for the P V products straight from the score registers ----
+      f16x8 pf[QT][NT / 2];
+#pragma unroll
+      for (int qt = 0; qt < QT; ++qt) {
+        const float moff = -mref[qt];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          float e[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            e[r] = __builtin_amdgcn_exp2f(fmaf(sacc[qt][t][r], sl2, moff));
+            if (TAIL && kv0 + t * 16 + g * 4 + r >= p.Lk) e[r] = 0.f;
+          }
+          typedef __fp16 h2_t __attribute__((ext_vector_type(2)));
+          const h2_t a = __builtin_amdgcn_cvt_pkrtz(e[0], e[1]), c = __builtin_amdgcn_cvt_pkrtz(e[2], e[3]);
+          pf[qt][t >> 1][(t & 1) * 4 + 0] = (f16)a[0]; pf[qt][t >> 1][(t & 1) * 4 + 1] = (f16)a[1];
+          pf[qt][t >> 1][(t & 1) * 4 + 2] = (f16)c[0]; pf[qt][t >> 1][(t & 1) * 4 + 3] = (f16)c[1];
+        }
+      }
+      // ---- O^T += V^T P^T; V^T row 40 (d tile 2, lane l15 = 8) is all ones: row 40 of O^T accumulates the row sums ----
+      const unsigned vb = vb0 + (unsigned)buf * FR_VB;
+      f16x4 vlo[NT / 2][DT], vhi[NT / 2][DT];
+      attn_static_for<0, NT / 2>([&](auto sc) {
+        constexpr int s2 = decltype(sc)::value;
+        attn_static_for<0, DT>([&](auto dc) {
+          constexpr int dt = decltype(dc)::value;
+          attn_lds_read_tr<(2 * s2) * 16 * (int)FR_VROW + dt * 32>(vlo[s2][dt], vb);
+          attn_lds_read_tr<(2 * s2 + 1) * 16 * (int)FR_VROW + dt * 32>(vhi[s2][dt], vb);
+        });
+      });
+      attn_static_for<0, NT / 2>([&](auto sc) {
+        constexpr int s2 = decltype(sc)::value;
+        attn_static_for<0, DT>([&](auto dc) {
+          constexpr int dt = decltype(dc)::value;
+          attn_lds_wait<2 * ((NT / 2 - 1 - s2) * DT + (DT - 1 - dt))>(vlo[s2][dt], vhi[s2][dt]);
+          f16x8 vf = {vlo[s2][dt][0], vlo[s2][dt][1], vlo[s2][dt][2], vlo[s2][dt][3], vhi[s2][dt][0], vhi[s2][dt][1], vhi[s2][dt][2], vhi[s2][dt][3]};
+          if constexpr (dt == 2) vf = l15 == 8 ? ones8 : vf;
+#pragma unroll
+          for (int qt = 0; qt < QT; ++qt) oacc[qt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf[qt][s2], oacc[qt][dt], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+        });
+      });
+    };
+    int buf = 0;
+    for (int kv0 = 0; kv0 < full; kv0 += FR_BKV, buf ^= 1) tile(kv0, buf, std::false_type());
+    if (full < p.Lk) tile(full, buf, std::true_type());
+
+    // ---- every row sum finite?  (row 40 of O^T: lane g = 2, register 0 of d tile 2) ----
+    bool bad = false;
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) bad |= g == 2 && !(oacc[qt][2][0] < 3.0e38f);
+    const float flag = __builtin_amdgcn_ballot_w64(bad) != 0 ? 1.0f : 0.0f;
+    __builtin_amdgcn_s_barrier();   // (all K / V reads of the pass are done)
+    if (lane == 0) d5_lds_write32(lds0 + FR_FL + (unsigned)(wave * 4), flag);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    f32x4 fl;
+    asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(fl) : "v"(lds0 + FR_FL) : "memory");
+    if (pass == 1 || __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, fl[0] + fl[1] + fl[2] + fl[3])) == 0) break;
+    // ---- some probability overflowed fp16: the true row maxima in a scores-only pass, then once more (cannot fail) ----
+    float mobs[QT] = {-1e30f, -1e30f};
+    __builtin_amdgcn_s_barrier();
+    issue_tile(0, 0);
+    buf = 0;
+    for (int kv0 = 0; kv0 < p.Lk; kv0 += FR_BKV, buf ^= 1) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (kv0 + FR_BKV < p.Lk) issue_tile(kv0 + FR_BKV, buf ^ 1);
+      f32x4 sacc[QT][NT];
+      scores(buf, sacc);
+#pragma unroll
+      for (int qt = 0; qt < QT; ++qt) mobs[qt] = fmaxf(mobs[qt], tile_max(kv0, kv0 + FR_BKV > p.Lk, sacc[qt]));
+    }
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) mref[qt] = xmax32(xmax16(mobs[qt])) * sl2;
+    __builtin_amdgcn_s_barrier();
+    issue_tile(0, 0);
+  }
+
+  // ---- normalise and store: lane holds O[q = l15][dd = 16 dt + 4 g + r]; the row sum sits in row 40 = lane (g = 2, l15), register 0 of d tile 2 ----
+  f16* Op = p.o + (long long)b * p.o_bstride + h * FR_D;
+#pragma unroll
+  for (int qt = 0; qt < QT; ++qt) {
+    const int qi = qbase + qt * 16 + l15;
+    const float lsum = __shfl(oacc[qt][2][0], 32 + l15);
+    const float inv = 1.0f / lsum;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) {
+      const int dd = dt * 16 + g * 4;
+      if (qi < p.Lq && dd < FR_D) {
+        const f16x4 o = {(f16)(oacc[qt][dt][0] * inv), (f16)(oacc[qt][dt][1] * inv), (f16)(oacc[qt][dt][2] * inv), (f16)(oacc[qt][dt][3] * inv)};
+        *reinterpret_cast<f16x4*>(Op + (long long)qi * p.ldo + dd) = o;
+      }
+    }
+  }
+}
+
+// LDIFF_ATTN_FIXREF: 1 (default) = d = 40 self-attention over at least two key tiles on the fixed-reference kernel, 0 = the generic kernel
+static bool attn_fr40_selected(const AttnParams& p) {
+  static const int mode = [] { const char* e = getenv("LDIFF_ATTN_FIXREF"); return e ? atoi(e) : 1; }();
+  if (!mode || p.d != FR_D || p.prescaled || p.Lk < 2 * FR_BKV) return false;
+  if ((long long)(p.Lk - 1) * p.ldk * 2 + 128 >= (1LL << 31) || (long long)(p.Lk - 1) * p.ldv * 2 + 128 >= (1LL << 31)) return false;
+  return true;
+}
+static void launch_attn_fr40(const AttnParams& p, hipStream_t s) {
+  auto kern = attn_fr40_kernel;
+  ensure_dyn_smem(reinterpret_cast<const void*>(kern), (int)FR_LDS);
+  dim3 grid((p.Lq + 127) / 128, p.heads, p.B);
+  const double bh = (double)p.B * p.heads;
+  ProfScope prof("attn<40,fixref>", 4.0 * bh * p.Lq * p.Lk * p.d, 2.0 * bh * p.d * (2.0 * p.Lq + 2.0 * p.Lk * (p.kv_bstride ? 1.0 : 1.0 / p.B)), s);
+  static const int xcd_mode = [] { const char* e = getenv("LDIFF_ATTN_XCD"); return e ? atoi(e) : 1; }();
+  AttnParams q = p;
+  q.xcd_order = xcd_mode && grid.x > 1 && p.Lk >= 256 ? 1 : 0;
+  hipLaunchKernelGGL(kern, grid, dim3(256), FR_LDS, s, q);
+  HIP_CHECK(hipGetLastError());
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // Short-K/V cross-attention: L_ctx <= 16 keys (the unpadded prompt "A pathological slide" is 5-6 tokens), all heads of a query row in
 // ONE wave.  The launch is pure streaming of Q and O (K / V are a few KB); one workgroup per (image, head, query tile) -- the generic kernel --
 // reads 80-byte pieces of the 640-byte query rows and pays a K / V tile staging plus two barriers per 64 queries.  Here
@@ -1010,6 +1269,7 @@ void launch_attention(const AttnParams& p, hipStream_t s) {
     if (d == 40) launch_xattn<40>(p, s); else if (d == 80) launch_xattn<80>(p, s); else launch_xattn<160>(p, s);
     return;
   }
+  if (attn_fr40_selected(p)) { launch_attn_fr40(p, s); return; }
   if (d <= 16) launch_attn_cfg<32, 16, 64, 2>(p, s);
   else if (d <= 32) launch_attn_cfg<32, 32, 64, 2>(p, s);
   else if (d <= 48) launch_attn_cfg<64, 48, 64, 2>(p, s);

@@ -275,6 +275,48 @@ def test_attention(lib, name):
     assert_close(o, ref, name, rtol=3e-3, atol_rel=3e-3)
 
 
+@pytest.mark.parametrize("name,B,heads,Lq,Lk,fused,late_spike", [
+    ("level0", 2, 8, 1024, 1024, True, False),
+    ("ragged_tails", 2, 8, 300, 333, False, False),
+    ("other_head_count", 1, 5, 200, 130, False, False),
+    ("repeat_pass", 2, 8, 384, 512, True, True),
+])
+def test_attention_d40_fixed_reference(lib, name, B, heads, Lq, Lk, fused, late_spike):
+    """attn_fr40_kernel (d = 40, at least two key tiles): fixed softmax reference per query (first key tile's maximum + 4 binades), row sums out of
+    the P V MFMAs through a ones row, P packed round-toward-zero, K / V by LDS-DMA.  Cases: fused q/k/v rows (the UNet's layout), ragged query /
+    key tails, a head count that is not 8, and late keys that overflow fp16 P against the first tile's reference (row sum inf -> the workgroup
+    takes the true maxima in a scores-only pass and repeats)."""
+    d = 40
+    Cc = heads * d
+    g = torch.Generator().manual_seed(zlib.crc32(name.encode()) % 1000)
+    q = torch.randn((B, Lq, Cc), generator=g)
+    k = torch.randn((B, Lk, Cc), generator=g)
+    v = torch.randn((B, Lk, Cc), generator=g)
+    if late_spike:
+        k[0, Lk - 3, 2 * d:3 * d] = 12.0 * q[0, 5, 2 * d:3 * d]        # head 2, query 5 of image 0: score 12 |q|^2 / sqrt(40) ~ 75 nats above the first tile
+        k[1, Lk // 2 + 1, :d] = 8.0 * q[1, 290, :d]                    # another workgroup, a middle tile
+    scale = 1.0 / math.sqrt(d)
+    o = torch.full((B, Lq, Cc), float("nan"), dtype=torch.float16, device=DEV)
+    if fused:
+        L = max(Lq, Lk)
+        buf = torch.zeros((B, L, 3 * Cc), dtype=torch.float16)
+        buf[:, :Lq, :Cc] = q.to(torch.float16); buf[:, :Lk, Cc:2 * Cc] = k.to(torch.float16); buf[:, :Lk, 2 * Cc:] = v.to(torch.float16)
+        buf = buf.to(DEV)
+        base = buf.data_ptr()
+        _lib.check(lib.ldiff_op_attention(base, 3 * Cc, base + 2 * Cc, 3 * Cc, base + 4 * Cc, 3 * Cc, o.data_ptr(), Cc, B, heads, Lq, Lk, d,
+                                          L * 3 * Cc, L * 3 * Cc, Lq * Cc, scale, sp()))
+    else:
+        qd, kd, vd = (t.to(torch.float16).to(DEV) for t in (q, k, v))
+        _lib.check(lib.ldiff_op_attention(qd.data_ptr(), Cc, kd.data_ptr(), Cc, vd.data_ptr(), Cc, o.data_ptr(), Cc, B, heads, Lq, Lk, d,
+                                          Lq * Cc, Lk * Cc, Lq * Cc, scale, sp()))
+    torch.cuda.synchronize()
+    qh = r16(q).view(B, Lq, heads, d).transpose(1, 2)
+    kh = r16(k).view(B, Lk, heads, d).transpose(1, 2)
+    vh = r16(v).view(B, Lk, heads, d).transpose(1, 2)
+    ref = F.scaled_dot_product_attention(qh, kh, vh).transpose(1, 2).reshape(B, Lq, Cc)
+    assert_close(o, ref, name, rtol=3e-3, atol_rel=3e-3)
+
+
 @pytest.mark.parametrize("name,B,Lq,Lk,fused,late_spike", [
     ("mid_block_1024", 2, 1024, 1024, True, False),
     ("ragged_tails", 3, 200, 333, False, False),

@@ -25,6 +25,10 @@ SHAPES = {
     "vae64_512_512_gn": (8, 512, 0, 64, 64, 512, 3, 1, 0, 1),
     "vae512_128_3_gn": (8, 128, 0, 512, 512, 3, 3, 1, 0, 1),
     "unetL0_320_320_gn": (8, 320, 0, 64, 64, 320, 3, 1, 0, 1),
+    # (not UNet shapes: N % 128 == 0, for kernel-against-kernel probes of the UNet-sized maps -- LDIFF_CONV3X3_DATAFLOW=0 / 2)
+    "probe_L0_320_256_gn": (8, 320, 0, 64, 64, 256, 3, 1, 0, 1),
+    "probe_L0_640_256_gn": (8, 640, 0, 64, 64, 256, 3, 1, 0, 1),
+    "probe_L1_640_640_gn": (8, 640, 0, 32, 32, 640, 3, 1, 0, 1),
     "unetL0_cat640_320_gn": (8, 320, 320, 64, 64, 320, 3, 1, 0, 1),
     "unetL1_640_640_gn": (8, 640, 0, 32, 32, 640, 3, 1, 0, 1),
     "unetL1_cat1280_640_gn": (8, 640, 640, 32, 32, 640, 3, 1, 0, 1),

@@ -877,9 +877,6 @@ constexpr int FR_BKV = 64, FR_D = 40;
 constexpr unsigned FR_KB = FR_BKV * 128, FR_VROW = 96, FR_VB = FR_BKV * FR_VROW, FR_K0 = 0, FR_V0 = 2 * FR_KB, FR_FL = FR_V0 + 2 * FR_VB, FR_LDS = FR_FL + 16;
 constexpr float FR_LEAD = 4.0f;
 
-template <bool PASS_MAX>
-struct FrTag {};
-
 __global__ __launch_bounds__(256, 2) void attn_fr40_kernel(const AttnParams p) {
   typedef __attribute__((address_space(3))) void lds_void;
   constexpr int QT = 2, KS = 2, NT = FR_BKV / 16, DT = 3;

@@ -877,6 +877,33 @@ def test_conv3x3_split_operand_with_fp8_lo_half(lib, Cin, res):
         assert torch.isfinite(sums).all() and ((sums - want).abs() / (want.abs() + H * W * 1e-3)).max() <= 1e-4, f"launch {it}: fused statistics"
 
 
+def test_cu_share_stream_runs_the_same_kernels(lib):
+    """ldiff_stream_create_cu_share: a stream restricted to a quarter of every XCD's CUs runs a conv and an attention launch to the same bits as
+    the whole-chip stream (the measurement aid behind profiles/r04_cu_partition.txt); bad shares are rejected."""
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn((2, 64, 32, 32), generator=g)
+    w = torch.randn((64, 64, 3, 3), generator=g) / 24.0
+    xd = nhwc16(x)
+    wd = w.permute(0, 2, 3, 1).to(torch.float16).reshape(64, -1).contiguous().to(DEV)
+    a_ = _lib.ConvArgs()
+    a_.x, a_.C1, a_.B, a_.Hin, a_.Win, a_.Hout, a_.Wout, a_.ks, a_.stride, a_.pad_t, a_.pad_l = xd.data_ptr(), 64, 2, 32, 32, 32, 32, 3, 1, 1, 1
+    a_.w, a_.N, a_.Nrows = wd.data_ptr(), 64, 64
+    outs = []
+    raw = C.c_void_p()
+    _lib.check(lib.ldiff_stream_create_cu_share(8, 16, C.byref(raw)))
+    for stream in (sp(), raw):
+        y = torch.full((2, 32, 32, 64), float("nan"), dtype=torch.float16, device=DEV)
+        a_.y, a_.ldy = y.data_ptr(), 64
+        _lib.check(lib.ldiff_op_conv(C.byref(a_), stream))
+        torch.cuda.synchronize()
+        outs.append(y.clone())
+    _lib.check(lib.ldiff_stream_destroy(raw))
+    assert torch.isfinite(outs[0]).all() and torch.equal(outs[0], outs[1])
+    bad = C.c_void_p()
+    assert lib.ldiff_stream_create_cu_share(4, 16, C.byref(bad)) != 0      # not a multiple of 8
+    assert lib.ldiff_stream_create_cu_share(16, 16, C.byref(bad)) != 0     # empty share
+
+
 def test_split_operand_beats_plain_operand(lib):
     """The point of the split operand: the same 1x1 conv over the same fp32 stream is ~2^-11 accurate with a plain fp16 operand and
     ~1e-6 with the split one."""

@@ -275,6 +275,27 @@ def test_attention(lib, name):
     assert_close(o, ref, name, rtol=3e-3, atol_rel=3e-3)
 
 
+@pytest.mark.parametrize("d,heads,Lq,Lk", [(40, 8, 200, 300), (512, 1, 200, 130)])
+def test_attention_long_shared_keys_on_the_fixed_reference_kernels(lib, d, heads, Lq, Lk):
+    """K / V shared by every image of the batch (kv_bstride = 0) with more than one key tile: not a shape the samplers launch, but the two
+    fixed-reference kernels accept it (their K / V buffer descriptors are built per image from the batch stride)."""
+    B, Cc = 3, heads * d
+    g = torch.Generator().manual_seed(d + Lq)
+    q = torch.randn((B, Lq, Cc), generator=g)
+    k = torch.randn((1, Lk, Cc), generator=g)
+    v = torch.randn((1, Lk, Cc), generator=g)
+    qd, kd, vd = (t.to(torch.float16).to(DEV) for t in (q, k, v))
+    o = torch.full((B, Lq, Cc), float("nan"), dtype=torch.float16, device=DEV)
+    _lib.check(lib.ldiff_op_attention(qd.data_ptr(), Cc, kd.data_ptr(), Cc, vd.data_ptr(), Cc, o.data_ptr(), Cc, B, heads, Lq, Lk, d,
+                                      Lq * Cc, 0, Lq * Cc, 1.0 / math.sqrt(d), sp()))
+    torch.cuda.synchronize()
+    qh = r16(q).view(B, Lq, heads, d).transpose(1, 2)
+    kh = r16(k).expand(B, -1, -1).reshape(B, Lk, heads, d).transpose(1, 2)
+    vh = r16(v).expand(B, -1, -1).reshape(B, Lk, heads, d).transpose(1, 2)
+    ref = F.scaled_dot_product_attention(qh, kh, vh).transpose(1, 2).reshape(B, Lq, Cc)
+    assert_close(o, ref, f"shared keys d={d}", rtol=3e-3, atol_rel=3e-3)
+
+
 @pytest.mark.parametrize("name,B,heads,Lq,Lk,fused,late_spike", [
     ("level0", 2, 8, 1024, 1024, True, False),
     ("ragged_tails", 2, 8, 300, 333, False, False),

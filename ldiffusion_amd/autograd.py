@@ -363,10 +363,11 @@ class InfoNceFn(torch.autograd.Function):
             # eager use: the indices address global reads and atomic scatters; the torch gather this replaces raised on a bad index
             # (triples sampled at another resolution than the feature map).  The capacity-sized graph path validates on the host
             # before the upload (train.GraphedStep.set_batch): no device read-back inside a replayed step.
-            hi = max(int(ai.max()), int(pi.max()), int(ni.max()))
-            lo = min(int(ai.min()), int(pi.min()), int(ni.min()))
-            if lo < 0 or hi >= H * W or int(bi.min()) < 0 or int(bi.max()) >= B:
-                raise IndexError(f"InfoNceFn: sample indices out of range for features [B={B}, {H}x{W}] (pixel {lo}..{hi}, image {int(bi.min())}..{int(bi.max())})")
+            # ONE device reduction and ONE read-back for the four bounds (was eight host syncs per step)
+            px = torch.cat([ai.reshape(-1), pi.reshape(-1), ni.reshape(-1)]).long()
+            lo, hi, blo, bhi = torch.stack([px.min(), px.max(), bi.min().long(), bi.max().long()]).tolist()
+            if lo < 0 or hi >= H * W or blo < 0 or bhi >= B:
+                raise IndexError(f"InfoNceFn: sample indices out of range for features [B={B}, {H}x{W}] (pixel {lo}..{hi}, image {blo}..{bhi})")
         loss = torch.empty(1, dtype=torch.float32, device=f.device)
         df = torch.empty_like(f)
         _lib.check(_lib.load().ldiff_op_infonce(f.data_ptr(), B, n, H * W, bi.data_ptr(), ai.data_ptr(), pi.data_ptr(), ni.data_ptr(), T,

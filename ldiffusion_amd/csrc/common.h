@@ -92,7 +92,8 @@ struct ConvParams {
   int lo8_slab0 = 0, lo8_sb = 0;
   const int* lo8_sa = nullptr;
 };
-constexpr int LO8_SHIFT = 15;   // lo = x - fp16(x) of a GroupNorm + SiLU output (|x| < 64: |lo| <= 2^-6) times 2^15 stays inside e4m3's 448; beyond, it saturates
+constexpr int LO8_SHIFT = 15;   // lo = x - fp16(x) of a GroupNorm + SiLU output: |lo| <= half an fp16 ulp = 2^-7 for |x| < 32, so lo * 2^15 <= 256 stays inside e4m3's 448;
+                                // for |x| in [32, 64) it reaches 512 and saturates at 448 (the correction term is clamped, harmless), as for everything beyond
 // [Nrows][taps][Cin] fp16 -> [Nrows][taps][Cin fp16 | Cin e4m3 of w * 2^sw], sw = floor(log2(448 / max |w|)); scale_out[0] = 127 - sw (one int)
 void launch_lo8_weights(const f16* w, void* wd, int* scale_out, int Nrows, int taps, int Cin, hipStream_t s);
 void launch_igemm(const ConvParams& p, hipStream_t s);   // dispatches to the halo-tile 3x3 kernel when eligible

@@ -867,8 +867,11 @@ static void launch_attn_d512(const AttnParams& p, hipStream_t s) {
 // cycles and is bound by them.  This one keeps the same tiling (128 queries per workgroup, 64-key tiles, S^T = K Q^T, P in registers) and
 //   * fixes every query's softmax reference after the first key tile (its maximum + 4 binades, as attn_d512_kernel): no max chain, no lane
 //     swaps, no alpha, no rescale in the loop.  The row sums come out of the P V MFMAs (V^T row 40 = 1: the lanes that hold channel 40 of a
-//     V^T fragment substitute 1.0), so a probability that overflowed fp16 makes its row sum inf: the end of the pass checks the sums, and the
-//     (rare) workgroup that failed takes the true row maxima in a scores-only pass and repeats with those;
+//     V^T fragment substitute 1.0).  v_cvt_pkrtz CLAMPS an overflowing probability to the largest finite fp16 (round toward zero never
+//     produces inf), so one clamped probability puts >= 65504 into its fp32 row sum: the end of the pass takes "row sum >= 65504" (or not
+//     finite: exp2 itself overflowed) as the overflow signal -- conservative (a row whose in-window probabilities add up to that much also
+//     repeats; both cases need > 2^20 times the weight of the first tile's best key in later tiles) -- and the (rare) workgroup that saw it
+//     takes the true row maxima in a scores-only pass and repeats with those;
 //   * packs P with v_cvt_pkrtz_f16_f32 (one instruction per two scores; numerator and row sum see the same rounded P);
 //   * brings K / V in by LDS-DMA, double-buffered, ONE raw barrier per tile (zero padding of the 128-byte K rows and the channel-40..47 chunk of
 //     V by the out-of-range sentinel), operand reads issued in batches with counted waits.
@@ -1047,10 +1050,10 @@ __global__ __launch_bounds__(256, 2) void attn_fr40_kernel(const AttnParams p) {
     for (int kv0 = 0; kv0 < full; kv0 += FR_BKV, buf ^= 1) tile(kv0, buf, std::false_type());
     if (full < p.Lk) tile(full, buf, std::true_type());
 
-    // ---- every row sum finite?  (row 40 of O^T: lane g = 2, register 0 of d tile 2) ----
+    // ---- no probability left fp16's range?  (row 40 of O^T: lane g = 2, register 0 of d tile 2; a clamped P alone contributes 65504) ----
     bool bad = false;
 #pragma unroll
-    for (int qt = 0; qt < QT; ++qt) bad |= g == 2 && !(oacc[qt][2][0] < 3.0e38f);
+    for (int qt = 0; qt < QT; ++qt) bad |= g == 2 && !(oacc[qt][2][0] < 65504.0f);
     const float flag = __builtin_amdgcn_ballot_w64(bad) != 0 ? 1.0f : 0.0f;
     __builtin_amdgcn_s_barrier();   // (all K / V reads of the pass are done)
     if (lane == 0) d5_lds_write32(lds0 + FR_FL + (unsigned)(wave * 4), flag);

@@ -86,7 +86,9 @@ def pixel_latent_vector(pipeline, vae=None, unet=None, num_inference_steps=5, tr
         if not images:
             return
         x = torch.cat(images, 0).to(dev, dtype=torch.float32)
-        feats = s.sample(x, text_embeddings.to(dev), num_inference_steps, want_features=True, want_rgb=False)["features"].cpu()
+        out = s.sample(x, text_embeddings.to(dev), num_inference_steps, want_features=True, want_rgb=False)
+        s.join()   # a caller's sampler in overlap mode 2 defers the side-stream join: the decodes must have written every plane before the copy
+        feats = out["features"].cpu()
         for b in range(x.shape[0]):
             lab = labels[b]
             lab = lab[0] if lab.dim() == 3 else lab                     # label[0] of the batch, then its channel 0 (`pixel_values[0][i, j]`, :88,93)

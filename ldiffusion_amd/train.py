@@ -381,11 +381,15 @@ LOSS_SCALE = 1024.0   # initial loss scale of the backward pass: activation grad
                       # ldiffusion.py:172 `fp16.enabled: False`); unscaled, 0.5 % of the non-negligible parameter-gradient entries underflow to zero
 
 
+LOSS_SCALE_GROWTH_INTERVAL = 200   # consecutive finite steps before a lowered loss scale doubles again (never above LOSS_SCALE)
+
+
 def finish_step(params, opt_state, lr, weight_decay, max_grad_norm, optimizer=None, update=None):
     """What follows the backward pass on every rank: gradient exchange -> global norm -> (clipping) -> AdamW.  The norm is taken AFTER the
     exchange, so all ranks see the same value and take the same branch: a non-finite norm (a float16 activation gradient overflowed under the
     loss scale; the reference trains in fp32 and cannot hit this) skips the update -- parameters, moments and the AdamW step count untouched --
-    and halves `opt_state["loss_scale"]` (dynamic loss scaling; the next step's backward reads it).  Returns True when the update ran.
+    and halves `opt_state["loss_scale"]` (dynamic loss scaling; the next step's backward reads it); LOSS_SCALE_GROWTH_INTERVAL finite steps in a row
+    double a lowered scale again, up to LOSS_SCALE.  Returns True when the update ran.
     `optimizer` = a ShardedAdamW (reduce-scatter / sharded update / all-gather) or None (flattened all-reduce + ag.adamw_step)."""
     if optimizer is not None:
         total = optimizer.step(max_grad_norm)
@@ -395,7 +399,15 @@ def finish_step(params, opt_state, lr, weight_decay, max_grad_norm, optimizer=No
     if not math.isfinite(total):
         opt_state["skipped_steps"] = opt_state.get("skipped_steps", 0) + 1
         opt_state["loss_scale"] = max(1.0, opt_state.get("loss_scale", LOSS_SCALE) * 0.5)
+        opt_state["finite_steps"] = 0
         return False
+    # growth rule of dynamic loss scaling: after LOSS_SCALE_GROWTH_INTERVAL consecutive finite steps the scale doubles, up to the initial
+    # LOSS_SCALE -- one transient overflow must not pin the scale low for the rest of the run (the underflow LOSS_SCALE exists to avoid would
+    # come back).  `total` is the exchanged norm, identical on every rank, so the decision is rank-uniform.
+    opt_state["finite_steps"] = opt_state.get("finite_steps", 0) + 1
+    if opt_state["finite_steps"] >= LOSS_SCALE_GROWTH_INTERVAL and opt_state.get("loss_scale", LOSS_SCALE) < LOSS_SCALE:
+        opt_state["loss_scale"] = min(LOSS_SCALE, opt_state["loss_scale"] * 2.0)
+        opt_state["finite_steps"] = 0
     if optimizer is None:
         (update or ag.adamw_step)(params, [p.grad for p in params], opt_state, lr=lr, weight_decay=weight_decay)
     return True

@@ -301,6 +301,8 @@ def test_attention_long_shared_keys_on_the_fixed_reference_kernels(lib, d, heads
     ("ragged_tails", 2, 8, 300, 333, False, False),
     ("other_head_count", 1, 5, 200, 130, False, False),
     ("repeat_pass", 2, 8, 384, 512, True, True),
+    ("repeat_pass_two_clamped_keys", 2, 8, 384, 512, False, "pair"),
+    ("repeat_pass_exp2_overflow", 1, 8, 256, 320, False, "huge"),
 ])
 def test_attention_d40_fixed_reference(lib, name, B, heads, Lq, Lk, fused, late_spike):
     """attn_fr40_kernel (d = 40, at least two key tiles): fixed softmax reference per query (first key tile's maximum + 4 binades), row sums out of
@@ -313,10 +315,28 @@ def test_attention_d40_fixed_reference(lib, name, B, heads, Lq, Lk, fused, late_
     q = torch.randn((B, Lq, Cc), generator=g)
     k = torch.randn((B, Lk, Cc), generator=g)
     v = torch.randn((B, Lk, Cc), generator=g)
-    if late_spike:
+    scale = 1.0 / math.sqrt(d)
+
+    def key_at(bi, qi, h, binades):
+        """a key along query (bi, qi) of head h whose score lies `binades` above that query's maximum over the first key tile (64 keys)"""
+        qv = r16(q[bi, qi, h * d:(h + 1) * d])
+        m1 = (r16(k[bi, :64, h * d:(h + 1) * d]) @ qv).max().item() * scale          # nats
+        return qv * ((m1 + binades * math.log(2.0)) / scale / (qv @ qv).item())
+
+    if late_spike is True:
         k[0, Lk - 3, 2 * d:3 * d] = 12.0 * q[0, 5, 2 * d:3 * d]        # head 2, query 5 of image 0: score 12 |q|^2 / sqrt(40) ~ 75 nats above the first tile
         k[1, Lk // 2 + 1, :d] = 8.0 * q[1, 290, :d]                    # another workgroup, a middle tile
-    scale = 1.0 / math.sqrt(d)
+    elif late_spike == "pair":
+        # TWO late keys of one row, 30 and 27 binades above the first tile (both beyond fp16 P's window of 16 - 4 lead binades, both far inside
+        # fp32 exp2's range): true weights 8 : 1.  Packed round-toward-zero both clamp to 65504 -- equal weights, a wrong softmax -- unless the
+        # kernel notices the clamp and repeats the pass with the true maximum (ADVICE round 4: the row-sum test must see a clamped P)
+        k[0, Lk - 7, 3 * d:4 * d] = key_at(0, 9, 3, 30.0)
+        k[0, Lk - 70, 3 * d:4 * d] = key_at(0, 9, 3, 27.0)
+        k[1, 200, 6 * d:7 * d] = key_at(1, 300, 6, 17.5)              # just outside the window: one clamped key beside in-window mass
+        k[1, 130, 6 * d:7 * d] = key_at(1, 300, 6, 14.0)
+    elif late_spike == "huge":
+        k[0, Lk - 1, :d] = key_at(0, 100, 0, 140.0)                    # exp2 overflows fp32: the row sum is inf / nan
+        k[0, 90, :d] = key_at(0, 100, 0, 139.0)
     o = torch.full((B, Lq, Cc), float("nan"), dtype=torch.float16, device=DEV)
     if fused:
         L = max(Lq, Lk)
@@ -336,6 +356,9 @@ def test_attention_d40_fixed_reference(lib, name, B, heads, Lq, Lk, fused, late_
     vh = r16(v).view(B, Lk, heads, d).transpose(1, 2)
     ref = F.scaled_dot_product_attention(qh, kh, vh).transpose(1, 2).reshape(B, Lq, Cc)
     assert_close(o, ref, name, rtol=3e-3, atol_rel=3e-3)
+    if late_spike == "pair":   # the case must be able to fail: equal weights on the two clamped keys are far outside the tolerance
+        wrong = 0.5 * (r16(v[0, Lk - 7, 3 * d:4 * d]) + r16(v[0, Lk - 70, 3 * d:4 * d]))
+        assert (wrong - ref[0, 9, 3 * d:4 * d]).abs().max() > 0.1
 
 
 @pytest.mark.parametrize("name,B,Lq,Lk,fused,late_spike", [

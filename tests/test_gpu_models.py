@@ -27,12 +27,44 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
-# "Identical arg-max masks" (north star) is not attainable bit for bit with fp16 MFMA operands: a mask pixel flips where one of its uint8 luma features is
-# one grey level off (6-7 % of the features with the all-fp16 decoder: DESIGN.md section 2) AND the probe's two best classes lie within that feature's
-# weight / 255.  Which pixels those are changes with every re-association of an fp32 sum (another split-K plan, another kernel for the same op): observed
-# over this round's kernel variants on the same inputs: 0-3 of 524,288 pixels at B = 2, 7 / 8 / 11 at the bench's B = 8 configuration.  The tests assert
-# at most MASK_FLIP_BOUND = 32 pixels (6e-5 of the mask) and print the count.
-MASK_FLIP_BOUND = 32
+# "Identical arg-max masks" (north star, segmentor.py:536-541) is not attainable bit for bit with fp16 MFMA operands: any float error moves some uint8
+# rounding boundaries of the luma features (6-7 % of them end one grey level off with the all-fp16 decoder: DESIGN.md section 2).  What IS asserted is
+# the contract that statement leaves: the device mask may differ from the oracle's ONLY at pixels where the oracle itself is within that rounding of a
+# tie -- per differing pixel, the oracle's logit margin between its own class c1 and the device's class c2 is at most what the pixel's feature
+# differences (each asserted <= one grey level) can move it:  lg[c1] - lg[c2] <= sum_n |w[c1,n] - w[c2,n]| * |f_dev[n] - f_ref[n]|
+# (<= sum_n |w[c1,n] - w[c2,n]|, the one-grey-level-on-every-feature bound).  No count threshold: the number of such pixels is printed, not bounded.
+
+
+def assert_mask_flips_within_margin(mask, rmask, ref_features, W, bias, dev_features=None, what=""):
+    """mask / rmask uint8 [B,H,W] (device / oracle); ref_features uint8 [B,N,H,W] (the oracle's); W [C,N] and bias [C] in logit units per RAW grey
+    level (the probe applied to features 0..255).  dev_features (same shape) tightens the bound to the features that really differ; without it the
+    bound is one grey level on every feature (merged / averaged logits).  Returns the number of differing pixels."""
+    mask, rmask = np.asarray(mask), np.asarray(rmask)
+    idx = np.argwhere(mask != rmask)
+    if len(idx) == 0:
+        return 0
+    b, y, x = idx.T
+    W64, b64 = W.double().numpy(), bias.double().numpy()
+    f = np.asarray(ref_features)[b, :, y, x].astype(np.float64)                      # [K, N]
+    lg = f @ W64.T + b64                                                              # oracle logits at the differing pixels, float64
+    k = np.arange(len(idx))
+    c1, c2 = rmask[b, y, x].astype(int), mask[b, y, x].astype(int)
+    margin = lg[k, c1] - lg[k, c2]
+    dW = np.abs(W64[c1] - W64[c2])                                                    # [K, N]
+    if dev_features is not None:
+        df = np.abs(np.asarray(dev_features)[b, :, y, x].astype(np.float64) - f)
+        assert df.max() <= 1
+        bound = (dW * df).sum(1)
+    else:
+        bound = dW.sum(1)
+    slack = 4e-6 * (np.abs(lg).max() + 1.0)                                           # float32 accumulation of the probe on both sides
+    worst = float((margin - bound).max())
+    print(f"  mask contract{' ' + what if what else ''}: {len(idx)} of {mask.size} pixels differ; oracle margin at those pixels <= {margin.max():.4f}, "
+          f"allowed by their feature differences: worst (margin - bound) {worst:.2e}")
+    assert (margin >= -slack).all(), "the oracle's own class is not its arg-max"
+    assert worst <= slack, (f"north star (segmentor.py:536-541): a mask pixel differs from the oracle's where the oracle is NOT within one grey level "
+                            f"of a tie: margin - bound = {worst:.3e}")
+    return len(idx)
 
 
 def rel_err(got, ref):
@@ -336,9 +368,8 @@ def test_config1_sd15_width_512_five_passes_against_oracle():
     print(f"  encoder mean : {err_report(z0_dev, z0_ref)}")
     assert e_enc <= 1e-3 and max(errs) <= 1e-3, "north-star tolerance: latents within 1e-3 of the reference (relative to the latent range)"
     assert fd.max() <= 1
-    # "identical arg-max masks": 0 to 3 of the 524,288 pixels differ from run to run of the kernel set (a uint8 luma one grey level off, 6-7 % of
-    # them with the all-fp16 decoder, moves an arg-max only where two classes of the probe are within that margin); asserted: at most MASK_FLIP_BOUND
-    assert ndiff <= MASK_FLIP_BOUND, f"north star: arg-max masks at configs[1]: {ndiff} pixels differ"
+    # "identical arg-max masks": the masks may differ only where the oracle is within its features' rounding of a tie (the contract at the top of the file)
+    assert assert_mask_flips_within_margin(mask, rmask, ref["features"], W, bias, out["features"].cpu().numpy(), "configs[1] B=2") == ndiff
     # the decoder's storage policy (default 0) does not touch the latents; what modes 1 / 2 would buy in the uint8 features, for the record
     for dmode in (1, 2):
         pipe.vae.set_precision(2, dmode)
@@ -535,6 +566,18 @@ def test_precision_modes_tiny(tiny):
         tiny["unet"].set_precision(3)
 
 
+def _assert_merged_mask_contract(mask, rmask, rmerged, W):
+    """Merged-logit form of the mask contract: rmerged [C,H,W] float64 oracle logits after the Gaussian merge."""
+    ys, xs = np.nonzero(mask != rmask)
+    if len(ys) == 0:
+        return
+    c1, c2 = rmask[ys, xs].astype(int), mask[ys, xs].astype(int)
+    margin = rmerged[c1, ys, xs] - rmerged[c2, ys, xs]
+    bound = np.abs(W.double().numpy()[c1] - W.double().numpy()[c2]).sum(1)
+    print(f"  mask contract (merged logits): {len(ys)} of {mask.size} pixels differ; worst (margin - bound) {(margin - bound).max():.2e}")
+    assert (margin <= bound + 1e-5 * (np.abs(rmerged).max() + 1)).all()
+
+
 def _probe_head(num_classes, n_feat, seed):
     """Deterministic linear probe [classes, passes] + bias on the per-pixel latent vectors (stand-in for the tissue head)."""
     g = torch.Generator().manual_seed(seed)
@@ -576,7 +619,10 @@ def test_config4_tiled_roi_20_passes_6_classes(tiny, step):
     print(f"config4 step={step}: {tiles.shape[0]} tiles x {N} passes; latents rel err {e:.3e}; luma max diff {fd.max()} (>1: {(fd > 1).mean():.4f}); "
           f"mask agreement {agree:.4f}")
     assert mask.shape == (128, 128) and mask.max() < C
-    assert e <= 1e-3 and fd.max() <= 1 and agree > 0.995   # 20 passes of uint8 features: a luma off by one can move an arg-max
+    assert e <= 1e-3 and fd.max() <= 1
+    # 20 passes of uint8 features: a luma off by one can move an arg-max, but only where the oracle's MERGED logits are within one grey level on
+    # every feature of a tie (the Gaussian merge is a convex combination of tile logits, so the per-tile bound carries over)
+    _assert_merged_mask_contract(mask, np.asarray(rmask), rmerged, W)
     if step == 1.0:   # non-overlapping: the merged mask is the tile masks side by side
         tm = argmax_mask(logits)
         assert torch.equal(tiling.merge_tile_masks(tm, origins, (128, 128)).cpu(), torch.from_numpy(mask))
@@ -625,12 +671,13 @@ def test_config3_full_size_roi_1024_four_tiles_20_passes():
     print(f"configs[3] full size: 4 tiles x {N} passes at SD15 width; tile 0 vs oracle: latents rel err {e:.3e}; luma max diff {fd.max()} "
           f"(!=0: {(fd > 0).mean():.4f}); mask agreement {agree:.5f} ({ndiff} of {rmask0.size} pixels differ)")
     print(f"  final latents of tile 0: {err_report(out['latents'][:1], ref['latents'][-1])}")
-    # "Identical arg-max masks" is NOT reached on this config, and the floor asserted here is the measured one: the feature vector of a pixel is
-    # 20 uint8 luma values, each within ONE grey level of the oracle's (asserted above: any float error moves some rounding boundaries; 3-7 % of
-    # the values differ by one), and a linear head over 20 such features changes its arg-max where two classes are within that margin:
-    # 0.16-0.26 % of the pixels on this input.  Storing the decoder's activations with the split residual stream (precision 1 / 2) halves the
-    # off-by-one rate and does not remove it (test_config1 prints the rates), so the sampler keeps the fast decoder.
-    assert mask.shape == (1024, 1024) and e <= 1e-3 and fd.max() <= 1 and agree >= 0.997
+    # "Identical arg-max masks" is NOT reached on this config: the feature vector of a pixel is 20 uint8 luma values, each within ONE grey level of
+    # the oracle's (asserted: any float error moves some rounding boundaries; 3-7 % of the values differ by one), and a linear head over 20 such
+    # features changes its arg-max where two classes are within that margin (0.08-0.26 % of the pixels on this input, printed).  Asserted, per
+    # differing pixel: the oracle's margin there is within what the pixel's own feature differences can move (the contract at the top of the file).
+    assert mask.shape == (1024, 1024) and e <= 1e-3 and fd.max() <= 1
+    assert assert_mask_flips_within_margin(mask[None, :512, :512], rmask0[None], ref["features"], W, bias, out["features"][:1].cpu().numpy(),
+                                           "configs[3] tile 0") == ndiff
 
 
 def test_tiles_are_independent_units(tiny):
@@ -1181,7 +1228,7 @@ def test_config1_b8_bench_mode_against_oracle():
           f"luma max diff {fd.max()} (!=0: {(fd > 0).mean():.4f}); masks: {ndiff} of {rmask.size} pixels differ")
     assert e <= 1e-3, "north-star tolerance: latents within 1e-3 of the reference (relative to the latent range)"
     assert fd.max() <= 1
-    assert ndiff <= MASK_FLIP_BOUND, f"north star: arg-max masks at configs[1], bench mode: {ndiff} pixels differ"
+    assert assert_mask_flips_within_margin(mask[sel], rmask, ref["features"], W, bias, outs[-1]["features"][sel].cpu().numpy(), "configs[1] bench mode") == ndiff
 
 
 @pytest.mark.timeout(2400)

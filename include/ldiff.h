@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define LDIFF_VERSION 142 /* 0.1.4.2: + fp8 lo halves (ldiff_op_norm_apply_lo8, ldiff_op_lo8_weights, ldiff_conv_args.lo8_*), CU-share streams */
+#define LDIFF_VERSION 150 /* 0.1.5.0: + dataflow GEMM (ldiff_conv_args.gemm_df) */
 #define LDIFF_MAX_BLOCKS 8
 
 typedef enum { LDIFF_OK = 0, LDIFF_ERR_INVALID = -1, LDIFF_ERR_RUNTIME = -2, LDIFF_ERR_STATE = -3 } ldiff_status;
@@ -216,6 +216,9 @@ typedef struct {
                                                        bytes, C1 = 3C/2, lo8_slab0 = C/64, w built by ldiff_op_lo8_weights; 3x3 stride 1, C % 128 == 0, N % 128 == 0,
                                                        split output with statistics, maps that fill the chip with 16 x 16 tiles; anything else: LDIFF_ERR_INVALID */
   const void* lo8_scale;                            /* the int ldiff_op_lo8_weights wrote (device memory) */
+  int gemm_df;                                      /* 1x1 / linear only, producer / consumer ("dataflow") GEMM: 0 = where the executors would pick it (unit list
+                                                       fills the chip), -1 = never, 1 = always where the shape is eligible (LDIFF_ERR_INVALID otherwise), 16 mt + ntw
+                                                       (mt 4 | 8, ntw 2 | 4 | 5) = always, with units of 16 mt rows x 64 ntw columns (tests, timing) */
 } ldiff_conv_args;
 int ldiff_op_conv(const ldiff_conv_args*, void* stream);
 /* row blocks per image the launch would emit statistics for (0 = unsupported for this shape) */

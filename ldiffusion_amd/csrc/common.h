@@ -84,13 +84,14 @@ struct ConvParams {
   float* post_img = nullptr; uint8_t* post_rgb = nullptr; uint8_t* post_luma = nullptr; int post_slots = 0, post_slot = 0, post_only = 0;   // post_only: y is not written
   int short_runs = 0;   // set by the executor of a graph that shares the chip with another stream (the VAE decoder beside the UNet): persistent kernels cap their run length
   unsigned div_tm; int tiles_m, img_fast;   // conv3x3 halo-tile kernels, set by their launchers: pixel tiles of the launch; tile order (see conv3x3_img_fast)
-  const f16* w_frag;      // conv3x3 dataflow kernel only (conv3x3d_selected): the weights fragment-packed by launch_pack_frag_weights
+  const f16* w_frag;      // dataflow kernels only: the weights fragment-packed by launch_pack_frag_weights (conv3x3d_selected) / launch_pack_gemm_frag (gemm_df_selected)
   // Split operand with an fp8 lo half (16 x 16 ping-pong kernel only, conv3x3p_selected): a row of x is [C fp16 hi | C e4m3 lo * 2^LO8_SHIFT] = 3C bytes,
   // a row of w per tap [C fp16 | C e4m3 of w * 2^sw] (launch_lo8_weights); in 128-byte slabs: C / 64 fp16 slabs, then C / 128 fp8 slabs, so
   // C1 = 3C / 2 "elements" and K = taps * 3C / 2.  lo8_slab0 = C / 64 (first fp8 slab; 0 = no such operand), lo8_sa -> the E8M0 scale operand
   // 127 - sw written by launch_lo8_weights, lo8_sb = 127 - LO8_SHIFT.  The fp8 slabs go through v_mfma_scale_f32_16x16x128_f8f6f4.
   int lo8_slab0 = 0, lo8_sb = 0;
   const int* lo8_sa = nullptr;
+  int df_force = 0;   // dataflow GEMM (gemm_df_selected): 0 = by the unit list, -1 = never, 1 = wherever eligible, 16 mt + ntw = with that unit shape (ldiff_conv_args.gemm_df)
 };
 constexpr int LO8_SHIFT = 15;   // lo = x - fp16(x) of a GroupNorm + SiLU output: |lo| <= half an fp16 ulp = 2^-7 for |x| < 32, so lo * 2^15 <= 256 stays inside e4m3's 448;
                                 // for |x| in [32, 64) it reaches 512 and saturates at 448 (the correction term is clamped, harmless), as for everything beyond
@@ -124,6 +125,11 @@ void launch_lngemm_tile_weights(const f16* w, f16* wt, int N, int C, hipStream_t
 void launch_lngemm(const f16* x, int ldx, int x_lo, int M, int C, const float* gamma, const float* beta, float eps, const f16* w_tiled, int N,
                    const float* bias, bool geglu, f16* y, int ldy, hipStream_t s, int qcols = 0, float qscale = 1.0f);   // columns [0, qcols) *= qscale before rounding
 bool gemm_dma_eligible(const ConvParams& p);
+// producer / consumer ("dataflow") GEMM for 1x1 convs / linears whose unit list fills the chip: kernels_gemm_df.hip
+bool gemm_df_selected(const ConvParams& p);
+size_t gemm_df_frag_bytes(const ConvParams& p);
+void launch_pack_gemm_frag(const f16* w, f16* wf, int Nrows, int K, hipStream_t s);   // [Nrows][K] K-major -> MFMA A fragments, one KiB each
+void launch_gemm_df(const ConvParams& p, hipStream_t s);   // needs ConvParams::w_frag
 void launch_gemm_dma(const ConvParams& p, hipStream_t s);      // kernels_gemm.hip
 
 // ---- attention (kernels_attn.hip) ------------------------------------------------------------

@@ -333,7 +333,11 @@ void launch_igemm(const ConvParams& p, hipStream_t s) {
   LDIFF_CHECK(!p.temb || p.ld_temb % 4 == 0, LDIFF_ERR_INVALID, "igemm: ld_temb must be a multiple of 4");
   if (p.M <= 0) return;
   if (conv3x3_eligible(p)) { launch_conv3x3(p, s); return; }
-  if (gemm_dma_eligible(p)) { launch_gemm_dma(p, s); return; }
+  if (gemm_dma_eligible(p)) {
+    if (p.w_frag && gemm_df_selected(p)) launch_gemm_df(p, s);   // the caller packed the weights for the dataflow kernel
+    else launch_gemm_dma(p, s);
+    return;
+  }
   LDIFF_CHECK(!p.geglu, LDIFF_ERR_INVALID, "GEGLU epilogue: only on 1x1 / linear layers with K %% 64 == 0, N %% 32 == 0, fp16 output, no residual");
   const bool fast = (Cin % BK == 0) && (p.C1 % BK == 0);
   // Tile choice: largest tile that still yields >= ~2 workgroups per CU worth of tiles; narrow N gets BN=64.

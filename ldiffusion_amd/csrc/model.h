@@ -43,6 +43,8 @@ struct MatW {   // [Nrows][K] fp16 K-major + fp32 bias
   mutable Derived dup;            //   split operand: [Nrows][taps][2*Cin] (same weights against the hi and the lo half); key = C1 of a concat
   mutable Derived dup_par;        //   parity weights of the duplicated matrix
   mutable Derived frag;           //   MFMA-fragment-packed copy for the dataflow conv3x3 kernel (kernels_conv3x3d.hip)
+  mutable Derived gfrag;          //   MFMA-fragment-packed copy for the dataflow GEMM (kernels_gemm_df.hip)
+  mutable Derived gfrag_dup;      //   the same of the duplicated (split-operand) matrix; key = C1 of a concat
   mutable Derived tiled;          //   panel-tiled copy for the LayerNorm-fused GEMM (kernels_gemm_ast.hip)
   mutable Derived lo8;            //   split operand with an fp8 lo half: [Nrows][taps][Cin fp16 | Cin e4m3] + one int (the E8M0 scale operand) behind it
 };
@@ -119,6 +121,7 @@ class Exec {
   const f16* derived_par(const MatW& w, const f16* src, int Cin, Derived& d);
   const f16* derived_frag(const MatW& w, const ConvParams& p);
   const f16* derived_tiled(const MatW& w, int N);
+  const f16* derived_gfrag(const MatW& w, const f16* src, int K, Derived& d, int key);   // fragment-packed copy of `src` [Nrows][K] for the dataflow GEMM
   const f16* derived_lo8(const MatW& w, const int** scale);   // fp8-lo weights of a split operand + the device int holding their E8M0 scale operand
   bool lo8_conv_ok(const MatW& w, const Act& x, bool res, bool split_out) const;   // would conv(w, norm_apply(x) with an fp8 lo half) run on the ping-pong kernel?
   Act norm_apply(const Act& x, const Act* x2, const GNss& g, bool silu, bool split_out, bool lo8 = false);

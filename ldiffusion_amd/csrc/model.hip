@@ -337,6 +337,20 @@ const f16* Exec::derived_tiled(const MatW& w, int N) {
   }
   return w.tiled.p;
 }
+const f16* Exec::derived_gfrag(const MatW& w, const f16* src, int K, Derived& d, int key) {
+  const int gen = weights_gen ? *weights_gen : 0;
+  if (!d.p) {
+    void* q = nullptr;
+    HIP_CHECK(hipMalloc(&q, (size_t)w.Nrows * K * sizeof(f16)));
+    owned.push_back(q);
+    d.p = (f16*)q;
+  }
+  if (d.gen != gen || d.key != key) {   // first use, the checkpoint was reloaded since, or the duplicated source was rebuilt for another concat split
+    launch_pack_gemm_frag(src, d.p, w.Nrows, K, s);
+    d.gen = gen; d.key = key;
+  }
+  return d.p;
+}
 const f16* Exec::derived_par(const MatW& w, const f16* src, int Cin, Derived& d) {
   const int gen = weights_gen ? *weights_gen : 0;
   if (!d.p) {
@@ -447,6 +461,8 @@ Act Exec::conv(const MatW& w, const Act& x, const Act* x2, const ConvOpts& o) {
   else p.splitk = 0;
   p.short_runs = short_runs ? 1 : 0;
   if (!o.split_in && conv3x3_eligible(p) && conv3x3d_selected(p)) p.w_frag = derived_frag(w, p);   // dataflow kernel: MFMA-fragment-packed weights
+  else if (!wfold && w.ks == 1 && !(o.split_in && x.lo8) && !conv3x3_eligible(p) && gemm_df_selected(p))   // dataflow GEMM: the same, of the matrix this launch reads
+    p.w_frag = derived_gfrag(w, wsrc, p.K, o.split_in ? w.gfrag_dup : w.gfrag, o.split_in ? x.C : 0);
   launch_igemm(p, s);
   if (p.splitk_ws) arena.free(p.splitk_ws);   // stream-ordered reuse: safe once the launches are enqueued
   if (wfold) { arena.free(bfold); arena.free(wfold); }

@@ -612,6 +612,129 @@ def test_linear_with_fused_geglu_epilogue(lib, M, Cc, inner):
 
 
 # ======================================================================================================================
+# Producer / consumer ("dataflow") GEMM (kernels_gemm_df.hip), forced through ldiff_conv_args.gemm_df = 16 mt + ntw
+# ======================================================================================================================
+GEMM_DF_CASES = {
+    # name: (M, K1, K2, N, epilogue, plan 16 mt + ntw or 1 = the launcher's own plan)
+    "plain_one_unit_per_workgroup": (2048, 320, 0, 320, "plain", 16 * 8 + 5),
+    "plain_bn128_tail_columns": (1024, 320, 0, 320, "plain", 16 * 8 + 2),            # N = 2.5 units of 128 columns
+    "plain_runs_of_units": (300 * 128, 64, 0, 640, "plain", 16 * 8 + 5),              # 600 units on <= 256 workgroups: runs of 2-3 units, K = one step
+    "plain_tail_rows": (1000, 128, 0, 256, "plain", 16 * 8 + 4),                      # M = 7.8 row blocks
+    "plain_mt4": (520, 192, 0, 384, "plain", 16 * 4 + 2),
+    "plain_mt4_ntw5": (8192, 640, 0, 640, "plain", 16 * 4 + 5),
+    "plain_mt4_ntw4_no_bias": (4096, 1280, 0, 1280, "plain_nobias", 16 * 4 + 4),
+    "res_plain": (4096, 320, 0, 320, "res", 16 * 8 + 5),
+    "split_out": (4096, 640, 0, 320, "split_out", 16 * 8 + 5),
+    "split_res_split_out": (8192, 320, 0, 320, "split_res_out", 16 * 8 + 5),
+    "split_res_split_out_long_k": (4096, 1280, 0, 320, "split_res_out", 16 * 8 + 2),
+    "split_res_split_out_mt4_tails": (1000, 256, 0, 200, "split_res_out", 16 * 4 + 2),
+    "split_res_plain_out": (2048, 320, 0, 640, "split_res", 16 * 8 + 4),
+    "concat_two_sources": (2048, 128, 64, 320, "split_out", 16 * 8 + 5),              # the 1x1 shortcut over [x | skip]
+    "concat_two_sources_pitch": (2048, 192, 320, 256, "plain", 16 * 8 + 2),
+    "geglu": (4096, 320, 0, 2560, "geglu", 16 * 8 + 5),
+    "geglu_bn128_tail_rows": (1000, 128, 0, 768, "geglu", 16 * 8 + 2),
+    "geglu_mt4_ntw4": (2048, 640, 0, 5120, "geglu", 16 * 4 + 4),
+    "auto_plan_level1_ff2": (8192, 2560, 0, 640, "split_res_out", 1),
+    "auto_plan_level2_qkv": (2048, 1280, 0, 3840, "plain_nobias", 1),
+}
+
+
+@pytest.mark.parametrize("name", list(GEMM_DF_CASES))
+def test_gemm_dataflow(lib, name):
+    """gemm_df_kernel against a float64 GEMM on the operands the kernel sees: every epilogue (bias, plain / split residual, plain / split output, GEGLU),
+    every unit shape, ragged rows and columns, two concat sources, runs of several units per workgroup.  Plain outputs: one fp16 rounding of the fp32
+    result; split outputs: hi + lo to fp32 round-off."""
+    M, K1, K2, N, epi, plan = GEMM_DF_CASES[name]
+    g = torch.Generator().manual_seed(zlib.crc32(name.encode()) % 1000)
+    K = K1 + K2
+    geglu = epi == "geglu"
+    x1 = torch.randn((M, K1), generator=g)
+    x2 = torch.randn((M, K2), generator=g) if K2 else None
+    w = r16(torch.randn((N, K), generator=g) / math.sqrt(K))
+    bias = None if epi == "plain_nobias" else torch.randn(N, generator=g) * 0.3
+    Nrows = (N + 15) // 16 * 16
+    a_ = _lib.ConvArgs()
+    keep = []
+    if name == "concat_two_sources_pitch":      # rows with a pitch: the hi halves of split tensors
+        x1d, x2d = to_split(x1).to(DEV), to_split(x2).to(DEV)
+        a_.ld1, a_.ld2 = 2 * K1, 2 * K2
+    else:
+        x1d, x2d = x1.to(torch.float16).to(DEV), (x2.to(torch.float16).to(DEV) if K2 else None)
+    a_.x, a_.C1, a_.C2 = x1d.data_ptr(), K1, K2
+    if K2:
+        a_.x2 = x2d.data_ptr()
+    A = torch.cat([r16(x1)] + ([r16(x2)] if K2 else []), 1).double()
+    if geglu:
+        inner = N // 2
+        perm = torch.empty(N, dtype=torch.long)
+        for r in range(N):
+            q = r if r < inner else r - inner
+            perm[(q // 16) * 32 + (0 if r < inner else 16) + q % 16] = r
+        wdev, bdev = w[perm], bias[perm]
+    else:
+        wdev, bdev = w, bias
+    wd = torch.zeros((Nrows, K), dtype=torch.float16); wd[:N] = wdev.to(torch.float16); wd = wd.to(DEV)
+    a_.w, a_.N, a_.Nrows = wd.data_ptr(), N, Nrows
+    if bdev is not None:
+        bd = torch.zeros(Nrows); bd[:N] = bdev; bd = bd.to(DEV); keep.append(bd)
+        a_.bias = bd.data_ptr()
+    a_.B, a_.Hin, a_.Win, a_.Hout, a_.Wout, a_.ks, a_.stride = 1, 1, M, 1, M, 1, 1
+    ref = A @ w.double().t() + (bias.double() if bias is not None else 0.0)
+    split_out = epi in ("split_out", "split_res_out")
+    Nout = N // 2 if geglu else N
+    if geglu:
+        ref = ref[:, :Nout] * F.gelu(ref[:, Nout:])
+    if epi in ("res", "split_res", "split_res_out"):
+        res = torch.randn((M, N), generator=g) * 3.0
+        if epi == "res":
+            rd = res.to(torch.float16).to(DEV)
+            a_.res, a_.ld_res = rd.data_ptr(), N
+            ref = ref + r16(res).double()
+        else:
+            rs = to_split(res); rd = rs.to(DEV)
+            a_.res, a_.ld_res, a_.res_lo = rd.data_ptr(), 2 * N, N
+            ref = ref + from_split(rs, N).double()
+        keep.append(rd)
+    y = torch.full((M, 2 * Nout if split_out else Nout), float("nan"), dtype=torch.float16, device=DEV)
+    a_.y, a_.ldy, a_.y_lo, a_.geglu = y.data_ptr(), y.shape[1], Nout if split_out else 0, int(geglu)
+    a_.gemm_df = plan
+    _lib.check(lib.ldiff_op_conv(C.byref(a_), sp()))
+    torch.cuda.synchronize()
+    yc = y.cpu()
+    assert torch.isfinite(yc.float()).all(), "unwritten or non-finite outputs"
+    if split_out:
+        got = from_split(yc, Nout).double()
+        err = (got - ref).abs().max().item() / ref.abs().max().item()
+        print(f"{name}: split output rel err {err:.2e}")
+        assert err <= 1e-5
+    else:
+        assert_close(yc.float(), ref.float(), name)
+    # the same launch on the LDS-DMA GEMM (gemm_df = -1): the two kernels must agree to their accumulation order
+    y2 = torch.full_like(y, float("nan"))
+    a_.y, a_.gemm_df = y2.data_ptr(), -1
+    _lib.check(lib.ldiff_op_conv(C.byref(a_), sp()))
+    torch.cuda.synchronize()
+    d = (y2.float() - y.float()).abs().max().item() if not split_out else (from_split(y2.cpu(), Nout) - from_split(yc, Nout)).abs().max().item()
+    assert d <= 2e-3 * max(1.0, ref.abs().max().item())
+
+
+def test_gemm_dataflow_rejects_what_it_does_not_take(lib):
+    a_ = _lib.ConvArgs()
+    x = torch.zeros((256, 96), dtype=torch.float16, device=DEV)
+    w = torch.zeros((64, 96), dtype=torch.float16, device=DEV)
+    y = torch.zeros((256, 64), dtype=torch.float16, device=DEV)
+    a_.x, a_.C1, a_.B, a_.Hin, a_.Win, a_.Hout, a_.Wout, a_.ks, a_.stride = x.data_ptr(), 96, 1, 1, 256, 1, 256, 1, 1
+    a_.w, a_.N, a_.Nrows, a_.y, a_.ldy, a_.gemm_df = w.data_ptr(), 64, 64, y.data_ptr(), 64, 1
+    with pytest.raises(ValueError):      # K % 64 != 0
+        _lib.check(lib.ldiff_op_conv(C.byref(a_), sp()))
+    x = torch.zeros((256, 128), dtype=torch.float16, device=DEV)
+    w = torch.zeros((64, 128), dtype=torch.float16, device=DEV)
+    a_.x, a_.C1, a_.w, a_.gemm_df = x.data_ptr(), 128, w.data_ptr(), 16 * 8 + 3
+    with pytest.raises(ValueError):      # a unit shape that is not built
+        _lib.check(lib.ldiff_op_conv(C.byref(a_), sp()))
+
+
+# ======================================================================================================================
 # Split tensors (fp16 hi | lo per row, value = hi + lo): the residual stream of the UNet / VAE (DESIGN.md section 3)
 # ======================================================================================================================
 def to_split(x_nhwc):

@@ -450,6 +450,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3d_kernel(const ConvParams p, co
   const unsigned cflag_addr = lane == 0 ? lds0 + D_FLAGS + 16u + (unsigned)wave * 4u : lds0 + D_DUMP + (unsigned)wave * 256u + (unsigned)lane * 4u;
   // fragment-packed weights: [tap][slab][channel tile of 128][wave_n][a][k-half][lane][16 B]: a step's eight fragments of this wave are 8 KiB in a row
   const char* wfrag = reinterpret_cast<const char*>(p.w_frag) + wave_n * 8192 + lane * 16;
+#ifdef C3D_ABL_NOW
+  bool abl_w_loaded[2] = {false, false};
+#endif
   const long long w_step_bytes = (long long)ntn * 16384;   // from slab c to slab c + 1 of a tap; a tap is nslab of these
 
 #ifdef C3D_STAMPS
@@ -471,6 +474,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3d_kernel(const ConvParams p, co
   };
   auto issue_w = [&](auto khc, const char* wq) __attribute__((always_inline)) {   // the four channel tiles of k-half kh of the step at wq
     constexpr int kh = decltype(khc)::value;
+#ifdef C3D_ABL_NOW   // ablation (timing only, results wrong): each k-half's weight fragments are loaded ONCE
+    if (abl_w_loaded[kh]) return;
+    abl_w_loaded[kh] = true;
+#endif
     glb_read128<kh * 1024>(Wf[kh][0], wq);          // (the instruction offset is 13 bits signed: channel tiles 2, 3 through a second base)
     glb_read128<2048 + kh * 1024>(Wf[kh][1], wq);
     glb_read128<kh * 1024>(Wf[kh][2], wq + 4096);

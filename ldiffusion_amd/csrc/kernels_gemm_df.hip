@@ -15,9 +15,9 @@
 //     16 MT rows x 64 k, the swizzled image of kernels_gemm.hip), rows in groups of four one group ahead, counted lgkmcnt.  At the end of a unit
 //     a consumer writes its fp32 sums to LDS in 64-column slices and goes on with the next unit.
 //   * waves 4 .. 4+NLOAD-1: LOADERS.  Free-running LDS-DMA of the activation slots, up to F_S - 1 steps ahead across unit boundaries (counted
-//     vmcnt; nothing asynchronous targets a VGPR), plus the bias slice of each unit into a small table the consumers start their sums from.
-//   * the remaining waves: EPILOGUE.  Plain compiled code (loads, waits and stores are the compiler's): take a slice from LDS, add the residual
-//     (fp16 hi + lo in fp32), round once, write y (plain, or split hi | lo) as full 128-byte lines.  Runs beside the next unit's MFMAs.
+//     vmcnt; nothing asynchronous targets a VGPR).
+//   * the remaining waves: EPILOGUE.  Plain compiled code (loads, waits and stores are the compiler's): take a slice from LDS, add the bias, then the
+//     residual (fp16 hi, then lo, in fp32: gemm_dma_kernel's order, the two kernels agree bit for bit), round once, write y (plain, or split hi | lo) as full 128-byte lines.  Runs beside the next unit's MFMAs.
 //   * progress words in LDS (one per wave, as in conv3x3d_kernel): loaders "steps landed", consumers "steps whose fragments are in registers"
 //     and "slices staged", epilogue waves "slices taken".
 // A workgroup walks a contiguous run of units (column unit fastest, XCD-aware: the runs of one XCD's workgroups are adjacent).
@@ -58,8 +58,7 @@ constexpr unsigned F_SLOT = 128 * 128;                   // one slot: up to 128 
 constexpr unsigned F_HP = 272;                           // hand-off slice: row pitch (64 fp32 + 16 B: conflict-free on both sides)
 constexpr unsigned F_HS = 128 * F_HP;                    // one slice buffer
 constexpr unsigned F_HAND = F_S * F_SLOT;                // the slice buffers
-constexpr unsigned F_BT = F_HAND + F_NH * F_HS;          // bias table: [unit parity 2][320 floats]
-constexpr unsigned F_FLAGS = F_BT + 2 * 1280;            // [loader steps x4][consumer steps x4][consumer slices x4][epilogue slices x4]
+constexpr unsigned F_FLAGS = F_HAND + F_NH * F_HS;       // [loader steps x4][consumer steps x4][consumer slices x4][epilogue slices x4]
 constexpr unsigned F_DUMP = F_FLAGS + 64;                // 8 waves x 256 B: where the lanes other than 0 put their copy of a progress word
 constexpr unsigned F_LDS = F_DUMP + 8 * 256;
 static_assert(F_LDS <= 160 * 1024, "LDS budget of one workgroup per CU");
@@ -168,7 +167,6 @@ __global__ __launch_bounds__(512, 2) void gemm_df_kernel(const ConvParams p, con
     const int pitch1 = p.ld1 ? p.ld1 : p.C1, pitch2 = p.ld2 ? p.ld2 : p.C2;
     const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)((long long)p.M * pitch1 * 2), 0x00020000);
     const __amdgpu_buffer_rsrc_t rs2 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x2 ? p.x2 : p.x), 0, (int)((long long)p.M * (p.x2 ? pitch2 : pitch1) * 2), 0x00020000);
-    const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc((void*)(p.bias ? p.bias : (const float*)p.x), 0, p.bias ? p.Nrows * 4 : 0, 0x00020000);
     const int kt2 = p.C1 >> 6;   // first K step of the second concat source
     const unsigned pflag_addr = lane == 0 ? pflags + (unsigned)lw * 4u : dump;
     int a_sw[NPMAX], a_row[NPMAX];
@@ -194,17 +192,7 @@ __global__ __launch_bounds__(512, 2) void gemm_df_kernel(const ConvParams p, con
       }
     };
     auto issue = [&]() __attribute__((always_inline)) {
-      if (ikt == 0) {
-        set_unit();
-        if (lw == 0) {   // the unit's bias slice (no bias: zero records, the DMA writes zeros), in front of the step's pieces
-          unsigned char* dst = smem_raw + F_BT + (unsigned)(iu & 1) * 1280u;
-          const int c0 = in0 + lane * 4, c1 = in0 + 256 + lane * 4;
-#if defined(__HIP_DEVICE_COMPILE__)   // the host pass rejects this builtin (target feature) and then silently drops the kernel stub
-          if (lane < (NTW < 4 ? NTW * 16 : 64)) __builtin_amdgcn_raw_ptr_buffer_load_lds(brs, (lptr_t*)dst, 16, c0 < p.Nrows ? c0 * 4 : (int)F_OOR, 0, 0, 0);
-          if constexpr (NTW > 4) { if (lane < NTW * 16 - 64) __builtin_amdgcn_raw_ptr_buffer_load_lds(brs, (lptr_t*)(dst + 1024), 16, c1 < p.Nrows ? c1 * 4 : (int)F_OOR, 0, 0, 0); }
-#endif
-        }
-      }
+      if (ikt == 0) set_unit();
       const bool second = ikt >= kt2;
       const int soff = (second ? ikt - kt2 : ikt) * 128;
       unsigned char* dst = smem_raw + (unsigned)(issued % F_S) * F_SLOT + (unsigned)first * 1024u;
@@ -254,6 +242,7 @@ __global__ __launch_bounds__(512, 2) void gemm_df_kernel(const ConvParams p, con
     const unsigned dflag_addr = lane == 0 ? dflags + (unsigned)ew * 4u : dump;
     const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, (int)((long long)p.M * p.ldy * 2), 0x00020000);
     const __amdgpu_buffer_rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc((void*)(p.res ? p.res : (const f16*)p.y), 0, (int)((long long)p.M * (p.res ? p.ld_res : p.ldy) * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc((void*)(p.bias ? p.bias : (const float*)p.y), 0, p.bias ? p.Nrows * 4 : 0, 0x00020000);   // no bias: zero records, loads return 0
     // a wave-instruction takes ROWS_I rows of the slice: 8 rows x 8 octets (a 64-column slice row = one 128-byte line of y), or, GEGLU, 16 rows x 4
     // octets (a slice carries 32 x | 32 gate columns = 32 outputs).  Row groups are dealt round-robin over the epilogue waves.
     constexpr int ROWS_I = GEGLU ? 16 : 8, NG = BM / ROWS_I, NIT = (NG + NEPI - 1) / NEPI;
@@ -270,6 +259,17 @@ __global__ __launch_bounds__(512, 2) void gemm_df_kernel(const ConvParams p, con
         const unsigned hb = lds0 + F_HAND + (unsigned)(sidx % F_NH) * F_HS;
         const int ncol = GEGLU ? n0 / 2 + a * 32 + o * 8 : n0 + a * 64 + o * 8;        // first of this lane's 8 output columns
         const bool nok = ncol < (GEGLU ? p.N / 2 : p.N);
+        // bias of this lane's columns (GEGLU: of its 8 x and its 8 gate weight rows), added to the sums FIRST, then the residual hi, then lo:
+        // the order of gemm_dma_kernel's epilogue, so that the two kernels agree bit for bit (a launch may go to either, by its row count)
+        // (GEGLU: the weight rows are x / gate interleaved by 16: output column 16 q + c <- x row 32 q + c, gate row 32 q + 16 + c)
+        const int brow = GEGLU ? n0 + a * 64 + (o >> 1) * 32 + (o & 1) * 8 : ncol;
+        f32x4 Bv[GEGLU ? 4 : 2];
+        Bv[0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(brs, brow * 4, 0, 0));
+        Bv[1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(brs, brow * 4 + 16, 0, 0));
+        if constexpr (GEGLU) {
+          Bv[2] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(brs, (brow + 16) * 4, 0, 0));
+          Bv[3] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(brs, (brow + 16) * 4 + 16, 0, 0));
+        }
         int yoff[NIT];
         u32x4 Rh[NIT], Rl[NIT];
 #pragma unroll
@@ -307,10 +307,10 @@ __global__ __launch_bounds__(512, 2) void gemm_df_kernel(const ConvParams p, con
           float v[8];
           if constexpr (GEGLU) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = U[it][e >> 2][e & 3] * gelu_erf(U[it][2 + (e >> 2)][e & 3]);
+            for (int e = 0; e < 8; ++e) v[e] = (U[it][e >> 2][e & 3] + Bv[e >> 2][e & 3]) * gelu_erf(U[it][2 + (e >> 2)][e & 3] + Bv[2 + (e >> 2)][e & 3]);
           } else {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = U[it][e >> 2][e & 3];
+            for (int e = 0; e < 8; ++e) v[e] = U[it][e >> 2][e & 3] + Bv[e >> 2][e & 3];
           }
           if constexpr (RES) {
 #pragma unroll
@@ -426,16 +426,11 @@ __global__ __launch_bounds__(512, 2) void gemm_df_kernel(const ConvParams p, con
     while (have < n) { have = flags_min_now(pflags); GACC(1, 1); }
   };
   unsigned taken = 0;  // slices known to be out of their buffers
-  auto init_from_table = [&](int parity) __attribute__((always_inline)) {
-    const unsigned taddr = lds0 + F_BT + (unsigned)parity * 1280u + (unsigned)g * 16u;
+  auto zero_sums = [&]() __attribute__((always_inline)) {
 #pragma unroll
-    for (int a = 0; a < NTW; ++a) {
-      const int tl = GEGLU ? 2 * (2 * a + (cw & 1)) + (cw >> 1) : 4 * a + cw;   // the column tile inside the unit
-      f32x4 b;
-      asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(b) : "v"(taddr + (unsigned)tl * 64u) : "memory");
+    for (int a = 0; a < NTW; ++a)
 #pragma unroll
-      for (int m = 0; m < MT; ++m) acc[a][m] = b;
-    }
+      for (int m = 0; m < MT; ++m) acc[a][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
   };
 
   GSTAMP(c_t0);
@@ -449,7 +444,7 @@ __global__ __launch_bounds__(512, 2) void gemm_df_kernel(const ConvParams p, con
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (nothing of the compiler's may be younger than the hand-counted loads below)
   issue_w(ic_t<0>{}, wq);
   need_steps(1u);
-  init_from_table(0);
+  zero_sums();
   issue_x(ic_t<0>{}, ic_t<0>{}, 0u, X[0]);
   GSTAMP(c_t1);
   GACC(0, c_t1 - c_t0);
@@ -504,8 +499,8 @@ __global__ __launch_bounds__(512, 2) void gemm_df_kernel(const ConvParams p, con
     GSTAMP(e1);
     GACC(3, e1 - e0); GACC(4, 1);
     if (has_next) {
-      need_steps((unsigned)j + 1u);   // the next unit's first step (and, in front of it, its bias slice)
-      init_from_table((i + 1) & 1);
+      need_steps((unsigned)j + 1u);   // the next unit's first step
+      zero_sums();
       issue_x(ic_t<0>{}, ic_t<0>{}, (unsigned)(j % F_S) * F_SLOT, X[0]);
       n0 = n0_next;
     }

@@ -1,4 +1,4 @@
-"""One eager SD-v1.5 UNet pass (B=8, 64x64 latents, default precision) with HIP events on every contraction / norm launch, one line per
+"""One eager SD-v1.5 UNet pass (B = LDIFF_UNET_B, default 8; 64x64 latents, default precision) with HIP events on every contraction / norm launch, one line per
 launch (LDIFF_PROF_DUMP): which launches are long AND slow?  Diagnostic; prints the launches sorted by time."""
 import os, re, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -28,7 +28,7 @@ from ldiffusion_amd.models import UNet2DConditionModel
 ucfg = configs.SD15_UNET
 unet = UNet2DConditionModel(ucfg, weights.synthetic_state_dict(weights.unet_param_shapes(ucfg), 42, fp16_values=True), "cuda:0")
 unet.set_graph(False)
-lat = torch.randn((8, 4, 64, 64), device="cuda:0")
+lat = torch.randn((int(os.environ.get("LDIFF_UNET_B", "8")), 4, 64, 64), device="cuda:0")   # LDIFF_UNET_B: batch (default 8; 1 = the reference's own batch)
 ctx = torch.randn((1, 6, 768), device="cuda:0") * 0.5
 for _ in range(2):
     unet(lat, 501, ctx)

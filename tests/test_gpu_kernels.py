@@ -639,6 +639,9 @@ GEMM_DF_CASES = {
 }
 
 
+GEMM_DF_SPLITK_ON_DMA = set()   # cases where gemm_dma_splitk_plan > 1 (filled if a case is added that has one; none of the above does)
+
+
 @pytest.mark.parametrize("name", list(GEMM_DF_CASES))
 def test_gemm_dataflow(lib, name):
     """gemm_df_kernel against a float64 GEMM on the operands the kernel sees: every epilogue (bias, plain / split residual, plain / split output, GEGLU),
@@ -709,13 +712,15 @@ def test_gemm_dataflow(lib, name):
         assert err <= 1e-5
     else:
         assert_close(yc.float(), ref.float(), name)
-    # the same launch on the LDS-DMA GEMM (gemm_df = -1): the two kernels must agree to their accumulation order
+    # the same launch on the LDS-DMA GEMM (gemm_df = -1): the two kernels add in the same order (K ascending in 32-deep MFMAs, then bias, residual hi,
+    # residual lo) and must agree BIT FOR BIT -- the executors send a layer to one or the other by its row count, and a tile sampled alone must equal
+    # the same tile inside a batch (test_tiles_are_independent_units).  gemm_dma's split-K plans sum K in another order: those shapes are left out.
     y2 = torch.full_like(y, float("nan"))
     a_.y, a_.gemm_df = y2.data_ptr(), -1
     _lib.check(lib.ldiff_op_conv(C.byref(a_), sp()))
     torch.cuda.synchronize()
-    d = (y2.float() - y.float()).abs().max().item() if not split_out else (from_split(y2.cpu(), Nout) - from_split(yc, Nout)).abs().max().item()
-    assert d <= 2e-3 * max(1.0, ref.abs().max().item())
+    if name not in GEMM_DF_SPLITK_ON_DMA:
+        assert torch.equal(y2, y), f"dataflow and LDS-DMA GEMM differ in {int((y2 != y).sum())} elements"
 
 
 def test_gemm_dataflow_rejects_what_it_does_not_take(lib):

@@ -418,7 +418,7 @@ __device__ __forceinline__ void wave_stats_store(const f32x4 (&o)[NT][MT], const
     for (int m = 0; m < MT; ++m) {
       if (m < M0 || m >= M1 || !ok[m]) continue;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) { const float v = o[a][m][r]; s[r] += v; q[r] += v * v; }
+      for (int r = 0; r < 4; ++r) { const float v = o[a][m][r]; s[r] += v; q[r] = __builtin_fmaf(v, v, q[r]); }   // (explicit: kernels_gemm_df.hip sums in this association, bit for bit)
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) { s[r] = row16_sum(s[r]); q[r] = row16_sum(q[r]); }

@@ -23,7 +23,7 @@
 // A workgroup walks a contiguous run of units (column unit fastest, XCD-aware: the runs of one XCD's workgroups are adjacent).
 //
 // Scope (gemm_df_selected): ks == 1, K % 64 == 0, one or two row-major sources (channel concat at a multiple of 64), fp16 output plain or split,
-// optional plain / split residual, optional GEGLU epilogue; no per-image weights, no split-K, no fused GroupNorm statistics (those stay on
+// optional plain / split residual, optional GEGLU epilogue or fused GroupNorm partial statistics; no per-image weights, no split-K (those stay on
 // gemm_dma_kernel).
 #include "common.h"
 #include <map>
@@ -63,7 +63,7 @@ constexpr unsigned F_DUMP = F_FLAGS + 64;                // 8 waves x 256 B: whe
 constexpr unsigned F_LDS = F_DUMP + 8 * 256;
 static_assert(F_LDS <= 160 * 1024, "LDS budget of one workgroup per CU");
 constexpr unsigned F_OOR = 0x80000000u;                  // beyond num_records of every descriptor used here
-enum { FG_RES = 1, FG_RES_SPLIT = 2, FG_OUT_SPLIT = 4, FG_GEGLU = 8 };
+enum { FG_RES = 1, FG_RES_SPLIT = 2, FG_OUT_SPLIT = 4, FG_GEGLU = 8, FG_STATS = 16 };
 
 __device__ __forceinline__ int swz8(int row, int chunk) { return chunk ^ ((row >> 1) & 7); }
 
@@ -132,6 +132,8 @@ __global__ __launch_bounds__(512, 2) void gemm_df_kernel(const ConvParams p, con
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   constexpr int BM = MT * 16, BN = NTW * 64, NP_ALL = MT * 2, NEPI = 4 - NLOAD;
   constexpr bool RES = (FL & FG_RES) != 0, RES_SPLIT = (FL & FG_RES_SPLIT) != 0, OUT_SPLIT = (FL & FG_OUT_SPLIT) != 0, GEGLU = (FL & FG_GEGLU) != 0;
+  constexpr bool STATS = (FL & FG_STATS) != 0;   // fused GroupNorm partial statistics (common.h): 32-row blocks, so row groups go to the epilogue waves in fours
+  static_assert(!STATS || (!GEGLU && (NLOAD == 2 || MT == 4)), "statistics: two epilogue waves (or one 64-row half each of three)");
   static_assert(NLOAD >= 1 && NLOAD <= 3 && (MT == 8 || MT == 4) && NTW >= 1 && NTW <= 5, "configuration");
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -245,7 +247,9 @@ __global__ __launch_bounds__(512, 2) void gemm_df_kernel(const ConvParams p, con
     const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc((void*)(p.bias ? p.bias : (const float*)p.y), 0, p.bias ? p.Nrows * 4 : 0, 0x00020000);   // no bias: zero records, loads return 0
     // a wave-instruction takes ROWS_I rows of the slice: 8 rows x 8 octets (a 64-column slice row = one 128-byte line of y), or, GEGLU, 16 rows x 4
     // octets (a slice carries 32 x | 32 gate columns = 32 outputs).  Row groups are dealt round-robin over the epilogue waves.
-    constexpr int ROWS_I = GEGLU ? 16 : 8, NG = BM / ROWS_I, NIT = (NG + NEPI - 1) / NEPI;
+    constexpr int ROWS_I = GEGLU ? 16 : 8, NG = BM / ROWS_I, NIT = STATS ? 4 * ((NG / 4 + NEPI - 1) / NEPI) : (NG + NEPI - 1) / NEPI;
+    // row group of iteration `it`: dealt round-robin -- or, with statistics, in runs of four (one 32-row block) round-robin
+    auto row_group = [&](int it) __attribute__((always_inline)) -> int { return STATS ? ((it >> 2) * NEPI + ew) * 4 + (it & 3) : ew + it * NEPI; };
     const int px = GEGLU ? lane >> 2 : lane >> 3, o = GEGLU ? lane & 3 : lane & 7;
 #ifdef GDF_STAMPS
     unsigned long long dbg[16] = {0};
@@ -274,7 +278,7 @@ __global__ __launch_bounds__(512, 2) void gemm_df_kernel(const ConvParams p, con
         u32x4 Rh[NIT], Rl[NIT];
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
-          const int rg = ew + it * NEPI, m = m0 + rg * ROWS_I + px;
+          const int rg = row_group(it), m = m0 + rg * ROWS_I + px;
           const bool ok = rg < NG && m < p.M && nok;
           yoff[it] = ok ? (m * p.ldy + ncol) * 2 : (int)F_OOR;
           if constexpr (RES) {
@@ -290,7 +294,7 @@ __global__ __launch_bounds__(512, 2) void gemm_df_kernel(const ConvParams p, con
         f32x4 U[NIT][GEGLU ? 4 : 2];
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
-          const int rg = ew + it * NEPI;
+          const int rg = row_group(it);
           const unsigned ra = hb + (unsigned)((rg < NG ? rg : 0) * ROWS_I + px) * F_HP + (unsigned)o * 32u;
           U[it][0] = *reinterpret_cast<const __attribute__((address_space(3))) f32x4*>((size_t)ra);
           U[it][1] = *reinterpret_cast<const __attribute__((address_space(3))) f32x4*>((size_t)(ra + 16u));
@@ -302,8 +306,17 @@ __global__ __launch_bounds__(512, 2) void gemm_df_kernel(const ConvParams p, con
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
         lds_write32(dflag_addr, (unsigned)sidx + 1u);   // the slice is in registers: its buffer is free
+        // statistics: two accumulator sets per 32-row block -- rows {px, px + 16} and {px + 8, px + 24} of the block -- reduced separately over the
+        // row lanes and added last: the association of gemm_dma_kernel's wave_stats_store (a lane's two rows, quad, octet, 16 rows), bit for bit
+        float x16[2][16];
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
+          if constexpr (STATS) {
+            if ((it & 3) == 0) {
+#pragma unroll
+              for (int j = 0; j < 16; ++j) { x16[0][j] = 0.f; x16[1][j] = 0.f; }
+            }
+          }
           float v[8];
           if constexpr (GEGLU) {
 #pragma unroll
@@ -337,6 +350,50 @@ __global__ __launch_bounds__(512, 2) void gemm_df_kernel(const ConvParams p, con
           }
           __builtin_amdgcn_raw_buffer_store_b128(oh, yrs, yoff[it], 0, 0);
           if constexpr (OUT_SPLIT) __builtin_amdgcn_raw_buffer_store_b128(ol, yrs, yoff[it] == (int)F_OOR ? (int)F_OOR : yoff[it] + p.y_lo * 2, 0, 0);
+          if constexpr (STATS) {
+            // what gemm_dma_kernel sums: the fp32 value of a split output, the rounded value of a plain one; rows beyond M count nothing
+            const bool rok = yoff[it] != (int)F_OOR;
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+              const unsigned hd = oh[d];
+              const f16x2 h = __builtin_bit_cast(f16x2, hd);
+              const float f0 = rok ? (OUT_SPLIT ? v[2 * d] : (float)h[0]) : 0.f, f1 = rok ? (OUT_SPLIT ? v[2 * d + 1] : (float)h[1]) : 0.f;
+              float (&xs)[16] = x16[it & 1];
+              xs[2 * d] += f0; xs[2 * d + 1] += f1;
+              xs[8 + 2 * d] = __builtin_fmaf(f0, f0, xs[8 + 2 * d]); xs[8 + 2 * d + 1] = __builtin_fmaf(f1, f1, xs[8 + 2 * d + 1]);
+            }
+            if ((it & 3) == 3) {
+              // a 32-row block is complete in this wave: per set 8 sums + 8 sums of squares per lane, reduced over the eight row lanes in three halving
+              // steps (row_ror:8, v_permlane16_swap, v_permlane32_swap: the scheme of conv3x3d_kernel's store_unit): every lane ends with
+              // (sum, sum of squares) of ONE channel: one 8-byte store
+              const bool b0 = (lane & 8) != 0;
+#pragma unroll
+              for (int h = 0; h < 2; ++h) {
+                float (&xs)[16] = x16[h];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                  const float keep = b0 ? xs[2 * q + 1] : xs[2 * q], send = b0 ? xs[2 * q] : xs[2 * q + 1];
+                  xs[q] = keep + dpp_f<0x128>(send);   // row_ror:8 = lane ^ 8
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                  auto sw = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, xs[2 * q + 1]), __builtin_bit_cast(unsigned, xs[2 * q]), false, false);
+                  xs[q] = u2f(sw[0]) + u2f(sw[1]);
+                }
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                  auto sw = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, xs[2 * q + 1]), __builtin_bit_cast(unsigned, xs[2 * q]), false, false);
+                  xs[q] = u2f(sw[0]) + u2f(sw[1]);
+                }
+              }
+              const float ssum = x16[0][0] + x16[1][0], ssq = x16[0][1] + x16[1][1];
+              const int chn = ((lane >> 3) & 1) | ((((lane >> 4) & 1) ^ 1) << 1) | ((((lane >> 5) & 1) ^ 1) << 2);
+              const int rg0 = row_group(it - 3), mblk = m0 + rg0 * ROWS_I;   // first row of the block (a multiple of 32)
+              const int hw = p.Hout * p.Wout, bimg = mblk / hw, rblk = (mblk - bimg * hw) >> 5, n = ncol + chn;
+              if (rg0 < NG && mblk < p.M && n < p.N)
+                *reinterpret_cast<float2*>(p.stats + (((long long)bimg * p.N + n) * p.stats_R + rblk) * 2) = make_float2(ssum, ssq);
+            }
+          }
         }
         GSTAMP(w2);
         GACC(2, w2 - w1); GACC(4, 1);
@@ -584,11 +641,14 @@ void launch_df_l(const ConvParams& p, hipStream_t s) {
   // three run the epilogue, which is what the consumers end up waiting for
 #ifdef GDF_TUNE   // tuning build: LDIFF_GEMM_DF_NLOAD = 1 / 2 / 3 (three times the instantiations)
   static const int nl = [] { const char* e = getenv("LDIFF_GEMM_DF_NLOAD"); return e ? atoi(e) : GDF_NLOAD; }();
-  if (nl == 1) return launch_df<MT, NTW, FL, 1>(p, s);
-  if (nl == 2) return launch_df<MT, NTW, FL, 2>(p, s);
-  if (nl == 3) return launch_df<MT, NTW, FL, 3>(p, s);
+  if constexpr ((FL & FG_STATS) == 0) {
+    if (nl == 1) return launch_df<MT, NTW, FL, 1>(p, s);
+    if (nl == 2) return launch_df<MT, NTW, FL, 2>(p, s);
+    if (nl == 3) return launch_df<MT, NTW, FL, 3>(p, s);
+  }
 #endif
-  launch_df<MT, NTW, FL, GDF_NLOAD>(p, s);
+  if constexpr ((FL & FG_STATS) != 0) launch_df<MT, NTW, FL, 2>(p, s);   // 32-row statistics blocks: two epilogue waves take two of a 128-row unit's four each
+  else launch_df<MT, NTW, FL, GDF_NLOAD>(p, s);
 }
 template <int FL>
 void launch_df_f(const ConvParams& p, hipStream_t s) {
@@ -618,7 +678,8 @@ size_t gemm_df_frag_bytes(const ConvParams& p) { return (size_t)p.Nrows * p.K * 
 bool gemm_df_selected(const ConvParams& p) {
   static const int mode = [] { const char* e = getenv("LDIFF_GEMM_DF"); return e ? atoi(e) : 1; }();
   if (p.df_force < 0 || (mode == 0 && p.df_force == 0) || !gemm_dma_eligible(p)) return false;
-  if (p.w_bstride != 0 || p.splitk > 1 || p.stats || p.out_f32 || p.M <= 0) return false;
+  if (p.w_bstride != 0 || p.splitk > 1 || p.out_f32 || p.M <= 0) return false;
+  if (p.stats && (p.geglu || (p.Hout * p.Wout) % 32 != 0 || p.stats_R != (p.Hout * p.Wout) / 32)) return false;
   if (p.C1 % 64 != 0 || p.C2 % 64 != 0 || p.Nrows % 16 != 0 || p.Nrows < p.N) return false;
   if ((p.N & 7) || (p.ldy & 7) || (p.y_lo & 7) || (p.res && ((p.ld_res & 7) || (p.res_lo & 7)))) return false;
   if (p.geglu && (p.N % 64 != 0 || p.res || p.y_lo)) return false;
@@ -642,7 +703,7 @@ void launch_gemm_df(const ConvParams& p, hipStream_t s) {
   LDIFF_CHECK(p.w_frag != nullptr, LDIFF_ERR_INVALID, "gemm (dataflow): the caller did not provide the fragment-packed weights (launch_pack_gemm_frag)");
   const double bytes = (double)p.M * p.K * 2.0 + (double)p.N * p.K * 2.0 + (double)p.M * (p.geglu ? p.N / 2 : p.N) * (p.y_lo ? 4.0 : 2.0) + (p.res ? (double)p.M * p.N * (p.res_lo ? 4.0 : 2.0) : 0.0);
   ProfScope prof(p.geglu ? "gemm_df<geglu>" : "gemm_df", 2.0 * p.M * (double)p.N * p.K, bytes, s);
-  const int fl = (p.res ? FG_RES : 0) | (p.res && p.res_lo ? FG_RES_SPLIT : 0) | (p.y_lo ? FG_OUT_SPLIT : 0) | (p.geglu ? FG_GEGLU : 0);
+  const int fl = (p.res ? FG_RES : 0) | (p.res && p.res_lo ? FG_RES_SPLIT : 0) | (p.y_lo ? FG_OUT_SPLIT : 0) | (p.geglu ? FG_GEGLU : 0) | (p.stats ? FG_STATS : 0);
   switch (fl) {
     case 0: launch_df_f<0>(p, s); break;
     case FG_RES: launch_df_f<FG_RES>(p, s); break;
@@ -651,6 +712,11 @@ void launch_gemm_df(const ConvParams& p, hipStream_t s) {
     case FG_RES | FG_RES_SPLIT: launch_df_f<FG_RES | FG_RES_SPLIT>(p, s); break;
     case FG_RES | FG_RES_SPLIT | FG_OUT_SPLIT: launch_df_f<FG_RES | FG_RES_SPLIT | FG_OUT_SPLIT>(p, s); break;
     case FG_GEGLU: launch_df_f<FG_GEGLU>(p, s); break;
+    // fused statistics: the layers that ask for them (proj_out of Transformer2DModel: split residual, split output; plain graphs: plain residual)
+    case FG_STATS | FG_RES | FG_RES_SPLIT | FG_OUT_SPLIT: launch_df_f<FG_STATS | FG_RES | FG_RES_SPLIT | FG_OUT_SPLIT>(p, s); break;
+    case FG_STATS | FG_RES: launch_df_f<FG_STATS | FG_RES>(p, s); break;
+    case FG_STATS | FG_OUT_SPLIT: launch_df_f<FG_STATS | FG_OUT_SPLIT>(p, s); break;
+    case FG_STATS: launch_df_f<FG_STATS>(p, s); break;
     default: LDIFF_CHECK(false, LDIFF_ERR_INVALID, "gemm (dataflow): unsupported epilogue %d", fl);
   }
 }

@@ -634,6 +634,9 @@ GEMM_DF_CASES = {
     "geglu": (4096, 320, 0, 2560, "geglu", 16 * 8 + 5),
     "geglu_bn128_tail_rows": (1000, 128, 0, 768, "geglu", 16 * 8 + 2),
     "geglu_mt4_ntw4": (2048, 640, 0, 5120, "geglu", 16 * 4 + 4),
+    "stats_split_res_split_out": (8192, 640, 0, 320, "split_res_out+stats", 16 * 8 + 5),     # proj_out of Transformer2DModel at level 0: two images of 4096 rows
+    "stats_plain_res_mt4": (2048, 256, 0, 256, "res+stats", 16 * 4 + 4),
+    "stats_split_out_bn128_tail_columns": (4096, 128, 0, 320, "split_out+stats", 16 * 8 + 2),
     "auto_plan_level1_ff2": (8192, 2560, 0, 640, "split_res_out", 1),
     "auto_plan_level2_qkv": (2048, 1280, 0, 3840, "plain_nobias", 1),
 }
@@ -648,6 +651,8 @@ def test_gemm_dataflow(lib, name):
     every unit shape, ragged rows and columns, two concat sources, runs of several units per workgroup.  Plain outputs: one fp16 rounding of the fp32
     result; split outputs: hi + lo to fp32 round-off."""
     M, K1, K2, N, epi, plan = GEMM_DF_CASES[name]
+    want_stats = epi.endswith("+stats")
+    epi = epi.replace("+stats", "")
     g = torch.Generator().manual_seed(zlib.crc32(name.encode()) % 1000)
     K = K1 + K2
     geglu = epi == "geglu"
@@ -681,7 +686,8 @@ def test_gemm_dataflow(lib, name):
     if bdev is not None:
         bd = torch.zeros(Nrows); bd[:N] = bdev; bd = bd.to(DEV); keep.append(bd)
         a_.bias = bd.data_ptr()
-    a_.B, a_.Hin, a_.Win, a_.Hout, a_.Wout, a_.ks, a_.stride = 1, 1, M, 1, M, 1, 1
+    Bimg = 2 if want_stats else 1          # statistics are per image: two images of M / 2 rows
+    a_.B, a_.Hin, a_.Win, a_.Hout, a_.Wout, a_.ks, a_.stride = Bimg, 1, M // Bimg, 1, M // Bimg, 1, 1
     ref = A @ w.double().t() + (bias.double() if bias is not None else 0.0)
     split_out = epi in ("split_out", "split_res_out")
     Nout = N // 2 if geglu else N
@@ -701,10 +707,21 @@ def test_gemm_dataflow(lib, name):
     y = torch.full((M, 2 * Nout if split_out else Nout), float("nan"), dtype=torch.float16, device=DEV)
     a_.y, a_.ldy, a_.y_lo, a_.geglu = y.data_ptr(), y.shape[1], Nout if split_out else 0, int(geglu)
     a_.gemm_df = plan
+    if want_stats:
+        R = lib.ldiff_op_conv_stats_blocks(C.byref(a_))
+        assert R == M // Bimg // 32
+        st = torch.full((Bimg, N, R, 2), float("nan"), device=DEV)
+        a_.stats = st.data_ptr()
     _lib.check(lib.ldiff_op_conv(C.byref(a_), sp()))
     torch.cuda.synchronize()
     yc = y.cpu()
     assert torch.isfinite(yc.float()).all(), "unwritten or non-finite outputs"
+    if want_stats:      # partial sums of the stored values (fp32 value of a split output, rounded value of a plain one) per 32-row block and channel
+        stored = (from_split(yc, Nout) if split_out else yc.float()).double().view(Bimg, R, 32, N)
+        sref = torch.stack([stored.sum(2), (stored * stored).sum(2)], -1).permute(0, 2, 1, 3)      # [B, N, R, 2]
+        stc = st.cpu().double()
+        assert torch.isfinite(stc).all(), "unwritten statistics"
+        assert (stc - sref).abs().max() <= 2e-5 * sref.abs().max()
     if split_out:
         got = from_split(yc, Nout).double()
         err = (got - ref).abs().max().item() / ref.abs().max().item()
@@ -717,10 +734,15 @@ def test_gemm_dataflow(lib, name):
     # the same tile inside a batch (test_tiles_are_independent_units).  gemm_dma's split-K plans sum K in another order: those shapes are left out.
     y2 = torch.full_like(y, float("nan"))
     a_.y, a_.gemm_df = y2.data_ptr(), -1
+    if want_stats:
+        st2 = torch.full_like(st, float("nan"))
+        a_.stats = st2.data_ptr()
     _lib.check(lib.ldiff_op_conv(C.byref(a_), sp()))
     torch.cuda.synchronize()
     if name not in GEMM_DF_SPLITK_ON_DMA:
         assert torch.equal(y2, y), f"dataflow and LDS-DMA GEMM differ in {int((y2 != y).sum())} elements"
+        if want_stats:
+            assert torch.equal(st2, st), f"fused statistics differ in {int((st2 != st).sum())} of {st.numel()} sums (max {float((st2 - st).abs().max()):.3e})"
 
 
 def test_gemm_dataflow_rejects_what_it_does_not_take(lib):

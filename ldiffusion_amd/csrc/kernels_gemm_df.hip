@@ -419,11 +419,18 @@ __global__ __launch_bounds__(512, 2) void gemm_df_kernel(const ConvParams p, con
 #ifdef GDF_STAMPS
   unsigned long long dbg[16] = {0};
 #endif
-  // activation fragments travel in groups of GR row tiles, one group ahead (two register sets): four where the registers allow, two under the
-  // 160 accumulator registers of NTW = 5 (ten MFMAs per group still cover an LDS round trip)
-  constexpr int GR = NTW >= 5 ? 2 : 4, NGH = MT / GR, NQ = 2 * NGH;
+  // activation fragments travel in groups of GR = 2 row tiles, XD - 1 groups ahead (XD register sets).  ONE group ahead is the kept form: three
+  // groups ahead (GDF_XD=4: 6 NTW MFMAs of lead instead of 2 NTW) made the K loops 10 % SLOWER (L1 q/k/v 28.9 -> 34.9 us, profiles/r05_gemm_df.md):
+  // the next slot is then asked for a third of a step into the current one, and with three ring slots the consumers end up polling for it.
+  // The read stream runs through step AND unit boundaries (the next unit's first slot is simply the ring's next one); behind the run's last
+  // step it reads a slot nobody filled, unused.
+#ifndef GDF_XD
+#define GDF_XD 2
+#endif
+  constexpr int GR = 2, NGH = MT / GR, NQ = 2 * NGH, XD = NTW >= 5 ? 2 : GDF_XD, XA = XD - 1;
+  static_assert(NQ % XD == 0 && XA <= NQ, "a step's group count must be a multiple of the register sets");
   f32x4 acc[NTW][MT];
-  f16x8 Wf[2][NTW], X[2][GR];
+  f16x8 Wf[2][NTW], X[XD][GR];
   unsigned woff[NTW];   // per column tile: byte offset of its fragments of K step 0 (+ lane * 16)
 
   auto set_unit_w = [&](int n0) __attribute__((always_inline)) {
@@ -453,7 +460,7 @@ __global__ __launch_bounds__(512, 2) void gemm_df_kernel(const ConvParams p, con
     else if constexpr (NTW == 4) vm_wait_frags(Wf[kh][0], Wf[kh][1], Wf[kh][2], Wf[kh][3]);
     else vm_wait_frags(Wf[kh][0], Wf[kh][1], Wf[kh][2], Wf[kh][3], Wf[kh][4]);
   };
-  auto issue_x = [&](auto gc, auto khc, unsigned sb, f16x8 (&dst)[GR]) __attribute__((always_inline)) {   // row tiles GR gr .. GR gr + GR - 1 of k-half kh from the slot at sb
+  auto issue_x = [&](auto gc, auto khc, unsigned sb, f16x8 (&dst)[GR]) __attribute__((always_inline)) {   // row tiles GR gr, GR gr + 1 of k-half kh from the slot at sb
     constexpr int gr = decltype(gc)::value, kh = decltype(khc)::value;
     const unsigned b0 = (xa0 + sb) ^ (kh ? 64u : 0u);
 #ifdef GDF_ABL_NOX   // ablation (timing only): no activation fragment reads
@@ -466,7 +473,7 @@ __global__ __launch_bounds__(512, 2) void gemm_df_kernel(const ConvParams p, con
 #ifdef GDF_ABL_NOX
     return;
 #endif
-    if constexpr (GR == 2) lds_wait2<CNT>(x[0], x[1]); else lds_wait4<CNT>(x[0], x[1], x[GR - 2], x[GR - 1]);
+    lds_wait2<CNT>(x[0], x[1]);
   };
   auto mfma_g = [&](auto khc, auto gc, f16x8 (&x)[GR]) __attribute__((always_inline)) {
     constexpr int kh = decltype(khc)::value, gr = decltype(gc)::value;
@@ -502,7 +509,7 @@ __global__ __launch_bounds__(512, 2) void gemm_df_kernel(const ConvParams p, con
   issue_w(ic_t<0>{}, wq);
   need_steps(1u);
   zero_sums();
-  issue_x(ic_t<0>{}, ic_t<0>{}, 0u, X[0]);
+  static_for<0, XA>([&](auto tc) { constexpr int t = decltype(tc)::value; issue_x(ic_t<t % NGH>{}, ic_t<t / NGH>{}, 0u, X[t]); });
   GSTAMP(c_t1);
   GACC(0, c_t1 - c_t0);
 
@@ -514,27 +521,27 @@ __global__ __launch_bounds__(512, 2) void gemm_df_kernel(const ConvParams p, con
     for (int kt = 0; kt < nk; ++kt, ++j) {
       const bool last = kt == nk - 1;
       const unsigned sb = (unsigned)(j % F_S) * F_SLOT, sbn = (unsigned)((j + 1) % F_S) * F_SLOT;
-      // entry: in flight are row group 0 of k-half 0 (GR LDS reads -> X[0]) and the weights of k-half 0 (NTW global loads -> Wf[0]).
-      // The step is NQ group-steps (k-half 0's row groups, then k-half 1's); group-step q reads with X[q & 1] while the reads of q + 1 travel.
+      // entry: in flight are this step's first XA row groups (-> X[0 .. XA-1]) and the weights of k-half 0 (NTW global loads -> Wf[0]).
+      // The step is NQ group-steps (k-half 0's row groups, then k-half 1's); group-step q computes with X[q % XD] while the reads of q + 1 .. q + XA travel.
+      const bool more = j + 1 < total;
       static_for<0, NQ>([&](auto qc) {
-        constexpr int q = decltype(qc)::value, kh = q / NGH, gr = q % NGH;
+        constexpr int q = decltype(qc)::value, kh = q / NGH, gr = q % NGH, t = q + XA;
         if constexpr (q == 0) issue_w(ic_t<1>{}, wq);
         if constexpr (q == NGH) {
           // the weights of the next step: the next K step of this unit, or step 0 of the next unit (after the last unit: loaded again, unused)
           if (last) { set_unit_w(n0_next); wq = wbase; } else wq += 2048;
           issue_w(ic_t<0>{}, wq);
         }
-        if constexpr (q + 1 < NQ) {
-          issue_x(ic_t<(q + 1) % NGH>{}, ic_t<(q + 1) / NGH>{}, sb, X[(q + 1) & 1]);
-          lds_wait_g(ic_t<GR>{}, X[q & 1]);
-        } else {
-          // every fragment of step j is in registers once the last group has landed: its slot is free
-          lds_wait_g(ic_t<0>{}, X[q & 1]);
-          lds_write32(cflag_addr, (unsigned)j + 1u);
-          if (!last) { need_steps((unsigned)j + 2u); issue_x(ic_t<0>{}, ic_t<0>{}, sbn, X[0]); }
+        if constexpr (t < NQ) issue_x(ic_t<t % NGH>{}, ic_t<t / NGH>{}, sb, X[t % XD]);
+        else {   // the next step's groups (its slot must have landed before the first of them is read)
+          if constexpr (t == NQ) { if (more) need_steps((unsigned)j + 2u); }
+          issue_x(ic_t<(t - NQ) % NGH>{}, ic_t<(t - NQ) / NGH>{}, sbn, X[t % XD]);
         }
+        lds_wait_g(ic_t<XA * GR>{}, X[q % XD]);
+        // every fragment of step j is in registers once its last group has landed: its slot is free
+        if constexpr (q == NQ - 1) lds_write32(cflag_addr, (unsigned)j + 1u);
         if constexpr (gr == 0) vm_wait_w(ic_t<kh>{});
-        mfma_g(ic_t<kh>{}, ic_t<gr>{}, X[q & 1]);
+        mfma_g(ic_t<kh>{}, ic_t<gr>{}, X[q % XD]);
         __builtin_amdgcn_sched_barrier(0);
       });
     }
@@ -556,9 +563,7 @@ __global__ __launch_bounds__(512, 2) void gemm_df_kernel(const ConvParams p, con
     GSTAMP(e1);
     GACC(3, e1 - e0); GACC(4, 1);
     if (has_next) {
-      need_steps((unsigned)j + 1u);   // the next unit's first step
-      zero_sums();
-      issue_x(ic_t<0>{}, ic_t<0>{}, (unsigned)(j % F_S) * F_SLOT, X[0]);
+      zero_sums();   // (the next unit's first fragments are already on their way: the read stream does not stop at a unit's end)
       n0 = n0_next;
     }
     GSTAMP(e2);
@@ -631,7 +636,11 @@ void launch_df(const ConvParams& p, hipStream_t s) {
   const int bm = MT * 16, bn = NTW * 64;
   const int nunits = (p.N + bn - 1) / bn, units = ((p.M + bm - 1) / bm) * nunits;
   const int cus = f_num_cus();
-  const int grid = units < cus ? units : cus;
+  // run length (units per workgroup): LDIFF_GEMM_DF_RUN > 0 caps it (diagnostic: a persistent workgroup holds its CU for the whole launch, which
+  // matters where another stream's kernels wait for CUs -- the sampler's decodes beside the UNet pass); 0 (default) = one workgroup per CU
+  static const int run_cap = [] { const char* e = getenv("LDIFF_GEMM_DF_RUN"); return e ? atoi(e) : 0; }();
+  int grid = units < cus ? units : cus;
+  if (run_cap > 0 && units > grid * run_cap) grid = (units + run_cap - 1) / run_cap;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(512), F_LDS, s, p, units, nunits);
   HIP_CHECK(hipGetLastError());
 }
@@ -685,6 +694,9 @@ bool gemm_df_selected(const ConvParams& p) {
   if (p.geglu && (p.N % 64 != 0 || p.res || p.y_lo)) return false;
   if ((long long)p.M * p.ldy * 2 >= (1LL << 31) || (p.res && (long long)p.M * p.ld_res * 2 >= (1LL << 31)) || (long long)p.Nrows * p.K * 2 >= (1LL << 31)) return false;
   if (mode == 2 || p.df_force > 0) return true;
+  // fused statistics: built and bit-identical to gemm_dma's, but with two epilogue waves summing beside their stores the launch takes twice
+  // gemm_dma's time (proj_out at level 0: 36 -> 68 us): only on request
+  if (p.stats) return false;
   // Measured against gemm_dma on the UNet's shapes at B = 8 (profiles/r05_gemm_df.md): ahead by 5-25 % wherever a launch has >= 4,096 rows, and on
   // the wide launches (N >= 3,840) of the 2,048-row level; behind on that level's narrow launches (16 row blocks: gemm_dma's 64 x 64 tiles and
   // split-K fill the chip better) and on GEGLU at K < 512, where the erf of the epilogue outweighs the matrix work whoever runs it.

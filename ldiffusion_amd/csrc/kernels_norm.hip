@@ -333,6 +333,9 @@ __global__ __launch_bounds__(256) void layernorm_kernel(SrcView xs, f16* __restr
   }
 }
 
+// (Round 5: a form with 64 / LPR rows per wave for C = 320 / 640 / 1280 -- every lane busy, ten 16-byte loads per lane in flight -- was built,
+// parity-green, and measured on the UNet pass: 12.42 / 12.41 ms with this kernel, 12.46 / 12.39 ms with it (profiles/r05_unet_ab_ln_rows.txt).
+// No gain: removed again.)
 void launch_layernorm(SrcView x, f16* y, int rows, const float* gamma, const float* beta, float eps, hipStream_t s) {
   x = norm_view(x);
   LDIFF_CHECK(x.C % 8 == 0 && x.C <= 8 * 64 * LN_MAXCH && x.ld % 8 == 0 && x.lo % 8 == 0, LDIFF_ERR_INVALID, "layernorm: C=%d unsupported", x.C);

@@ -1159,6 +1159,23 @@ def test_norm_apply(lib, C1, C2, in_split, out_split, silu):
         _lib.check(lib.ldiff_op_norm_apply(x1d.data_ptr(), C1, ld(C1), lo(C1), None, 0, 0, 0, B, HW, sd.data_ptr(), hd.data_ptr(), silu, y.data_ptr(), C1 - 8, 0, sp()))
 
 
+@pytest.mark.parametrize("rows,Cc", [(1027, 640), (515, 1280), (9, 320), (8192, 640)])
+def test_layernorm_on_split_rows_at_the_unet_widths(lib, rows, Cc):
+    """LayerNorm of split rows hi | lo at C = 320 / 640 / 1280, ragged row counts, against fp32 LayerNorm of hi + lo with ONE fp16 rounding; nothing
+    is written behind the last row."""
+    g = torch.Generator().manual_seed(rows + Cc)
+    x = torch.randn((rows, Cc), generator=g) * 2 + 0.5
+    gamma, beta = 1 + 0.1 * torch.randn(Cc, generator=g), 0.1 * torch.randn(Cc, generator=g)
+    xs = to_split(x).to(DEV)
+    gd, bd = gamma.to(DEV), beta.to(DEV)
+    y = torch.full((rows + 3, Cc), float("nan"), dtype=torch.float16, device=DEV)
+    _lib.check(lib.ldiff_op_layernorm(xs.data_ptr(), 2 * Cc, Cc, y.data_ptr(), rows, Cc, gd.data_ptr(), bd.data_ptr(), 1e-5, sp()))
+    torch.cuda.synchronize()
+    ref = F.layer_norm(from_split(xs.cpu(), Cc), (Cc,), gamma, beta, 1e-5)
+    assert_close(y[:rows], ref, f"layernorm split {rows}x{Cc}", rtol=6e-4, atol_rel=1e-5)
+    assert torch.isnan(y[rows:].float()).all(), "rows beyond the tensor were written"
+
+
 def test_layernorm_and_groupnorm_statistics_read_split_tensors(lib):
     g = torch.Generator().manual_seed(12)
     rows, Cc = 513, 320

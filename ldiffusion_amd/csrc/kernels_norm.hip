@@ -219,7 +219,11 @@ void launch_gn_stats(SrcView x1, SrcView x2, int B, int HW, int groups, float ep
   LDIFF_CHECK(x1.ld % 8 == 0 && x1.lo % 8 == 0 && (!x2.p || (x2.ld % 8 == 0 && x2.lo % 8 == 0)), LDIFF_ERR_INVALID, "gn_stats: pitches must be multiples of 8");
   LDIFF_CHECK(C % groups == 0, LDIFF_ERR_INVALID, "gn_stats: C=%d not divisible by groups=%d", C, groups);
   LDIFF_CHECK(gn_partial_bytes(B, HW, C) <= partial_bytes, LDIFF_ERR_INVALID, "gn_stats: workspace too small");
-  if (HW <= 1024 && B * groups >= 64) {   // small map, enough (image, group) workgroups: one launch
+  // small map with enough (image, group) workgroups, or a batch so small that either form is a latency chain (B = 1, the reference's own batch:
+  // the two-launch form costs 22 us per tensor there, 43 tensors per UNet pass -- profiles/r05_unet_launches_b1.txt): one launch.
+  // LDIFF_GN_SMALL_BATCH=0 restores the two-launch form for small batches (A/B).
+  static const bool small_batch = [] { const char* e = getenv("LDIFF_GN_SMALL_BATCH"); return !e || atoi(e) != 0; }();
+  if ((HW <= 1024 && B * groups >= 64) || (small_batch && B * groups < 256 && HW <= 4096)) {
     ProfScope prof("gn_stats", 3.0 * B * HW * (double)C, 2.0 * B * HW * ((double)C1 * (x1.lo ? 2 : 1) + (double)C2 * (x2.lo ? 2 : 1)), s);
     hipLaunchKernelGGL(gn_small_kernel, dim3(groups, B), dim3(256), 0, s, x1, x2, HW, groups, eps, gamma, beta, scale, shift);
     HIP_CHECK(hipGetLastError());

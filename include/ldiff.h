@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define LDIFF_VERSION 150 /* 0.1.5.0: + dataflow GEMM (ldiff_conv_args.gemm_df) */
+#define LDIFF_VERSION 151 /* 0.1.5.1: + dataflow GEMM (ldiff_conv_args.gemm_df), shortcut conv folded into the dataflow conv3x3 (ldiff_conv_args.sc_*) */
 #define LDIFF_MAX_BLOCKS 8
 
 typedef enum { LDIFF_OK = 0, LDIFF_ERR_INVALID = -1, LDIFF_ERR_RUNTIME = -2, LDIFF_ERR_STATE = -3 } ldiff_status;
@@ -219,6 +219,13 @@ typedef struct {
   int gemm_df;                                      /* 1x1 / linear only, producer / consumer ("dataflow") GEMM: 0 = where the executors would pick it (unit list
                                                        fills the chip), -1 = never, 1 = always where the shape is eligible (LDIFF_ERR_INVALID otherwise), 16 mt + ntw
                                                        (mt 4 | 8, ntw 2 | 4 | 5) = always, with units of 16 mt rows x 64 ntw columns (tests, timing) */
+  const void* sc_x;                                 /* 3x3 stride-1 GroupNorm + SiLU convs on the dataflow kernel only: the 1x1 conv_shortcut of a ResnetBlock2D that changes width
+                                                       (diffusers ResnetBlock2D.conv_shortcut), folded into the block's second conv: y = conv3x3(silu(gn(x))) + sc_w . sc_x + bias +
+                                                       sc_bias.  sc_x [B, Hin, Win, sc_C] fp16 (row pitch sc_ld, 0 = sc_C; sc_C % 64 == 0), sc_w [Nrows, sc_C] fp16 K-major,
+                                                       sc_bias [Nrows] fp32 or NULL; no res then.  Shapes the dataflow kernel does not take: LDIFF_ERR_INVALID */
+  int sc_C, sc_ld;
+  const void* sc_w;
+  const void* sc_bias;
 } ldiff_conv_args;
 int ldiff_op_conv(const ldiff_conv_args*, void* stream);
 /* row blocks per image the launch would emit statistics for (0 = unsupported for this shape) */

@@ -477,6 +477,7 @@ static void conv_args_to_params(const ldiff_conv_args* a, ConvParams& p) {
   p.geglu = a->geglu != 0;
   p.lo8_slab0 = a->lo8_slab0; p.lo8_sa = (const int*)a->lo8_scale; p.lo8_sb = a->lo8_slab0 ? 127 - LO8_SHIFT : 0;
   p.df_force = a->gemm_df;
+  p.xs = (const f16*)a->sc_x; p.Cs = a->sc_x ? a->sc_C : 0; p.lds = a->sc_x ? a->sc_ld : 0;
 }
 int ldiff_op_conv(const ldiff_conv_args* a, void* stream) {
   API_BEGIN
@@ -493,9 +494,16 @@ int ldiff_op_conv(const ldiff_conv_args* a, void* stream) {
     p.w_par = wpar;
     if (p.stats) p.stats_R = conv_stats_blocks_per_image(p);
   }
+  LDIFF_CHECK(!p.xs || (a->sc_w && conv3x3_eligible(p) && conv3x3d_selected(p)), LDIFF_ERR_INVALID, "op_conv: a folded shortcut (sc_x) needs sc_w and a launch the dataflow conv3x3 kernel takes");
   if (conv3x3d_selected(p)) {   // dataflow kernel: fragment-packed weights (the executors cache them per layer; here per call)
     f16* wf = (f16*)op_scratch(st, 3, conv3x3d_frag_bytes(p));
     launch_pack_frag_weights(p.w, wf, p.N, p.C1, st);
+    if (p.xs) {   // the folded shortcut's weights behind the nine taps, the two biases summed
+      launch_pack_frag_weights_sc((const f16*)a->sc_w, wf, p.N, p.C1, p.Cs, p.Cs, st);
+      float* bsum = (float*)op_scratch(st, 5, (size_t)p.Nrows * sizeof(float));
+      launch_add_vectors(p.bias, (const float*)a->sc_bias, bsum, p.Nrows, st);
+      p.bias = bsum;
+    }
     p.w_frag = wf;
   }
   const bool df_asked = p.df_force > 0;

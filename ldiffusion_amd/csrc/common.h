@@ -91,6 +91,10 @@ struct ConvParams {
   // 127 - sw written by launch_lo8_weights, lo8_sb = 127 - LO8_SHIFT.  The fp8 slabs go through v_mfma_scale_f32_16x16x128_f8f6f4.
   int lo8_slab0 = 0, lo8_sb = 0;
   const int* lo8_sa = nullptr;
+  // conv3x3 dataflow kernel only: the 1x1 conv_shortcut of a ResnetBlock2D that changes width, folded into the block's second conv -- y = conv3x3(gn(x)) +
+  // W_sc xs + (b + b_sc): the shortcut's Cs input channels are Cs / 64 extra slabs taken at the CENTRE tap only (raw operand, no GroupNorm), their
+  // weights behind the nine taps in w_frag (launch_pack_frag_weights_sc), the two biases summed by the caller.  No residual then.
+  const f16* xs = nullptr; int Cs = 0, lds = 0;
   int df_force = 0;   // dataflow GEMM (gemm_df_selected): 0 = by the unit list, -1 = never, 1 = wherever eligible, 16 mt + ntw = with that unit shape (ldiff_conv_args.gemm_df)
 };
 constexpr int LO8_SHIFT = 15;   // lo = x - fp16(x) of a GroupNorm + SiLU output: |lo| <= half an fp16 ulp = 2^-7 for |x| < 32, so lo * 2^15 <= 256 stays inside e4m3's 448;
@@ -116,6 +120,8 @@ bool conv3x3d_selected(const ConvParams& p);
 int conv3x3d_stats_blocks(const ConvParams& p);
 size_t conv3x3d_frag_bytes(const ConvParams& p);
 void launch_pack_frag_weights(const f16* w, f16* wf, int N, int Cin, hipStream_t s);   // [N][9 Cin] K-major -> MFMA A fragments, one KiB each
+void launch_pack_frag_weights_sc(const f16* wsc, f16* wf, int N, int Cin, int Cs, int ld_wsc, hipStream_t s);   // the folded shortcut's [N][Cs] behind them (ConvParams::xs)
+void launch_add_vectors(const float* a, const float* b, float* out, int n, hipStream_t s);   // out = a + b (either may be null = 0)
 void launch_conv3x3d(const ConvParams& p, hipStream_t s);
 int conv3x3p_stats_blocks(const ConvParams& p);
 void launch_conv3x3p(const ConvParams& p, hipStream_t s);

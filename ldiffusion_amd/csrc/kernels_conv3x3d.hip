@@ -65,7 +65,7 @@ static_assert((16 - D_STG_CHUNKS) * 4096 <= D_HB, "the rest of a staged tile mus
 static_assert(D_LDS <= 160 * 1024, "LDS budget of one workgroup per CU");
 constexpr unsigned D_OOR = 0x80000000u;                                // beyond num_records of every descriptor used here: the load returns zeros
 constexpr int D_NROUND = 11;                                           // pieces per producer wave and slab: 41 = 4 x 10 + 1
-enum { D_RES = 1, D_STATS = 2 };
+enum { D_RES = 1, D_STATS = 2, D_SC = 4 };   // D_SC: the folded 1x1 shortcut (ConvParams::xs) -- a flag of its own so that the other instantiations carry none of its code
 
 __device__ __forceinline__ int d_swzx(int hx) { return (0xcb5888 >> (3 * (hx >> 1))) & 7; }   // column swizzle of the halo image (kernels_conv3x3.hip)
 
@@ -122,6 +122,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3d_kernel(const ConvParams p, co
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const unsigned lds0 = (unsigned)(size_t)(lptr_t*)smem_raw;
   const int Cin = p.C1, nslab = Cin >> 6, ntn = p.N >> 7;
+  const int nsx = (FLAGS & D_SC) ? p.Cs >> 6 : 0, nsl = nslab + nsx;   // slabs of the folded 1x1 shortcut (centre tap only), slabs of a unit in all
   const int H = p.Hout, W = p.Wout, tiles_x = W >> 4, tiles_y = H >> 4;
 
   // this workgroup's run of units (n-tile fastest, then x, y, image); the runs of the workgroups that share an XCD are adjacent
@@ -130,7 +131,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3d_kernel(const ConvParams p, co
   const int sw = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
   const int u0 = (int)((long long)sw * units / G), u1 = (int)((long long)(sw + 1) * units / G);
   const int n_u = u1 - u0;
-  const int total_slabs = n_u * nslab;
+  const int total_slabs = n_u * nsl;
   auto decode = [&](int u) __attribute__((always_inline)) -> UnitC {   // (readfirstlane: descriptors and LDS-DMA bases built from these must be provably uniform)
     UnitC c;
     int t = u / ntn;
@@ -186,7 +187,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3d_kernel(const ConvParams p, co
     }
     // A slab's coordinates: which of this lane's halo pixels lie inside the image (bit r), and a descriptor whose base is halo pixel (0, 0) of
     // the unit (it may lie in front of the tensor for border tiles: only lanes whose pixel is inside are ever given a real offset).
-    struct SlabC { int k, c, u; UnitC un; unsigned vbits; __amdgpu_buffer_rsrc_t xrsrc; };
+    struct SlabC { int k, c, u; UnitC un; unsigned vbits; __amdgpu_buffer_rsrc_t xrsrc, xrsrc2; };   // (xrsrc2: D_SC only)
+    const int lds2 = p.lds ? p.lds : p.Cs;
     auto set_unit = [&](SlabC& sc) __attribute__((always_inline)) {
       sc.un = decode(sc.u);
       unsigned vb = 0;
@@ -201,10 +203,16 @@ __global__ __launch_bounds__(512, 2) void conv3x3d_kernel(const ConvParams p, co
       const unsigned long long xa = (unsigned long long)reinterpret_cast<const char*>(p.x) + (unsigned long long)org;
       const unsigned xlo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)xa), xhi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(xa >> 32));
       sc.xrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)xhi << 32) | xlo), 0, 0x7fffffff, 0x00020000);
+      if constexpr ((FLAGS & D_SC) != 0) {   // the folded shortcut's source: same pixels, its own pitch
+        const long long org2 = ((long long)(sc.un.b * H + sc.un.oy0 - 1) * W + sc.un.ox0 - 1) * lds2 * 2;
+        const unsigned long long xa2 = (unsigned long long)reinterpret_cast<const char*>(p.xs) + (unsigned long long)org2;
+        const unsigned xlo2 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)xa2), xhi2 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(xa2 >> 32));
+        sc.xrsrc2 = __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)xhi2 << 32) | xlo2), 0, 0x7fffffff, 0x00020000);
+      }
     };
     auto advance = [&](SlabC& sc) __attribute__((always_inline)) {   // next slab of the run; the unit's constants are rebuilt when it changes
       ++sc.k;
-      if (++sc.c == nslab) { sc.c = 0; ++sc.u; if (sc.u < u1) set_unit(sc); }
+      if (++sc.c == nsl) { sc.c = 0; ++sc.u; if (sc.u < u1) set_unit(sc); }
     };
     // everything slab `sc` needs from memory, as LDS-DMA: the scale / shift table (2 instructions), the bias / time-embedding table when the
     // slab opens a unit (2, producer wave 0), the raw halo pieces (10, or 11 for producer wave 0).  Returns the number of instructions issued.
@@ -212,7 +220,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3d_kernel(const ConvParams p, co
       const unsigned hbuf = (unsigned)(sc.k % D_NBUF) * D_HB;
       int n = 2;
       {
-        const int voff = lane < 32 ? (sc.un.b * Cin + sc.c * 64) * 4 + (lane & 15) * 16 : (int)D_OOR;
+        const int voff = (lane < 32 && ((FLAGS & D_SC) == 0 || sc.c < nslab)) ? (sc.un.b * Cin + sc.c * 64) * 4 + (lane & 15) * 16 : (int)D_OOR;   // (a shortcut slab: zeros, unused -- the instruction count of a slab stays the same)
         unsigned char* dst = smem_raw + D_AFF + (unsigned)(pw * 3 + sc.k % D_NBUF) * 512u;
 #if defined(__HIP_DEVICE_COMPILE__)   // the host pass rejects this builtin (target feature) and then silently drops the kernel stub
         if (lane < 16) __builtin_amdgcn_raw_ptr_buffer_load_lds(scrsrc, (lptr_t*)dst, 16, voff, 0, 0, 0);
@@ -229,13 +237,19 @@ __global__ __launch_bounds__(512, 2) void conv3x3d_kernel(const ConvParams p, co
 #endif
         n += 2;
       }
+      const bool extra = (FLAGS & D_SC) != 0 && sc.c >= nslab;   // a slab of the folded shortcut: the other source, its own pitch (offsets rebuilt from the pixel coordinates)
       static_for<0, D_NROUND>([&](auto rc_) {
         constexpr int r = decltype(rc_)::value;
         if (r < 10 || pw == 0) {
-          const int voff = ((sc.vbits >> r) & 1u) ? (int)rc_rel[r] : (int)D_OOR;
+          int voff = ((sc.vbits >> r) & 1u) ? (int)rc_rel[r] : (int)D_OOR;
           unsigned char* dst = smem_raw + hbuf + (unsigned)(pw + 4 * r) * 1024u;
 #if defined(__HIP_DEVICE_COMPILE__)
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(sc.xrsrc, (lptr_t*)dst, 16, voff, sc.c * 128, 0, 0);
+          if (extra) {
+            const int hy = (int)(rc_yx[r] >> 8), hx = (int)(rc_yx[r] & 0xff);
+            if ((sc.vbits >> r) & 1u) voff = ((hy * W + hx) * lds2 + (((lane & 7) ^ d_swzx(hx)) << 3)) * 2;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(sc.xrsrc2, (lptr_t*)dst, 16, voff, (sc.c - nslab) * 128, 0, 0);
+          } else
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(sc.xrsrc, (lptr_t*)dst, 16, voff, sc.c * 128, 0, 0);
 #endif
           ++n;
         }
@@ -388,7 +402,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3d_kernel(const ConvParams p, co
     int stored = 0;   // units whose tile has been stored
     for (int k = 0; k < total_slabs; ++k) {
       advance(nxt);
-      const bool store_here = k >= 2 && (k - 1) % nslab == 0;
+      const bool store_here = k >= 2 && (k - 1) % nsl == 0;
       int n_next = 0;
       DSTAMP(q0);
       if (!store_here && nxt.k < total_slabs) {
@@ -405,13 +419,13 @@ __global__ __launch_bounds__(512, 2) void conv3x3d_kernel(const ConvParams p, co
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       DSTAMP(q2);
 #ifndef C3D_ABL_NOXF
-      xform_slab(cur);
+      if ((FLAGS & D_SC) == 0 || cur.c < nslab) xform_slab(cur);   // (a slab of the folded shortcut is a raw operand)
 #endif
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       lds_write32(pflag_addr, (unsigned)k + 1u);
       DSTAMP(q3);
       if (store_here) {
-        const int i = (k - 1) / nslab - 1;
+        const int i = (k - 1) / nsl - 1;
 #ifndef C3D_ABL_NOSTORE
         store_unit(i, (unsigned)((k + 1) % D_NBUF) * D_HB);
 #else
@@ -428,7 +442,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3d_kernel(const ConvParams p, co
       cur = nxt;
     }
 #ifndef C3D_ABL_NOSTORE
-    for (int i = stored; i < n_u; ++i) store_unit(i, (unsigned)(((i + 1) * nslab - 1) % D_NBUF) * D_HB);   // the last unit (one-slab units: the last two)
+    for (int i = stored; i < n_u; ++i) store_unit(i, (unsigned)(((i + 1) * nsl - 1) % D_NBUF) * D_HB);   // the last unit (one-slab units: the last two)
 #endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #ifdef C3D_STAMPS
@@ -574,15 +588,18 @@ __global__ __launch_bounds__(512, 2) void conv3x3d_kernel(const ConvParams p, co
   int k = 0;   // global slab of this workgroup
   for (int u = u0; u < u1; ++u) {
     const bool has_next = u + 1 < u1;
+    // the folded shortcut's weights of this unit's channel tile: behind the nine taps, one 16-KiB block per (slab, channel tile)
+    const char* wx0 = wfrag + (long long)9 * nslab * w_step_bytes + (long long)(cur.n0 >> 7) * 16384;
     for (int c = 0; c < nslab; ++c, ++k) {
-      const bool last_slab = c == nslab - 1;
+      const bool last_slab = c == nsl - 1;
+      const bool to_extra = (FLAGS & D_SC) != 0 && nsx > 0 && c == nslab - 1;   // the next slab is the shortcut's first: its one step is the centre tap
       const unsigned hb = (unsigned)(k % D_NBUF) * D_HB;
       const unsigned hbn = (unsigned)((k + 1) % D_NBUF) * D_HB;
       static_for<0, 9>([&](auto tc) {
         constexpr int T = decltype(tc)::value, ky = T / 3, kx = T % 3;
         constexpr int nky = ((T + 1) % 9) / 3, nkx = (T + 1) % 3;
         // weights of the next step: the next tap of this slab (a tap = nslab slab blocks), or tap 0 of the next slab
-        const char* wn = T == 8 ? wq - (8 * nslab - 1) * w_step_bytes : wq + nslab * w_step_bytes;
+        const char* wn = T == 8 ? (to_extra ? wx0 : wq - (8 * nslab - 1) * w_step_bytes) : wq + nslab * w_step_bytes;
         // entry: in flight are group 0 of k-half 0 (4 LDS reads -> X[0]) and the weights of k-half 0 (4 global loads -> Wf[0])
         // ---- k-half 0 ----
         issue_w(ic_t<1>{}, wq);
@@ -609,7 +626,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3d_kernel(const ConvParams p, co
           lds_wait4<0>(X[1][0], X[1][1], X[1][2], X[1][3]);
           lds_write32(cflag_addr, (unsigned)k + 1u);
           if (!last_slab) { DACC(2, 1); wait_producers((unsigned)k + 2u); }
-          issue_x(ic_t<0>{}, ic_t<0>{}, ic_t<0>{}, ic_t<0>{}, hbn, X[0]);
+          if (to_extra) issue_x(ic_t<0>{}, ic_t<1>{}, ic_t<1>{}, ic_t<0>{}, hbn, X[0]);
+          else issue_x(ic_t<0>{}, ic_t<0>{}, ic_t<0>{}, ic_t<0>{}, hbn, X[0]);
         } else {
           issue_x(ic_t<0>{}, ic_t<nky>{}, ic_t<nkx>{}, ic_t<0>{}, hb, X[0]);
           lds_wait4<4>(X[1][0], X[1][1], X[1][2], X[1][3]);
@@ -618,6 +636,36 @@ __global__ __launch_bounds__(512, 2) void conv3x3d_kernel(const ConvParams p, co
         __builtin_amdgcn_sched_barrier(0);
         wq = wn;
       });
+    }
+    // ---- the folded 1x1 shortcut: one step (the centre tap) per 64-channel slab of its source ----
+    for (int e = 0; e < nsx; ++e, ++k) {
+      const bool last_slab = e == nsx - 1;
+      const unsigned hb = (unsigned)(k % D_NBUF) * D_HB;
+      const unsigned hbn = (unsigned)((k + 1) % D_NBUF) * D_HB;
+      const char* wn = wq + w_step_bytes;   // the next slab's block (behind the last one: padding, loaded and unused)
+      issue_w(ic_t<1>{}, wq);
+      issue_x(ic_t<1>{}, ic_t<1>{}, ic_t<1>{}, ic_t<0>{}, hb, X[1]);
+      lds_wait4<4>(X[0][0], X[0][1], X[0][2], X[0][3]);
+      vm_wait4<4>(Wf[0][0], Wf[0][1], Wf[0][2], Wf[0][3]);
+      mfma16(ic_t<0>{}, ic_t<0>{}, X[0]);
+      __builtin_amdgcn_sched_barrier(0);
+      issue_x(ic_t<0>{}, ic_t<1>{}, ic_t<1>{}, ic_t<1>{}, hb, X[0]);
+      lds_wait4<4>(X[1][0], X[1][1], X[1][2], X[1][3]);
+      mfma16(ic_t<0>{}, ic_t<1>{}, X[1]);
+      __builtin_amdgcn_sched_barrier(0);
+      issue_w(ic_t<0>{}, wn);
+      issue_x(ic_t<1>{}, ic_t<1>{}, ic_t<1>{}, ic_t<1>{}, hb, X[1]);
+      lds_wait4<4>(X[0][0], X[0][1], X[0][2], X[0][3]);
+      vm_wait4<4>(Wf[1][0], Wf[1][1], Wf[1][2], Wf[1][3]);
+      mfma16(ic_t<1>{}, ic_t<0>{}, X[0]);
+      __builtin_amdgcn_sched_barrier(0);
+      lds_wait4<0>(X[1][0], X[1][1], X[1][2], X[1][3]);
+      lds_write32(cflag_addr, (unsigned)k + 1u);
+      if (!last_slab) { DACC(2, 1); wait_producers((unsigned)k + 2u); }
+      issue_x(ic_t<0>{}, ic_t<1>{}, ic_t<1>{}, ic_t<0>{}, hbn, X[0]);
+      mfma16(ic_t<1>{}, ic_t<1>{}, X[1]);
+      __builtin_amdgcn_sched_barrier(0);
+      wq = wn;
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // the unused operands of the unit's last step
     DSTAMP(e0);
@@ -668,6 +716,24 @@ __global__ void pack_frag_weights_kernel(const f16* __restrict__ w, f16* __restr
   *reinterpret_cast<uint4*>(wf + t * 8) = *reinterpret_cast<const uint4*>(w + (long long)n * 9 * Cin + k);
 }
 
+// the folded shortcut's [N][Cs] (row pitch ld) behind the nine taps: block (slab e, channel tile nt) at 9 nslab ntn + e ntn + nt, same fragment order
+__global__ void pack_frag_weights_sc_kernel(const f16* __restrict__ wsc, f16* __restrict__ wf, int N, int Cin, int Cs, int ld) {
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int nslab = Cin >> 6, nsx = Cs >> 6, ntn = N >> 7;
+  const long long total = (long long)nsx * ntn * 16 * 64;
+  if (t >= total) return;
+  const int lane = (int)(t & 63);
+  long long f = t >> 6;
+  const int kh = (int)(f & 1); f >>= 1;
+  const int a = (int)(f & 3); f >>= 2;
+  const int wn = (int)(f & 1); f >>= 1;
+  const int nt = (int)(f % ntn);
+  const int e = (int)(f / ntn);
+  const int n = nt * 128 + wn * 64 + a * 16 + (lane & 15);
+  const int k = e * 64 + kh * 32 + (lane >> 4) * 8;
+  *reinterpret_cast<uint4*>(wf + ((long long)9 * nslab * ntn * 1024 + t) * 8) = *reinterpret_cast<const uint4*>(wsc + (long long)n * ld + k);
+}
+
 int d_num_cus() {
   static std::mutex mu;
   static std::map<int, int> cus;
@@ -696,13 +762,18 @@ void launch_c3d(const ConvParams& p, hipStream_t s) {
   int grid = units < d_num_cus() ? units : d_num_cus();
   if (run_cap > 0 && units > grid * run_cap) grid = (units + run_cap - 1) / run_cap;
   const double bytes = (double)p.B * p.Hin * p.Win * p.C1 * 2.0 + (double)p.N * p.K * 2.0 + (double)p.M * p.N * 2.0 + (p.res ? (double)p.M * p.N * 2.0 : 0.0);
-  ProfScope prof("conv3x3<16x16d,128,gn>", 2.0 * p.M * (double)p.N * p.K, bytes, s);
+  ProfScope prof("conv3x3<16x16d,128,gn>", 2.0 * p.M * (double)p.N * (p.K + p.Cs), bytes + (double)p.M * p.Cs * 2.0 + (double)p.N * p.Cs * 2.0, s);
   hipLaunchKernelGGL(kern, dim3(grid), dim3(512), D_LDS, s, p, units);
   HIP_CHECK(hipGetLastError());
 }
 
 }  // namespace
 
+void launch_pack_frag_weights_sc(const f16* wsc, f16* wf, int N, int Cin, int Cs, int ld_wsc, hipStream_t s) {
+  const long long total = (long long)(Cs >> 6) * (N >> 7) * 16 * 64;
+  hipLaunchKernelGGL(pack_frag_weights_sc_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, wsc, wf, N, Cin, Cs, ld_wsc);
+  HIP_CHECK(hipGetLastError());
+}
 void launch_pack_frag_weights(const f16* w, f16* wf, int N, int Cin, hipStream_t s) {
   const long long total = (long long)9 * (Cin >> 6) * (N >> 7) * 16 * 64;
   hipLaunchKernelGGL(pack_frag_weights_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w, wf, N, Cin);
@@ -717,6 +788,7 @@ bool conv3x3d_selected(const ConvParams& p) {
   if (!p.gn_scale || !p.silu_in || p.x2 || p.C2 != 0 || p.C1 % 64 != 0 || p.N % 128 != 0 || p.Nrows < p.N) return false;
   if (p.Hout % 16 != 0 || p.Wout % 16 != 0 || p.Hin != p.Hout || p.Win != p.Wout) return false;
   if (p.out_f32 || p.y_lo || p.res_lo || (p.ldy & 7) || (p.res && (p.ld_res & 7))) return false;
+  if (p.xs && (p.res || p.Cs % 64 != 0 || p.Cs <= 0 || ((p.lds ? p.lds : p.Cs) & 7) || (long long)p.B * p.Hin * p.Win * (p.lds ? p.lds : p.Cs) * 2 >= (1LL << 31))) return false;
   const long long px = (long long)p.B * p.Hin * p.Win;
   if (px * (p.ld1 ? p.ld1 : p.C1) * 2 >= (1LL << 31) || (long long)p.M * p.ldy * 2 >= (1LL << 31) || (p.res && (long long)p.M * p.ld_res * 2 >= (1LL << 31))) return false;
   if ((long long)p.Nrows * 9 * p.C1 * 2 >= (1LL << 31)) return false;
@@ -726,7 +798,8 @@ bool conv3x3d_selected(const ConvParams& p) {
   const long long rounds = (units + cus - 1) / cus;
   return units >= cus && units * 100 >= rounds * cus * 88;   // the runs must split evenly over the CUs
 }
-size_t conv3x3d_frag_bytes(const ConvParams& p) { return (size_t)p.N * 9 * p.C1 * sizeof(f16); }
+// (+ the folded shortcut's blocks and, behind them, one unread step of padding: the consumers load one step ahead)
+size_t conv3x3d_frag_bytes(const ConvParams& p) { return (size_t)p.N * (9 * p.C1 + p.Cs) * sizeof(f16) + (p.Cs ? (size_t)(p.N >> 7) * 16384 + 16384 : 0); }
 int conv3x3d_stats_blocks(const ConvParams& p) { return (p.Hout >> 4) * (p.Wout >> 4) * 2; }   // one row block per consumer wave pair (8 x 16 pixels)
 #ifdef C3D_STAMPS
 extern "C" int ldiff_debug_c3d_stamps(unsigned long long* out) {   // diagnostic build only
@@ -735,9 +808,12 @@ extern "C" int ldiff_debug_c3d_stamps(unsigned long long* out) {   // diagnostic
 #endif
 void launch_conv3x3d(const ConvParams& p, hipStream_t s) {
   LDIFF_CHECK(p.w_frag != nullptr, LDIFF_ERR_INVALID, "conv3x3 (dataflow): the caller did not provide the fragment-packed weights (launch_pack_frag_weights)");
-  const int f = (p.res ? D_RES : 0) | (p.stats ? D_STATS : 0);
+  const int f = (p.res ? D_RES : 0) | (p.stats ? D_STATS : 0) | (p.xs ? D_SC : 0);
   if (f == 0) launch_c3d<0>(p, s);
   else if (f == 1) launch_c3d<1>(p, s);
   else if (f == 2) launch_c3d<2>(p, s);
-  else launch_c3d<3>(p, s);
+  else if (f == 3) launch_c3d<3>(p, s);
+  else if (f == D_SC) launch_c3d<D_SC>(p, s);
+  else if (f == (D_SC | D_STATS)) launch_c3d<D_SC | D_STATS>(p, s);
+  else LDIFF_CHECK(false, LDIFF_ERR_INVALID, "conv3x3 (dataflow): a folded shortcut replaces the residual");
 }

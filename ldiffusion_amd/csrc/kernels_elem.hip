@@ -115,6 +115,15 @@ __global__ void lo8_weights_kernel(const f16* __restrict__ w, unsigned char* __r
   q0 = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], q0, true); q1 = __builtin_amdgcn_cvt_pk_fp8_f32(f[6], f[7], q1, true);
   *reinterpret_cast<int2*>(row + 2 * Cin + c) = make_int2(q0, q1);
 }
+__global__ void add_vectors_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = (a ? a[i] : 0.f) + (b ? b[i] : 0.f);
+}
+void launch_add_vectors(const float* a, const float* b, float* out, int n, hipStream_t s) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(add_vectors_kernel, dim3((n + 255) / 256), dim3(256), 0, s, a, b, out, n);
+  HIP_CHECK(hipGetLastError());
+}
 void launch_lo8_weights(const f16* w, void* wd, int* scale_out, int Nrows, int taps, int Cin, hipStream_t s) {
   LDIFF_CHECK(w && wd && scale_out && Cin % 128 == 0 && Nrows > 0 && taps > 0, LDIFF_ERR_INVALID, "lo8_weights: Cin %d must be a multiple of 128", Cin);
   const long long rows = (long long)Nrows * taps, n = rows * (Cin >> 3);

@@ -43,6 +43,8 @@ struct MatW {   // [Nrows][K] fp16 K-major + fp32 bias
   mutable Derived dup;            //   split operand: [Nrows][taps][2*Cin] (same weights against the hi and the lo half); key = C1 of a concat
   mutable Derived dup_par;        //   parity weights of the duplicated matrix
   mutable Derived frag;           //   MFMA-fragment-packed copy for the dataflow conv3x3 kernel (kernels_conv3x3d.hip)
+  mutable Derived frag_sc;        //   ... with a folded shortcut's weights behind the nine taps (key = the shortcut matrix's address bits) and the summed bias
+  mutable float* bias_sc = nullptr;
   mutable Derived gfrag;          //   MFMA-fragment-packed copy for the dataflow GEMM (kernels_gemm_df.hip)
   mutable Derived gfrag_dup;      //   the same of the duplicated (split-operand) matrix; key = C1 of a concat
   mutable Derived tiled;          //   panel-tiled copy for the LayerNorm-fused GEMM (kernels_gemm_ast.hip)
@@ -103,6 +105,9 @@ struct ConvOpts {
   // decode_latents tail in the epilogue (VAE conv_out): applied iff the narrow-output kernel takes the launch; *post_done says whether it did
   float* post_img = nullptr; uint8_t* post_rgb = nullptr; uint8_t* post_luma = nullptr; int post_slots = 0, post_slot = 0; bool post_only = false;
   bool* post_done = nullptr;
+  // the block's 1x1 conv_shortcut folded into this (its second) conv where the dataflow conv3x3 kernel takes the launch (ConvParams::xs): sc_x = the block's
+  // input, sc_w = the shortcut's weights; *sc_done says whether the fold happened (else the caller runs the shortcut conv and passes its output as res)
+  const Act* sc_x = nullptr; const struct MatW* sc_w = nullptr; bool* sc_done = nullptr;
 };
 
 class Exec {
@@ -120,6 +125,7 @@ class Exec {
   const f16* derived_dup(const MatW& w, int C1_logical, int C2_logical);
   const f16* derived_par(const MatW& w, const f16* src, int Cin, Derived& d);
   const f16* derived_frag(const MatW& w, const ConvParams& p);
+  const f16* derived_frag_sc(const MatW& w, const MatW& sc, const ConvParams& p, const float** bias_sum);   // ... + the folded shortcut
   const f16* derived_tiled(const MatW& w, int N);
   const f16* derived_gfrag(const MatW& w, const f16* src, int K, Derived& d, int key);   // fragment-packed copy of `src` [Nrows][K] for the dataflow GEMM
   const f16* derived_lo8(const MatW& w, const int** scale);   // fp8-lo weights of a split operand + the device int holding their E8M0 scale operand

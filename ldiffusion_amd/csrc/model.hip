@@ -323,6 +323,27 @@ const f16* Exec::derived_frag(const MatW& w, const ConvParams& p) {
   }
   return w.frag.p;
 }
+const f16* Exec::derived_frag_sc(const MatW& w, const MatW& sc, const ConvParams& p, const float** bias_sum) {
+  const int gen = weights_gen ? *weights_gen : 0;
+  if (!w.frag_sc.p) {
+    void* q = nullptr;
+    HIP_CHECK(hipMalloc(&q, conv3x3d_frag_bytes(p)));
+    HIP_CHECK(hipMemset(q, 0, conv3x3d_frag_bytes(p)));   // (the padding step behind the shortcut's blocks is loaded, never used)
+    owned.push_back(q);
+    w.frag_sc.p = (f16*)q;
+    HIP_CHECK(hipMalloc(&q, (size_t)w.Nrows * sizeof(float)));
+    owned.push_back(q);
+    w.bias_sc = (float*)q;
+  }
+  if (w.frag_sc.gen != gen) {   // first use, or the checkpoint was reloaded since
+    launch_pack_frag_weights(w.w, w.frag_sc.p, p.N, p.C1, s);
+    launch_pack_frag_weights_sc(sc.w, w.frag_sc.p, p.N, p.C1, p.Cs, sc.K, s);
+    launch_add_vectors(w.b, sc.b, w.bias_sc, w.Nrows, s);
+    w.frag_sc.gen = gen;
+  }
+  *bias_sum = w.bias_sc;
+  return w.frag_sc.p;
+}
 const f16* Exec::derived_tiled(const MatW& w, int N) {
   const int gen = weights_gen ? *weights_gen : 0;
   if (!w.tiled.p) {
@@ -460,7 +481,25 @@ Act Exec::conv(const MatW& w, const Act& x, const Act* x2, const ConvOpts& o) {
   if (!o.out_f32 && p.splitk > 1) p.splitk_ws = tmp<float>((size_t)p.splitk * p.M * p.N);
   else p.splitk = 0;
   p.short_runs = short_runs ? 1 : 0;
-  if (!o.split_in && conv3x3_eligible(p) && conv3x3d_selected(p)) p.w_frag = derived_frag(w, p);   // dataflow kernel: MFMA-fragment-packed weights
+  if (o.sc_done) *o.sc_done = false;
+  if (o.sc_x && o.sc_w && o.sc_done && !o.split_in && !o.res && !o.sc_x->split && o.sc_w->ks == 1 && o.sc_w->Nrows == w.Nrows) {
+    // fold the block's 1x1 shortcut into this conv where the dataflow kernel takes the launch (LDIFF_C3D_FOLD_SC=0: never)
+    static const bool fold = [] { const char* e = getenv("LDIFF_C3D_FOLD_SC"); return !e || atoi(e) != 0; }();
+    ConvParams q = p;
+    q.xs = o.sc_x->p; q.Cs = o.sc_x->C; q.lds = o.sc_x->ld();
+    if (fold && o.sc_w->K == q.Cs && conv3x3_eligible(q) && conv3x3d_selected(q)) {
+      p = q;
+      p.w_frag = derived_frag_sc(w, *o.sc_w, p, &p.bias);
+      *o.sc_done = true;
+    }
+  }
+  if (o.sc_x && !p.xs) {   // asked for the folded form only: nothing is launched, the caller takes the two-launch form
+    if (p.splitk_ws) arena.free(p.splitk_ws);
+    release(y);
+    return Act{};
+  }
+  if (p.xs) {}
+  else if (!o.split_in && conv3x3_eligible(p) && conv3x3d_selected(p)) p.w_frag = derived_frag(w, p);   // dataflow kernel: MFMA-fragment-packed weights
   else if (!wfold && w.ks == 1 && !(o.split_in && x.lo8) && !conv3x3_eligible(p) && gemm_df_selected(p))   // dataflow GEMM: the same, of the matrix this launch reads
     p.w_frag = derived_gfrag(w, wsrc, p.K, o.split_in ? w.gfrag_dup : w.gfrag, o.split_in ? x.C : 0);
   launch_igemm(p, s);
@@ -534,15 +573,29 @@ Act Exec::resnet(const ResnetW& r, const Act& x, const Act* skip, const float* t
   GNss g2 = gn(h, nullptr, r.n2, groups, eps);
   Act sc;
   const Act* resp = &x;
+  ConvOpts o2;
+  o2.want_stats = true; o2.split_out = st;
+  Act out;
+  if (r.has_sc && !st && !skip) {
+    // plain graph (the VAE decoder's two width-changing blocks): try the shortcut as extra centre-tap slabs of conv2 on the dataflow kernel -- no
+    // 1x1 launch, no round trip of its output through memory, the sum in fp32.  Where the kernel does not take the launch: the two-launch form below.
+    bool folded = false;
+    ConvOpts of = o2;
+    of.gn = &g2; of.silu = 1; of.sc_x = &x; of.sc_w = &r.sc; of.sc_done = &folded;
+    out = conv(r.c2, h, nullptr, of);   // (launches nothing and returns an empty tensor when it cannot fold)
+    if (folded) {
+      release(g2);
+      release(h);
+      return out;
+    }
+  }
   if (r.has_sc) {
     ConvOpts os;
     os.split_in = st; os.split_out = st;
     sc = conv(r.sc, x, skip, os);
     resp = &sc;
   }
-  ConvOpts o2;
-  o2.res = resp; o2.want_stats = true; o2.split_out = st;
-  Act out;
+  o2.res = resp;
   if (full) {
     Act a = norm_apply(h, nullptr, g2, true, true, lo8_conv_ok(r.c2, h, true, o2.split_out));
     o2.split_in = true;

@@ -8,7 +8,9 @@ from ldiffusion_amd import _lib
 lib = _lib.load()
 sp = C.c_void_p(torch.cuda.current_stream().cuda_stream)
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 100
-for (B, Cin, H, Cout, res, stats) in [(8, 128, 512, 128, 1, 1), (8, 128, 512, 128, 0, 1), (8, 256, 256, 256, 1, 1), (8, 512, 128, 512, 0, 0), (3, 128, 256, 128, 1, 1)]:
+# (B, Cin, H, Cout, residual, statistics, channels of a folded 1x1 shortcut or 0)
+for (B, Cin, H, Cout, res, stats, Cs) in [(8, 128, 512, 128, 1, 1, 0), (8, 128, 512, 128, 0, 1, 0), (8, 256, 256, 256, 1, 1, 0), (8, 512, 128, 512, 0, 0, 0), (3, 128, 256, 128, 1, 1, 0),
+                                          (8, 128, 512, 128, 0, 1, 256), (8, 256, 256, 256, 0, 1, 512), (3, 128, 256, 128, 0, 0, 256)]:
     g = torch.Generator().manual_seed(B + Cin)
     x = torch.randn((B, H, H, Cin), generator=g).to(torch.float16).cuda()
     w = (torch.randn((Cout, 9 * Cin), generator=g) / math.sqrt(9 * Cin)).to(torch.float16).cuda()
@@ -22,6 +24,11 @@ for (B, Cin, H, Cout, res, stats) in [(8, 128, 512, 128, 1, 1), (8, 128, 512, 12
     if res:
         r = torch.randn((B, H, H, Cout), generator=g).to(torch.float16).cuda()
         a.res, a.ld_res = r.data_ptr(), Cout
+    if Cs:
+        xs = torch.randn((B, H, H, Cs), generator=g).to(torch.float16).cuda()
+        wsc = (torch.randn((Cout, Cs), generator=g) / math.sqrt(Cs)).to(torch.float16).cuda()
+        bsc = torch.randn(Cout, generator=g).cuda()
+        a.sc_x, a.sc_C, a.sc_ld, a.sc_w, a.sc_bias = xs.data_ptr(), Cs, Cs, wsc.data_ptr(), bsc.data_ptr()
     st = None
     if stats:
         R = lib.ldiff_op_conv_stats_blocks(C.byref(a))
@@ -40,6 +47,6 @@ for (B, Cin, H, Cout, res, stats) in [(8, 128, 512, 128, 1, 1), (8, 128, 512, 12
             assert torch.isfinite(ref_y).all() and (ref_s is None or torch.isfinite(ref_s).all())
         else:
             bad += int(not torch.equal(y, ref_y)) + int(st is not None and not torch.equal(st, ref_s))
-    print(f"B{B} Cin{Cin} H{H} Cout{Cout} res{res} stats{stats}: {reps} launches, {bad} differ from the first", flush=True)
+    print(f"B{B} Cin{Cin} H{H} Cout{Cout} res{res} stats{stats} folded shortcut {Cs}: {reps} launches, {bad} differ from the first", flush=True)
     assert bad == 0
 print("ok")

@@ -943,6 +943,80 @@ def test_conv3x3_dataflow_kernel(lib, shape, res, stats, temb):
             assert err <= 1e-4, f"launch {it}: fused statistics differ from the sums of the outputs by {err:.3e}"
 
 
+@pytest.mark.parametrize("shape", ["vae_256_to_128", "vae_512_to_256", "one_slab_each", "vae_256_to_128_short_runs", "pitched_source"])
+@pytest.mark.parametrize("stats", [0, 1])
+def test_conv3x3_dataflow_kernel_with_folded_shortcut(lib, shape, stats):
+    """ldiff_conv_args.sc_*: the 1x1 conv_shortcut of a width-changing ResnetBlock2D as extra centre-tap slabs of the block's second conv on the
+    producer / consumer kernel (raw operand, no GroupNorm; weights behind the nine taps; biases summed): y = conv3x3(silu(gn(x))) + sc_w . sc_x + b + b_sc,
+    against torch fp32 on the operands the kernel sees.  Persistent runs of several units and one unit per workgroup, with and without the fused
+    statistics, a source read through a row pitch; three launches each (progress words: a missing wait shows up as a now-and-then wrong tile)."""
+    short = shape.endswith("_short_runs")
+    B, Cin, H, W, Cout, Cs = {"vae_256_to_128": (3, 128, 256, 256, 128, 256), "vae_512_to_256": (2, 256, 128, 128, 256, 512), "one_slab_each": (2, 64, 256, 256, 128, 64),
+                              "pitched_source": (2, 128, 256, 256, 128, 192)}[shape.replace("_short_runs", "")]
+    g = torch.Generator().manual_seed(stats + len(shape))
+    x = torch.randn((B, H, W, Cin), generator=g).to(torch.float16)
+    pitch = Cs + 64 if shape == "pitched_source" else Cs
+    xs_full = torch.randn((B, H, W, pitch), generator=g).to(torch.float16)
+    xs = xs_full[..., :Cs]
+    w = (torch.randn((Cout, 3, 3, Cin), generator=g) / math.sqrt(9 * Cin)).to(torch.float16)
+    wsc = (torch.randn((Cout, Cs), generator=g) / math.sqrt(Cs)).to(torch.float16)
+    bias, bsc = torch.randn(Cout, generator=g) * 0.1, torch.randn(Cout, generator=g) * 0.1
+    sc, sh = 1.0 + 0.2 * torch.randn((B, Cin), generator=g), 0.2 * torch.randn((B, Cin), generator=g)
+    a = F.silu(x.float() * sc[:, None, None, :] + sh[:, None, None, :]).to(torch.float16).float()
+    ref = F.conv2d(a.permute(0, 3, 1, 2), w.float().permute(0, 3, 1, 2), bias, padding=1)
+    ref = ref + F.conv2d(xs.float().permute(0, 3, 1, 2), wsc.float()[:, :, None, None], bsc)
+    xd, xsd, wd, wscd = x.to(DEV), xs_full.to(DEV), w.reshape(Cout, -1).contiguous().to(DEV), wsc.contiguous().to(DEV)
+    bd, bscd, scd, shd = bias.to(DEV), bsc.to(DEV), sc.to(DEV), sh.to(DEV)
+    a_ = _lib.ConvArgs()
+    a_.x, a_.C1, a_.B, a_.Hin, a_.Win, a_.Hout, a_.Wout = xd.data_ptr(), Cin, B, H, W, H, W
+    a_.ks, a_.stride, a_.pad_t, a_.pad_l = 3, 1, 1, 1
+    a_.w, a_.N, a_.Nrows, a_.bias = wd.data_ptr(), Cout, Cout, bd.data_ptr()
+    a_.gn_scale, a_.gn_shift, a_.silu_in = scd.data_ptr(), shd.data_ptr(), 1
+    a_.short_runs = 1 if short else 0
+    a_.sc_x, a_.sc_C, a_.sc_ld, a_.sc_w, a_.sc_bias = xsd.data_ptr(), Cs, pitch, wscd.data_ptr(), bscd.data_ptr()
+    y = torch.empty((B, H, W, Cout), dtype=torch.float16, device=DEV)
+    a_.y, a_.ldy = y.data_ptr(), Cout
+    if stats:
+        R = lib.ldiff_op_conv_stats_blocks(C.byref(a_))
+        assert R > 0
+        st = torch.empty((B, Cout, R, 2), device=DEV)
+        a_.stats = st.data_ptr()
+    first = None
+    for it in range(3):
+        y.fill_(float("nan"))
+        if stats:
+            st.fill_(float("nan"))
+        _lib.check(lib.ldiff_op_conv(C.byref(a_), sp()))
+        torch.cuda.synchronize()
+        assert_close(y.float().cpu().permute(0, 3, 1, 2), ref, f"{shape} launch {it}")
+        if first is None:
+            first = y.clone()
+        assert torch.equal(y, first), f"launch {it} differs from the first"
+        if stats:
+            sums = st.double().cpu().sum(dim=2)
+            yd = y.double().cpu()
+            want = torch.stack([yd.sum(dim=(1, 2)), (yd * yd).sum(dim=(1, 2))], dim=-1)
+            assert torch.isfinite(sums).all()
+            assert ((sums - want).abs() / (want.abs() + H * W * 1e-3)).max().item() <= 1e-4
+    # what it replaces: the shortcut as its own 1x1 launch, its fp16 output as the residual of the 3x3 conv (two roundings more): same result to fp16 noise
+    ysc = torch.empty((B, H, W, Cout), dtype=torch.float16, device=DEV)
+    b_ = _lib.ConvArgs()
+    b_.x, b_.C1, b_.ld1, b_.B, b_.Hin, b_.Win, b_.Hout, b_.Wout, b_.ks, b_.stride = xsd.data_ptr(), Cs, pitch, B, H, W, H, W, 1, 1
+    b_.w, b_.N, b_.Nrows, b_.bias, b_.y, b_.ldy = wscd.data_ptr(), Cout, Cout, bscd.data_ptr(), ysc.data_ptr(), Cout
+    _lib.check(lib.ldiff_op_conv(C.byref(b_), sp()))
+    a_.sc_x, a_.sc_w, a_.sc_bias, a_.sc_C, a_.sc_ld = None, None, None, 0, 0
+    a_.res, a_.ld_res, a_.stats = ysc.data_ptr(), Cout, None
+    y2 = torch.empty_like(y)
+    a_.y = y2.data_ptr()
+    _lib.check(lib.ldiff_op_conv(C.byref(a_), sp()))
+    torch.cuda.synchronize()
+    assert (y2.float() - first.float()).abs().max().item() <= 4e-3 * max(1.0, ref.abs().max().item())
+    # shapes the kernel does not take are refused, not silently run without the shortcut
+    a_.res, a_.ld_res, a_.sc_x, a_.sc_C, a_.sc_ld, a_.sc_w = None, 0, xsd.data_ptr(), Cs - 32, pitch, wscd.data_ptr()
+    with pytest.raises(ValueError):
+        _lib.check(lib.ldiff_op_conv(C.byref(a_), sp()))
+
+
 @pytest.mark.parametrize("shape", ["one_tile_per_workgroup", "two_tiles_per_workgroup"])
 @pytest.mark.parametrize("res,lo,stats", [(r, l, s_) for r in (0, 1) for l in (0, 1) for s_ in (0, 1)])
 def test_conv3x3_persistent_kernel_epilogue_configs(lib, shape, res, lo, stats):

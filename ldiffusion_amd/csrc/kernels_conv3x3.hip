@@ -721,16 +721,28 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const ConvParams p) 
   if (i >= (long long)p.M * n4) return;
   const long long m = i / n4;
   const int n = (int)(i - m * n4) * 4;
+  // every partial (and the epilogue's operands below) is loaded BEFORE the first add: as a plain `for s: v += load` the compiler waits for each load
+  // in turn, eight dependent memory round trips per thread = 14.6 us per launch on 40 launches of a UNet pass (round 5; the sum order is unchanged)
+  const float* wsp = p.splitk_ws + m * p.N + n;
+  const long long sstride = (long long)p.M * p.N;
+  f32x4 part[8];
+  const int S = p.splitk;
+#pragma unroll
+  for (int s = 0; s < 8; ++s) part[s] = *reinterpret_cast<const f32x4*>(wsp + (s < S ? s : S - 1) * sstride);   // (unconditional: a slot beyond S re-reads the last one, unused)
+  // (null operands read a valid dummy address -- the partials -- and are masked out: no branch, hence no wait, between the loads)
+  const float4 tb = *reinterpret_cast<const float4*>(p.bias ? p.bias + n : wsp);
+  const float4 tt = *reinterpret_cast<const float4*>(p.temb ? p.temb + (m / ((long long)p.Hout * p.Wout)) * p.ld_temb + n : wsp);
+  const f16x4 rh = *reinterpret_cast<const f16x4*>(p.res ? p.res + m * p.ld_res + n : reinterpret_cast<const f16*>(wsp));
+  const f16x4 rl = *reinterpret_cast<const f16x4*>((p.res && p.res_lo) ? p.res + m * p.ld_res + p.res_lo + n : reinterpret_cast<const f16*>(wsp));
   f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
-  for (int s = 0; s < p.splitk; ++s) v += *reinterpret_cast<const f32x4*>(p.splitk_ws + ((long long)s * p.M + m) * p.N + n);
-  if (p.bias) { const float4 t = *reinterpret_cast<const float4*>(p.bias + n); v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w; }
-  if (p.temb) {
-    const float4 t = *reinterpret_cast<const float4*>(p.temb + (m / ((long long)p.Hout * p.Wout)) * p.ld_temb + n);
-    v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
-  }
+#pragma unroll
+  for (int s = 0; s < 8; ++s) if (s < S) v += part[s];
+  for (int s = 8; s < S; ++s) v += *reinterpret_cast<const f32x4*>(wsp + s * sstride);   // (plans stop at 8 splits; kept for callers of the op entry)
+  if (p.bias) { v[0] += tb.x; v[1] += tb.y; v[2] += tb.z; v[3] += tb.w; }
+  if (p.temb) { v[0] += tt.x; v[1] += tt.y; v[2] += tt.z; v[3] += tt.w; }
   if (p.res) {
-    v += up4(*reinterpret_cast<const f16x4*>(p.res + m * p.ld_res + n));
-    if (p.res_lo) v += up4(*reinterpret_cast<const f16x4*>(p.res + m * p.ld_res + p.res_lo + n));
+    v += up4(rh);
+    if (p.res_lo) v += up4(rl);
   }
   if (p.out_f32) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.y) + m * p.ldy + n) = v;
   else {

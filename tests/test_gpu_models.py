@@ -323,6 +323,32 @@ def test_sd15_width_unet_and_vae_against_oracle():
     assert e_u <= 1e-3 and e_e <= 3e-4 and e_d <= 4e-3
 
 
+@pytest.mark.timeout(900)
+def test_unet_pass_is_bit_identical_with_and_without_the_dataflow_kernels():
+    """The executors send a 1x1 conv / linear to gemm_df_kernel or gemm_dma_kernel by its row count (and the VAE decoder's shortcut convs into the
+    dataflow conv or not): the kernels are built to add in the same order, so one SD-v1.5-width UNet pass must come out BIT FOR BIT the same with
+    LDIFF_GEMM_DF=0 and =1 (the switch is read once per process: two child processes, CRC32 of the fp32 output)."""
+    import subprocess
+    import sys
+    code = (
+        "import sys, zlib, torch; sys.path.insert(0, %r)\n"
+        "from ldiffusion_amd import configs, weights\n"
+        "from ldiffusion_amd.models import UNet2DConditionModel\n"
+        "ucfg = configs.SD15_UNET\n"
+        "unet = UNet2DConditionModel(ucfg, weights.synthetic_state_dict(weights.unet_param_shapes(ucfg), 42, fp16_values=True), 'cuda:0')\n"
+        "g = torch.Generator().manual_seed(5)\n"
+        "x = torch.randn((2, 4, 64, 64), generator=g).cuda(); ctx = (torch.randn((1, 6, 768), generator=g) * 0.5).cuda()\n"
+        "y = unet(x, 501, ctx).sample; torch.cuda.synchronize()\n"
+        "assert torch.isfinite(y).all()\n"
+        "print('CRC', zlib.crc32(y.cpu().numpy().tobytes()))\n" % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    crcs = []
+    for v in ("0", "1"):
+        out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, LDIFF_GEMM_DF=v), capture_output=True, text=True, timeout=400)
+        assert out.returncode == 0, out.stderr[-2000:]
+        crcs.append([l for l in out.stdout.splitlines() if l.startswith("CRC")][-1])
+    assert crcs[0] == crcs[1], f"UNet output differs between LDIFF_GEMM_DF=0 and 1: {crcs}"
+
+
 @pytest.mark.timeout(2400)
 def test_config1_sd15_width_512_five_passes_against_oracle():
     """BASELINE.json configs[1] at its real size: SD-v1.5-width UNet + VAE (fp16 checkpoint values), 512x512 patches, the 5-pass

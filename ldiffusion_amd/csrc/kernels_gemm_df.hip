@@ -12,7 +12,7 @@
 //     column tiles {4 a + w}: MT x NTW accumulator tiles.  The WEIGHTS of a step come straight from global memory (L2) into registers -- the
 //     matrix is stored fragment-packed per layer (launch_pack_gemm_frag: every 16 x 32 MFMA A fragment is one contiguous KiB), NTW
 //     global_load_dwordx4 per k-half issued one k-half ahead, counted vmcnt.  The ACTIVATIONS come from a ring of F_S slots in LDS (one slot =
-//     16 MT rows x 64 k, the swizzled image of kernels_gemm.hip), rows in groups of four one group ahead, counted lgkmcnt.  At the end of a unit
+//     16 MT rows x 64 k, the swizzled image of kernels_gemm.hip), row tiles in groups of two one group ahead, counted lgkmcnt.  At the end of a unit
 //     a consumer writes its fp32 sums to LDS in 64-column slices and goes on with the next unit.
 //   * waves 4 .. 4+NLOAD-1: LOADERS.  Free-running LDS-DMA of the activation slots, up to F_S - 1 steps ahead across unit boundaries (counted
 //     vmcnt; nothing asynchronous targets a VGPR).
@@ -70,10 +70,6 @@ __device__ __forceinline__ int swz8(int row, int chunk) { return chunk ^ ((row >
 template <int OFF>
 __device__ __forceinline__ void lds_read128(f16x8& d, unsigned addr) {
   asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF) : "memory");
-}
-template <int CNT>
-__device__ __forceinline__ void lds_wait4(f16x8& a, f16x8& b, f16x8& c, f16x8& d) {
-  asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(CNT));
 }
 template <int CNT>
 __device__ __forceinline__ void lds_wait2(f16x8& a, f16x8& b) { asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "n"(CNT)); }

@@ -331,3 +331,26 @@ def test_non_finite_gradient_skips_the_update_and_halves_the_loss_scale():
     qs[0].grad = torch.tensor([2.0, 0, 0, 0, 0])
     assert train.finish_step(qs, state, 0.1, 0.0, None, optimizer=opt) is True
     assert opt.step_count == 1 and torch.allclose(qs[0].data, torch.tensor([0.8, 1, 1, 1, 1]))
+
+
+def test_ctypes_struct_mirrors_have_the_headers_layout(tmp_path):
+    """Every struct the C ABI passes by pointer (include/ldiff.h) against its ctypes mirror in _lib.py: same size and the same offset for every
+    field, as gcc lays the header out -- an appended or reordered field on one side only would otherwise be read as garbage, not fail."""
+    pairs = {"ldiff_unet_cfg": _lib.UNetCfg, "ldiff_vae_cfg": _lib.VaeCfg, "ldiff_conv_args": _lib.ConvArgs, "ldiff_prof_row": _lib.ProfRow}
+    hdr = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "ldiff.h")).read(), flags=re.S)
+    assert set(re.findall(r"typedef struct\s*{[^}]*}\s*(ldiff_[a-z0-9_]+)\s*;", hdr)) == set(pairs), "a struct of the header has no ctypes mirror in this test"
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "ldiff.h"', 'int main(void) {']
+    for cname, cls in pairs.items():
+        lines.append(f'  printf("{cname} . %zu\\n", sizeof({cname}));')
+        lines += [f'  printf("{cname} {f[0]} %zu\\n", offsetof({cname}, {f[0]}));' for f in cls._fields_]
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines + ["  return 0;", "}"]))
+    subprocess.run(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(tmp_path / "layout")], check=True)
+    got = {tuple(l.split()[:2]): int(l.split()[2]) for l in subprocess.run([str(tmp_path / "layout")], check=True, capture_output=True, text=True).stdout.splitlines()}
+    for cname, cls in pairs.items():
+        body = re.search(r"typedef struct\s*{([^}]*)}\s*" + cname, hdr).group(1)
+        names = [n for decl in body.split(";") for n in re.findall(r"(\w+)\s*(?:\[[^\]]*\])?\s*(?:,|$)", re.sub(r"^\s*(?:const\s+)?\w+\s*\*?", "", decl.strip()))]
+        assert names == [f[0] for f in cls._fields_], f"{cname}: field order differs: {names} vs {[f[0] for f in cls._fields_]}"
+        assert got[(cname, ".")] == C.sizeof(cls), f"{cname}: sizeof {got[(cname, '.')]} vs ctypes {C.sizeof(cls)}"
+        for f in cls._fields_:
+            assert got[(cname, f[0])] == getattr(cls, f[0]).offset, f"{cname}.{f[0]}: offset {got[(cname, f[0])]} vs ctypes {getattr(cls, f[0]).offset}"

@@ -240,6 +240,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3d_kernel(const ConvParams p, co
       const bool extra = (FLAGS & D_SC) != 0 && sc.c >= nslab;   // a slab of the folded shortcut: the other source, its own pitch (offsets rebuilt from the pixel coordinates)
       static_for<0, D_NROUND>([&](auto rc_) {
         constexpr int r = decltype(rc_)::value;
+#ifdef C3D_ABL_NODMA   // ablation (timing only, results wrong): only the first three halo images are fetched
+        if (sc.k >= 3) return;
+#endif
         if (r < 10 || pw == 0) {
           int voff = ((sc.vbits >> r) & 1u) ? (int)rc_rel[r] : (int)D_OOR;
           unsigned char* dst = smem_raw + hbuf + (unsigned)(pw + 4 * r) * 1024u;
@@ -467,6 +470,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3d_kernel(const ConvParams p, co
 #ifdef C3D_ABL_NOW
   bool abl_w_loaded[2] = {false, false};
 #endif
+#ifdef C3D_ABL_NOX
+  int abl_nx = 0;
+#endif
   const long long w_step_bytes = (long long)ntn * 16384;   // from slab c to slab c + 1 of a tap; a tap is nslab of these
 
 #ifdef C3D_STAMPS
@@ -481,6 +487,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3d_kernel(const ConvParams p, co
   auto issue_x = [&](auto gc, auto kyc, auto kxc, auto khc, unsigned hb, f16x8 (&dst)[4]) __attribute__((always_inline)) {   // rows 4 gr .. 4 gr + 3 of k-half kh at tap (ky, kx)
     constexpr int gr = decltype(gc)::value, ky = decltype(kyc)::value, kx = decltype(kxc)::value, kh = decltype(khc)::value;
     const unsigned b0 = (xb[kx] + hb) ^ (kh ? 64u : 0u);   // chunk bit 2 = k-half: XOR commutes with the swizzle
+#ifdef C3D_ABL_NOX   // ablation (timing only, results wrong): only the first eight groups of pixel rows are read
+    if (abl_nx >= 8) return;
+    ++abl_nx;
+#endif
     lds_read128<(4 * gr + ky) * D_ROWB>(dst[0], b0);
     lds_read128<(4 * gr + 1 + ky) * D_ROWB>(dst[1], b0);
     lds_read128<(4 * gr + 2 + ky) * D_ROWB>(dst[2], b0);
@@ -499,6 +509,16 @@ __global__ __launch_bounds__(512, 2) void conv3x3d_kernel(const ConvParams p, co
   };
   auto mfma16 = [&](auto khc, auto gc, f16x8 (&x)[4]) __attribute__((always_inline)) {
     constexpr int kh = decltype(khc)::value, gr = decltype(gc)::value;
+#ifdef C3D_ABL_PAIRS   // issue-order probe (timing only, results wrong): the sixteen MFMAs of a half-step as eight DEPENDENT pairs (profiles/r02_mfma_peak.md)
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int a = 2 * kh; a < 2 * kh + 2; ++a) {
+        acc[a][4 * gr + r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Wf[0][a], x[r], acc[a][4 * gr + r], 0, 0, 0);
+        acc[a][4 * gr + r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Wf[1][a], x[r], acc[a][4 * gr + r], 0, 0, 0);
+      }
+    return;
+#endif
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll

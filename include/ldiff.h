@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define LDIFF_VERSION 151 /* 0.1.5.1: + dataflow GEMM (ldiff_conv_args.gemm_df), shortcut conv folded into the dataflow conv3x3 (ldiff_conv_args.sc_*) */
+#define LDIFF_VERSION 152 /* 0.1.5.2: + ldiff_conv_args.n_real (tap-folded conv_out kernel); 0.1.5.1: dataflow GEMM (gemm_df), shortcut conv folded into the dataflow conv3x3 (sc_*) */
 #define LDIFF_MAX_BLOCKS 8
 
 typedef enum { LDIFF_OK = 0, LDIFF_ERR_INVALID = -1, LDIFF_ERR_RUNTIME = -2, LDIFF_ERR_STATE = -3 } ldiff_status;
@@ -226,6 +226,8 @@ typedef struct {
   int sc_C, sc_ld;
   const void* sc_w;
   const void* sc_bias;
+  int n_real;                                       /* output channels of the layer where N (the stored columns, a multiple of 4) rounds them up; 0 = not stated.  The tap-folded
+                                                       3x3 kernel for <= 3 output channels (the VAE's conv_out) runs only where this says so */
 } ldiff_conv_args;
 int ldiff_op_conv(const ldiff_conv_args*, void* stream);
 /* row blocks per image the launch would emit statistics for (0 = unsupported for this shape) */

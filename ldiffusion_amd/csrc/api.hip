@@ -466,6 +466,7 @@ static void conv_args_to_params(const ldiff_conv_args* a, ConvParams& p) {
   LDIFF_CHECK((p.ks == 1 || p.ks == 3) && (p.stride == 1 || p.stride == 2) && (p.ups == 0 || p.ups == 1), LDIFF_ERR_INVALID,
               "op_conv: unsupported ks=%d stride=%d ups=%d", p.ks, p.stride, p.ups);
   p.w = (const f16*)a->w; p.N = a->N; p.Nrows = a->Nrows; p.K = a->ks * a->ks * (a->C1 + a->C2);
+  p.n_real = a->n_real > 0 && a->n_real <= a->N ? a->n_real : 0;
   p.gn_scale = (const float*)a->gn_scale; p.gn_shift = (const float*)a->gn_shift; p.silu_in = a->silu_in;
   p.bias = (const float*)a->bias; p.temb = (const float*)a->temb; p.ld_temb = a->ld_temb;
   p.res = (const f16*)a->res; p.ld_res = a->ld_res;

@@ -54,6 +54,7 @@ struct ConvParams {
   int ks, stride, pad_t, pad_l, ups;
   const f16* w;      // [Nrows, K] K-major, Nrows = roundup(N,16), rows >= N zero
   int N, Nrows, K;   // N = columns stored (multiple of 4)
+  int n_real = 0;    // output channels of the layer before that rounding (0: not stated; kernels that need it decline)
   const float* gn_scale;  // [B, Cin] or nullptr
   const float* gn_shift;  // [B, Cin]
   int silu_in;            // apply SiLU after the affine (only with gn_scale)

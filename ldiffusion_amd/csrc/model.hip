@@ -303,7 +303,7 @@ bool Exec::lo8_conv_ok(const MatW& w, const Act& x, bool res, bool split_out) co
   static const int one = 127;
   p.x = x.p; p.C1 = x.C + x.C / 2; p.lo8_slab0 = x.C / 64; p.lo8_sb = 127 - LO8_SHIFT; p.lo8_sa = &one;
   p.B = x.B; p.Hin = p.Hout = x.H; p.Win = p.Wout = x.W; p.ks = 3; p.stride = 1; p.pad_t = p.pad_l = 1;
-  p.w = w.w; p.N = roundup(w.N, 4); p.Nrows = w.Nrows; p.K = 9 * p.C1; p.M = x.B * x.H * x.W;
+  p.w = w.w; p.N = roundup(w.N, 4); p.n_real = w.N; p.Nrows = w.Nrows; p.K = 9 * p.C1; p.M = x.B * x.H * x.W;
   if (p.N != w.N || p.N % 8 != 0) return false;
   p.y = x.p; p.ldy = 2 * p.N; p.y_lo = p.N; p.stats = reinterpret_cast<float*>(x.p);   // (placeholders: only null / non-null and the layout matter)
   if (res) { p.res = x.p; p.ld_res = 2 * p.N; p.res_lo = p.N; }
@@ -417,6 +417,7 @@ Act Exec::conv(const MatW& w, const Act& x, const Act* x2, const ConvOpts& o) {
   const f16* wsrc = (o.split_in && x.lo8) ? derived_lo8(w, &p.lo8_sa) : o.split_in ? derived_dup(w, x.C, x2 ? x2->C : 0) : w.w;
   p.w = wsrc; p.Nrows = w.Nrows; p.K = w.ks * w.ks * Cin_eff;
   p.N = o.N_override ? o.N_override : roundup(w.N, 4);
+  p.n_real = o.N_override ? 0 : w.N;
   p.bias = w.b;
   f16* wfold = nullptr;
   float* bfold = nullptr;

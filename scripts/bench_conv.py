@@ -111,6 +111,7 @@ def main():
             a.x2, a.C2 = x2.data_ptr(), C2
         a.B, a.Hin, a.Win, a.Hout, a.Wout, a.ks, a.stride, a.pad_t, a.pad_l, a.ups = B, H, W, Ho, Wo, ks, stride, ks // 2, ks // 2, ups
         a.w, a.N, a.Nrows, a.bias = w.data_ptr(), Nst, Nrows, bias.data_ptr()
+        a.n_real = Cout
         if gn:
             a.gn_scale, a.gn_shift, a.silu_in = sc.data_ptr(), sh.data_ptr(), int(os.environ.get("LDIFF_BENCH_SILU", "1"))
         a.y, a.ldy = y.data_ptr(), Nst

@@ -88,7 +88,7 @@ def run_conv(lib, x, w, bias=None, x2=None, stride=1, pad=(1, 1), ups=0, gn=None
     a_.B, a_.Hin, a_.Win, a_.Hout, a_.Wout = B, H, W, Ho, Wo
     a_.ks, a_.stride, a_.ups = ks, stride, ups
     a_.pad_t, a_.pad_l = (0, 0) if asym else pad
-    a_.w = wd.data_ptr(); a_.N = Nst; a_.Nrows = Nrows
+    a_.w = wd.data_ptr(); a_.N = Nst; a_.Nrows = Nrows; a_.n_real = Cout
     if gn is not None:
         sd, hd = gn[0].contiguous().to(DEV), gn[1].contiguous().to(DEV); keep += [sd, hd]
         a_.gn_scale, a_.gn_shift, a_.silu_in = sd.data_ptr(), hd.data_ptr(), silu
@@ -131,6 +131,10 @@ CONV_CASES = {
     "3x3_cout4_f32_concat_320": (2, 192, 128, 24, 40, 4, 3, 1, 0, False, True, False),
     "3x3_cout3_f32_plain_512": (1, 512, 0, 16, 48, 3, 3, 1, 0, False, False, False),
     "3x3_cout4_f32_large": (8, 128, 0, 128, 128, 4, 3, 1, 0, False, True, False),
+    # <= 3 output channels over 128 input channels: the tap-folded kernel (conv3x3nt_kernel); 2800 tiles on 512 workgroups: 5 or 6 each, ragged borders
+    "3x3_cout3_f32_several_tiles_per_workgroup_ragged": (8, 128, 0, 200, 216, 3, 3, 1, 0, False, True, False),
+    "3x3_cout3_f32_plain_128_ragged": (2, 128, 0, 20, 27, 3, 3, 1, 0, False, False, False),
+    "3x3_cout2_f32_gn_128": (1, 128, 0, 8, 16, 2, 3, 1, 0, False, True, False),
     "1x1_cin8_cout8": (2, 8, 0, 8, 8, 8, 1, 1, 0, False, False, False),
     "3x3_1x1_spatial": (3, 64, 0, 1, 1, 64, 3, 1, 0, False, False, False),
     "3x3_splitk_8x8_1280": (2, 1280, 0, 8, 8, 256, 3, 1, 0, False, True, True),
@@ -190,6 +194,43 @@ def test_conv(lib, name):
     res = torch.randn((B, Cout, Ho, Wo), generator=g) if extras else None
     got, ref = run_conv(lib, x, w, bias, x2, stride, (ks // 2, ks // 2), ups, gn, 1 if use_gn else 0, temb, res, out_f32, asym)
     assert_close(got, ref, name)
+
+
+@pytest.mark.parametrize("silu", [0, 1])
+def test_narrow_conv_tap_folded_against_the_lds_image_kernel(lib, silu):
+    """conv_out of the VAE decoder (128 -> 3, GroupNorm prologue): the tap-folded kernel (taps as output columns of one narrow GEMM over the halo
+    pixels, then a gather) against torch AND against the LDS-image kernel it replaces (LDIFF_CONV3X3_NARROW_FOLD=0 in a child process is not
+    needed: n_real = 0 keeps the launch on the old kernel) -- same operands, a different fp32 summation order: equal to 1e-5 of the output range."""
+    g = torch.Generator().manual_seed(11 + silu)
+    B, Cc, H, W, Cout = 3, 128, 40, 56, 3
+    x = torch.randn((B, Cc, H, W), generator=g)
+    w = torch.randn((Cout, Cc, 3, 3), generator=g) / math.sqrt(9 * Cc)
+    bias = torch.randn(Cout, generator=g) * 0.1
+    gn = (1.0 + 0.2 * torch.randn((B, Cc), generator=g), 0.2 * torch.randn((B, Cc), generator=g))
+    got, ref = run_conv(lib, x, w, bias, gn=gn, silu=silu, out_f32=True)
+    assert_close(got, ref, f"tap-folded silu={silu}", rtol=1e-4, atol_rel=1e-4)
+    # the same launch with n_real = 0 (not stated): the LDS-image kernel
+    Nrows = 16
+    wd = torch.zeros((Nrows, 3, 3, Cc), dtype=torch.float16); wd[:Cout] = w.permute(0, 2, 3, 1).to(torch.float16)
+    wd = wd.reshape(Nrows, 9 * Cc).contiguous().to(DEV)
+    xd = nhwc16(x)
+    sd, hd = gn[0].contiguous().to(DEV), gn[1].contiguous().to(DEV)
+    bd = torch.zeros(Nrows); bd[:Cout] = bias; bd = bd.to(DEV)
+    ys = []
+    for n_real in (Cout, 0):
+        a_ = _lib.ConvArgs()
+        a_.x, a_.C1, a_.B, a_.Hin, a_.Win, a_.Hout, a_.Wout, a_.ks, a_.stride, a_.pad_t, a_.pad_l = xd.data_ptr(), Cc, B, H, W, H, W, 3, 1, 1, 1
+        a_.w, a_.N, a_.Nrows, a_.n_real, a_.bias = wd.data_ptr(), 4, Nrows, n_real, bd.data_ptr()
+        a_.gn_scale, a_.gn_shift, a_.silu_in = sd.data_ptr(), hd.data_ptr(), silu
+        y = torch.full((B, H, W, 4), float("nan"), device=DEV)
+        a_.y, a_.ldy, a_.out_f32 = y.data_ptr(), 4, 1
+        _lib.check(lib.ldiff_op_conv(C.byref(a_), sp()))
+        torch.cuda.synchronize()
+        ys.append(y.cpu())
+    assert torch.isfinite(ys[0]).all() and torch.equal(ys[0][..., 3], ys[1][..., 3])          # the pad column: the bias of the zero row
+    d = (ys[0] - ys[1]).abs().max().item() / ys[1].abs().max().item()
+    # (the two kernels round the normalised operand to fp16 once / twice -- a last-bit difference of single operand elements)
+    assert d <= 2e-4, f"tap-folded and LDS-image kernels differ by {d:.2e} of the output range"
 
 
 def test_conv_groupnorm_without_silu(lib):

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define LDIFF_VERSION 152 /* 0.1.5.2: + ldiff_conv_args.n_real (tap-folded conv_out kernel); 0.1.5.1: dataflow GEMM (gemm_df), shortcut conv folded into the dataflow conv3x3 (sc_*) */
+#define LDIFF_VERSION 152 /* 0.1.5.2: + ldiff_conv_args.n_real (tap-folded conv_out kernel), c3d_ups (upsampling convs on the dataflow kernel); 0.1.5.1: dataflow GEMM (gemm_df), shortcut conv folded into the dataflow conv3x3 (sc_*) */
 #define LDIFF_MAX_BLOCKS 8
 
 typedef enum { LDIFF_OK = 0, LDIFF_ERR_INVALID = -1, LDIFF_ERR_RUNTIME = -2, LDIFF_ERR_STATE = -3 } ldiff_status;
@@ -226,6 +226,8 @@ typedef struct {
   int sc_C, sc_ld;
   const void* sc_w;
   const void* sc_bias;
+  int c3d_ups;                                      /* ups = 1 convs on the dataflow kernel: 1 = wherever the shape is eligible (tests, timing); 0 = the executors' choice (never: it does
+                                                       not pay in the sampler's step) */
   int n_real;                                       /* output channels of the layer where N (the stored columns, a multiple of 4) rounds them up; 0 = not stated.  The tap-folded
                                                        3x3 kernel for <= 3 output channels (the VAE's conv_out) runs only where this says so */
 } ldiff_conv_args;

@@ -37,7 +37,7 @@ class ConvArgs(C.Structure):
                 ("res", C.c_void_p), ("ld_res", C.c_int), ("y", C.c_void_p), ("ldy", C.c_int), ("out_f32", C.c_int), ("stats", C.c_void_p),
                 ("geglu", C.c_int), ("ld1", C.c_int), ("ld2", C.c_int), ("res_lo", C.c_int), ("y_lo", C.c_int), ("short_runs", C.c_int),
                 ("lo8_slab0", C.c_int), ("lo8_scale", C.c_void_p), ("gemm_df", C.c_int),
-                ("sc_x", C.c_void_p), ("sc_C", C.c_int), ("sc_ld", C.c_int), ("sc_w", C.c_void_p), ("sc_bias", C.c_void_p), ("n_real", C.c_int)]
+                ("sc_x", C.c_void_p), ("sc_C", C.c_int), ("sc_ld", C.c_int), ("sc_w", C.c_void_p), ("sc_bias", C.c_void_p), ("c3d_ups", C.c_int), ("n_real", C.c_int)]
 
 
 # name -> (restype, argtypes); every symbol include/ldiff.h declares

@@ -467,6 +467,7 @@ static void conv_args_to_params(const ldiff_conv_args* a, ConvParams& p) {
               "op_conv: unsupported ks=%d stride=%d ups=%d", p.ks, p.stride, p.ups);
   p.w = (const f16*)a->w; p.N = a->N; p.Nrows = a->Nrows; p.K = a->ks * a->ks * (a->C1 + a->C2);
   p.n_real = a->n_real > 0 && a->n_real <= a->N ? a->n_real : 0;
+  p.c3d_ups = a->c3d_ups;
   p.gn_scale = (const float*)a->gn_scale; p.gn_shift = (const float*)a->gn_shift; p.silu_in = a->silu_in;
   p.bias = (const float*)a->bias; p.temb = (const float*)a->temb; p.ld_temb = a->ld_temb;
   p.res = (const f16*)a->res; p.ld_res = a->ld_res;
@@ -498,7 +499,8 @@ int ldiff_op_conv(const ldiff_conv_args* a, void* stream) {
   LDIFF_CHECK(!p.xs || (a->sc_w && conv3x3_eligible(p) && conv3x3d_selected(p)), LDIFF_ERR_INVALID, "op_conv: a folded shortcut (sc_x) needs sc_w and a launch the dataflow conv3x3 kernel takes");
   if (conv3x3d_selected(p)) {   // dataflow kernel: fragment-packed weights (the executors cache them per layer; here per call)
     f16* wf = (f16*)op_scratch(st, 3, conv3x3d_frag_bytes(p));
-    launch_pack_frag_weights(p.w, wf, p.N, p.C1, st);
+    if (p.ups) launch_pack_frag_weights_par(p.w_par, wf, p.N, p.Nrows, p.C1, st);
+    else launch_pack_frag_weights(p.w, wf, p.N, p.C1, st);
     if (p.xs) {   // the folded shortcut's weights behind the nine taps, the two biases summed
       launch_pack_frag_weights_sc((const f16*)a->sc_w, wf, p.N, p.C1, p.Cs, p.Cs, st);
       float* bsum = (float*)op_scratch(st, 5, (size_t)p.Nrows * sizeof(float));
@@ -534,6 +536,7 @@ int ldiff_op_conv_stats_blocks(const ldiff_conv_args* a) {
   try {
     ConvParams p;
     conv_args_to_params(a, p);
+    if (p.ups && conv3x3_eligible(p)) p.w_par = p.w;   // (what ldiff_op_conv will do: the kernels choose by null / non-null only)
     return conv_stats_blocks_per_image(p);
   } catch (const LdiffError& e) { return e.code; }
 }

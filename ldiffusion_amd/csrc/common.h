@@ -54,6 +54,7 @@ struct ConvParams {
   int ks, stride, pad_t, pad_l, ups;
   const f16* w;      // [Nrows, K] K-major, Nrows = roundup(N,16), rows >= N zero
   int N, Nrows, K;   // N = columns stored (multiple of 4)
+  int c3d_ups = 0;   // upsampling conv on the dataflow kernel: 1 = wherever eligible (tests, timing); 0 / -1 = no (conv3x3d_selected: it does not pay in the step)
   int n_real = 0;    // output channels of the layer before that rounding (0: not stated; kernels that need it decline)
   const float* gn_scale;  // [B, Cin] or nullptr
   const float* gn_shift;  // [B, Cin]
@@ -121,6 +122,7 @@ bool conv3x3d_selected(const ConvParams& p);
 int conv3x3d_stats_blocks(const ConvParams& p);
 size_t conv3x3d_frag_bytes(const ConvParams& p);
 void launch_pack_frag_weights(const f16* w, f16* wf, int N, int Cin, hipStream_t s);   // [N][9 Cin] K-major -> MFMA A fragments, one KiB each
+void launch_pack_frag_weights_par(const f16* wpar, f16* wf, int N, int Nrows, int Cin, hipStream_t s);   // ... of the parity-folded weights (ups = 1)
 void launch_pack_frag_weights_sc(const f16* wsc, f16* wf, int N, int Cin, int Cs, int ld_wsc, hipStream_t s);   // the folded shortcut's [N][Cs] behind them (ConvParams::xs)
 void launch_add_vectors(const float* a, const float* b, float* out, int n, hipStream_t s);   // out = a + b (either may be null = 0)
 void launch_conv3x3d(const ConvParams& p, hipStream_t s);

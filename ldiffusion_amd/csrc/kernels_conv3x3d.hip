@@ -65,7 +65,7 @@ static_assert((16 - D_STG_CHUNKS) * 4096 <= D_HB, "the rest of a staged tile mus
 static_assert(D_LDS <= 160 * 1024, "LDS budget of one workgroup per CU");
 constexpr unsigned D_OOR = 0x80000000u;                                // beyond num_records of every descriptor used here: the load returns zeros
 constexpr int D_NROUND = 11;                                           // pieces per producer wave and slab: 41 = 4 x 10 + 1
-enum { D_RES = 1, D_STATS = 2, D_SC = 4 };   // D_SC: the folded 1x1 shortcut (ConvParams::xs) -- a flag of its own so that the other instantiations carry none of its code
+enum { D_RES = 1, D_STATS = 2, D_SC = 4, D_UPS = 8 };   // D_UPS: nearest-2x upsample folded into the conv (ConvParams::w_par): units per output parity, four taps, raw operand   // D_SC: the folded 1x1 shortcut (ConvParams::xs) -- a flag of its own so that the other instantiations carry none of its code
 
 __device__ __forceinline__ int d_swzx(int hx) { return (0xcb5888 >> (3 * (hx >> 1))) & 7; }   // column swizzle of the halo image (kernels_conv3x3.hip)
 
@@ -97,7 +97,7 @@ __device__ __forceinline__ void lds_write128(unsigned addr, const u32x4& v) { as
 // (a __builtin_bit_cast applied directly to a vector ELEMENT expression reads element 0 whatever the index: hipcc 7.2; by value it is fine)
 __device__ __forceinline__ float u2f(unsigned v) { return __builtin_bit_cast(float, v); }
 
-struct UnitC { int b, oy0, ox0, n0; };
+struct UnitC { int b, oy0, ox0, n0, q; };   // q: output parity 2 py + px of a D_UPS unit (else 0)
 
 #ifdef C3D_STAMPS   // diagnostic build only (scripts/conv_stamps_d.py): cycle sums / poll counts of waves 0 and 4 of workgroup 0
 __device__ unsigned long long c3d_dbg[48];
@@ -123,7 +123,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3d_kernel(const ConvParams p, co
   const unsigned lds0 = (unsigned)(size_t)(lptr_t*)smem_raw;
   const int Cin = p.C1, nslab = Cin >> 6, ntn = p.N >> 7;
   const int nsx = (FLAGS & D_SC) ? p.Cs >> 6 : 0, nsl = nslab + nsx;   // slabs of the folded 1x1 shortcut (centre tap only), slabs of a unit in all
-  const int H = p.Hout, W = p.Wout, tiles_x = W >> 4, tiles_y = H >> 4;
+  constexpr bool UPS = (FLAGS & D_UPS) != 0;
+  const int H = UPS ? p.Hin : p.Hout, W = UPS ? p.Win : p.Wout, tiles_x = W >> 4, tiles_y = H >> 4;   // the map the tiles and halos live on (D_UPS: the source; the output is 2H x 2W)
 
   // this workgroup's run of units (n-tile fastest, then x, y, image); the runs of the workgroups that share an XCD are adjacent
   const int G = gridDim.x, id = blockIdx.x;
@@ -136,6 +137,12 @@ __global__ __launch_bounds__(512, 2) void conv3x3d_kernel(const ConvParams p, co
     UnitC c;
     int t = u / ntn;
     c.n0 = __builtin_amdgcn_readfirstlane((u - t * ntn) * 128);
+    c.q = 0;
+    if constexpr (UPS) {   // the four parities of a pixel tile are neighbours in the unit list: their halos meet in L2
+      const int tq = t >> 2;
+      c.q = __builtin_amdgcn_readfirstlane(t - tq * 4);
+      t = tq;
+    }
     const int t2 = t / tiles_x;
     c.ox0 = __builtin_amdgcn_readfirstlane((t - t2 * tiles_x) * 16);
     const int t3 = t2 / tiles_y;
@@ -220,7 +227,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3d_kernel(const ConvParams p, co
       const unsigned hbuf = (unsigned)(sc.k % D_NBUF) * D_HB;
       int n = 2;
       {
-        const int voff = (lane < 32 && ((FLAGS & D_SC) == 0 || sc.c < nslab)) ? (sc.un.b * Cin + sc.c * 64) * 4 + (lane & 15) * 16 : (int)D_OOR;   // (a shortcut slab: zeros, unused -- the instruction count of a slab stays the same)
+        const int voff = (!UPS && lane < 32 && ((FLAGS & D_SC) == 0 || sc.c < nslab)) ? (sc.un.b * Cin + sc.c * 64) * 4 + (lane & 15) * 16 : (int)D_OOR;   // (a shortcut slab: zeros, unused -- the instruction count of a slab stays the same)
         unsigned char* dst = smem_raw + D_AFF + (unsigned)(pw * 3 + sc.k % D_NBUF) * 512u;
 #if defined(__HIP_DEVICE_COMPILE__)   // the host pass rejects this builtin (target feature) and then silently drops the kernel stub
         if (lane < 16) __builtin_amdgcn_raw_ptr_buffer_load_lds(scrsrc, (lptr_t*)dst, 16, voff, 0, 0, 0);
@@ -313,9 +320,12 @@ __global__ __launch_bounds__(512, 2) void conv3x3d_kernel(const ConvParams p, co
     auto store_unit = [&](int i, unsigned hb_last) __attribute__((always_inline)) {
       constexpr bool RES = (FLAGS & D_RES) != 0, ST = (FLAGS & D_STATS) != 0;
       const UnitC un = decode(u0 + i);
-      const unsigned pix0 = (unsigned)((un.b * H + un.oy0 + e_wm * 8) * W + un.ox0);   // first pixel of the wave's 8 x 16 block
+      // first pixel of the wave's 8 x 16 block; D_UPS: source pixel (Y, X) of parity (py, px) is output pixel (2 Y + py, 2 X + px) of the 2H x 2W map
+      const unsigned pix0 = UPS ? (unsigned)((un.b * 2 * H + 2 * (un.oy0 + e_wm * 8) + (un.q >> 1)) * 2 * W + 2 * un.ox0 + (un.q & 1))
+                                : (unsigned)((un.b * H + un.oy0 + e_wm * 8) * W + un.ox0);
       const unsigned ch0 = (unsigned)(un.n0 + e_wn * 64);
-      const int ylane = (e_px * p.ldy + e_o * 8) * 2, rlane = (e_px * p.ld_res + e_o * 8) * 2;
+      const int ypx = UPS ? 2 : 1, yrow = UPS ? 4 * W : W;   // output pixels per tile column / per tile row
+      const int ylane = (e_px * ypx * p.ldy + e_o * 8) * 2, rlane = (e_px * p.ld_res + e_o * 8) * 2;
       const unsigned ybase = (pix0 * (unsigned)p.ldy + ch0) * 2u, rbase = (pix0 * (unsigned)p.ld_res + ch0) * 2u;
       u32x4 R[16];
       if constexpr (RES) {   // (nothing of this wave's is in flight here: the compiler's own waits for these loads are exact)
@@ -355,7 +365,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3d_kernel(const ConvParams p, co
         }
         // (offset in the VGPR and a wait state behind the store: with an SGPR soffset a VALU write of the data registers right after a
         // 16-byte store is seen by the store -- profiles/r02_conv3x3_pingpong.md)
-        __builtin_amdgcn_raw_buffer_store_b128(o, yrsrc, ylane + (int)(ybase + (unsigned)(((j >> 1) * W + (j & 1) * 8) * p.ldy) * 2u), 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(o, yrsrc, ylane + (int)(ybase + (unsigned)(((j >> 1) * yrow + (j & 1) * 8 * ypx) * p.ldy) * 2u), 0, 0);
         asm volatile("s_nop 1" ::: "memory");
         if constexpr (ST) {
 #pragma unroll
@@ -387,7 +397,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3d_kernel(const ConvParams p, co
           x16[q] = u2f(sw[0]) + u2f(sw[1]);
         }
         const int chn = ((lane >> 3) & 1) | ((((lane >> 4) & 1) ^ 1) << 1) | ((((lane >> 5) & 1) ^ 1) << 2);
-        const long long rblk = ((long long)(un.oy0 >> 4) * tiles_x + (un.ox0 >> 4)) * 2 + e_wm;
+        const long long rblk = (((long long)(un.oy0 >> 4) * tiles_x + (un.ox0 >> 4)) * 2 + e_wm) * (UPS ? 4 : 1) + un.q;
         const int n = (int)ch0 + e_o * 8 + chn;
         *reinterpret_cast<float2*>(p.stats + (((long long)un.b * p.N + n) * p.stats_R + rblk) * 2) = make_float2(x16[0], x16[1]);
       }
@@ -422,7 +432,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3d_kernel(const ConvParams p, co
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       DSTAMP(q2);
 #ifndef C3D_ABL_NOXF
-      if ((FLAGS & D_SC) == 0 || cur.c < nslab) xform_slab(cur);   // (a slab of the folded shortcut is a raw operand)
+      if constexpr (!UPS)   // (D_UPS: the conv behind an Upsample2D has no GroupNorm in front of it -- raw operand; zero padding = the DMA's zeros)
+        if ((FLAGS & D_SC) == 0 || cur.c < nslab) xform_slab(cur);   // (a slab of the folded shortcut is a raw operand)
 #endif
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       lds_write32(pflag_addr, (unsigned)k + 1u);
@@ -495,6 +506,26 @@ __global__ __launch_bounds__(512, 2) void conv3x3d_kernel(const ConvParams p, co
     lds_read128<(4 * gr + 1 + ky) * D_ROWB>(dst[1], b0);
     lds_read128<(4 * gr + 2 + ky) * D_ROWB>(dst[2], b0);
     lds_read128<(4 * gr + 3 + ky) * D_ROWB>(dst[3], b0);
+  };
+  // D_UPS: the same four rows at tap row ty of the column base `base` (= xb[column tap] + parity row + image; chosen per unit, not per instantiation)
+  auto issue_xb = [&](auto gc, auto tyc, auto khc, unsigned base, f16x8 (&dst)[4]) __attribute__((always_inline)) {
+    constexpr int gr = decltype(gc)::value, ty = decltype(tyc)::value, kh = decltype(khc)::value;
+    const unsigned b0 = base ^ (kh ? 64u : 0u);
+    lds_read128<(4 * gr + ty) * D_ROWB>(dst[0], b0);
+    lds_read128<(4 * gr + 1 + ty) * D_ROWB>(dst[1], b0);
+    lds_read128<(4 * gr + 2 + ty) * D_ROWB>(dst[2], b0);
+    lds_read128<(4 * gr + 3 + ty) * D_ROWB>(dst[3], b0);
+  };
+  // D_UPS: output parity (py, px) reads source rows Y - 1 + py + ty and columns X - 1 + px + tx, ty, tx in {0, 1} = halo rows py + ty, halo columns px + tx;
+  // fragment-packed weights [parity][tap 2 ty + tx][slab][channel tile] (launch_pack_frag_weights_par)
+  unsigned ub[2] = {xb[0], xb[1]};
+  auto set_parity = [&](const UnitC& un) __attribute__((always_inline)) {
+    const unsigned ro = (unsigned)((un.q >> 1) * D_ROWB);
+    ub[0] = ((un.q & 1) ? xb[1] : xb[0]) + ro;
+    ub[1] = ((un.q & 1) ? xb[2] : xb[1]) + ro;
+  };
+  auto wbase = [&](const UnitC& un) __attribute__((always_inline)) -> const char* {
+    return wfrag + ((long long)(UPS ? un.q * 4 * nslab * ntn : 0) + (un.n0 >> 7)) * 16384;
   };
   auto issue_w = [&](auto khc, const char* wq) __attribute__((always_inline)) {   // the four channel tiles of k-half kh of the step at wq
     constexpr int kh = decltype(khc)::value;
@@ -597,12 +628,14 @@ __global__ __launch_bounds__(512, 2) void conv3x3d_kernel(const ConvParams p, co
       for (int m = 0; m < 8; ++m) acc[a][m] = b;
     }
   }
-  const char* wq = wfrag + (long long)(cur.n0 >> 7) * 16384;   // weights of the current step (tap 0, slab 0 of the unit's channel tile)
+  const char* wq = wbase(cur);   // weights of the current step (tap 0, slab 0 of the unit's channel tile)
+  if constexpr (UPS) set_parity(cur);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (nothing of the compiler's may be younger than the hand-counted loads below)
   wait_producers(1u);
   DSTAMP(c_t1);
   DACC(0, c_t1 - c_t0);
-  issue_x(ic_t<0>{}, ic_t<0>{}, ic_t<0>{}, ic_t<0>{}, 0u, X[0]);
+  if constexpr (UPS) issue_xb(ic_t<0>{}, ic_t<0>{}, ic_t<0>{}, ub[0], X[0]);
+  else issue_x(ic_t<0>{}, ic_t<0>{}, ic_t<0>{}, ic_t<0>{}, 0u, X[0]);
   issue_w(ic_t<0>{}, wq);
 
   int k = 0;   // global slab of this workgroup
@@ -615,6 +648,42 @@ __global__ __launch_bounds__(512, 2) void conv3x3d_kernel(const ConvParams p, co
       const bool to_extra = (FLAGS & D_SC) != 0 && nsx > 0 && c == nslab - 1;   // the next slab is the shortcut's first: its one step is the centre tap
       const unsigned hb = (unsigned)(k % D_NBUF) * D_HB;
       const unsigned hbn = (unsigned)((k + 1) % D_NBUF) * D_HB;
+      if constexpr (UPS) {
+        static_for<0, 4>([&](auto tc) {   // the four taps of the unit's parity: the step of the nine-tap loop below with a column base chosen per unit
+          constexpr int T = decltype(tc)::value, ty = T >> 1, tx = T & 1;
+          constexpr int nty = ((T + 1) & 3) >> 1, ntx = (T + 1) & 1;
+          const char* wn = T == 3 ? wq - (3 * nslab - 1) * w_step_bytes : wq + nslab * w_step_bytes;
+          const unsigned xc = ub[tx] + hb;
+          issue_w(ic_t<1>{}, wq);
+          issue_xb(ic_t<1>{}, ic_t<ty>{}, ic_t<0>{}, xc, X[1]);
+          lds_wait4<4>(X[0][0], X[0][1], X[0][2], X[0][3]);
+          vm_wait4<4>(Wf[0][0], Wf[0][1], Wf[0][2], Wf[0][3]);
+          mfma16(ic_t<0>{}, ic_t<0>{}, X[0]);
+          __builtin_amdgcn_sched_barrier(0);
+          issue_xb(ic_t<0>{}, ic_t<ty>{}, ic_t<1>{}, xc, X[0]);
+          lds_wait4<4>(X[1][0], X[1][1], X[1][2], X[1][3]);
+          mfma16(ic_t<0>{}, ic_t<1>{}, X[1]);
+          __builtin_amdgcn_sched_barrier(0);
+          issue_w(ic_t<0>{}, wn);
+          issue_xb(ic_t<1>{}, ic_t<ty>{}, ic_t<1>{}, xc, X[1]);
+          lds_wait4<4>(X[0][0], X[0][1], X[0][2], X[0][3]);
+          vm_wait4<4>(Wf[1][0], Wf[1][1], Wf[1][2], Wf[1][3]);
+          mfma16(ic_t<1>{}, ic_t<0>{}, X[0]);
+          __builtin_amdgcn_sched_barrier(0);
+          if constexpr (T == 3) {
+            lds_wait4<0>(X[1][0], X[1][1], X[1][2], X[1][3]);
+            lds_write32(cflag_addr, (unsigned)k + 1u);
+            if (!last_slab) { DACC(2, 1); wait_producers((unsigned)k + 2u); }
+            issue_xb(ic_t<0>{}, ic_t<0>{}, ic_t<0>{}, ub[0] + hbn, X[0]);
+          } else {
+            issue_xb(ic_t<0>{}, ic_t<nty>{}, ic_t<0>{}, ub[ntx] + hb, X[0]);
+            lds_wait4<4>(X[1][0], X[1][1], X[1][2], X[1][3]);
+          }
+          mfma16(ic_t<1>{}, ic_t<1>{}, X[1]);
+          __builtin_amdgcn_sched_barrier(0);
+          wq = wn;
+        });
+      } else
       static_for<0, 9>([&](auto tc) {
         constexpr int T = decltype(tc)::value, ky = T / 3, kx = T % 3;
         constexpr int nky = ((T + 1) % 9) / 3, nkx = (T + 1) % 3;
@@ -691,7 +760,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3d_kernel(const ConvParams p, co
     DSTAMP(e0);
     UnitC nxt = cur;
     if (has_next) nxt = decode(u + 1);
-    wq = wfrag + (long long)(nxt.n0 >> 7) * 16384;
+    wq = wbase(nxt);
     stage_ready(u - u0, (unsigned)k);
     issue_w(ic_t<0>{}, wq);   // the next unit's first weights travel while the tile is staged (after the last unit: loaded again, unused)
 #ifndef C3D_ABL_NOSTAGE
@@ -707,7 +776,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3d_kernel(const ConvParams p, co
       init_from_table((u + 1 - u0) & 1);
       DSTAMP(e2);
       DACC(5, e2 - e1);
-      issue_x(ic_t<0>{}, ic_t<0>{}, ic_t<0>{}, ic_t<0>{}, (unsigned)(k % D_NBUF) * D_HB, X[0]);
+      if constexpr (UPS) { set_parity(nxt); issue_xb(ic_t<0>{}, ic_t<0>{}, ic_t<0>{}, ub[0] + (unsigned)(k % D_NBUF) * D_HB, X[0]); }
+      else issue_x(ic_t<0>{}, ic_t<0>{}, ic_t<0>{}, ic_t<0>{}, (unsigned)(k % D_NBUF) * D_HB, X[0]);
       cur = nxt;
     }
   }
@@ -754,6 +824,26 @@ __global__ void pack_frag_weights_sc_kernel(const f16* __restrict__ wsc, f16* __
   *reinterpret_cast<uint4*>(wf + ((long long)9 * nslab * ntn * 1024 + t) * 8) = *reinterpret_cast<const uint4*>(wsc + (long long)n * ld + k);
 }
 
+// D_UPS: the parity-folded weights w_par[q][Nrows][t][Cin] (launch_make_parity_weights) in the same fragment order, block (q, t, slab, channel tile) at
+// ((q 4 + t) nslab + slab) ntn + nt
+__global__ void pack_frag_weights_par_kernel(const f16* __restrict__ wpar, f16* __restrict__ wf, int N, int Nrows, int Cin) {
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int nslab = Cin >> 6, ntn = N >> 7;
+  const long long total = (long long)16 * nslab * ntn * 16 * 64;
+  if (t >= total) return;
+  const int lane = (int)(t & 63);
+  long long f = t >> 6;
+  const int kh = (int)(f & 1); f >>= 1;
+  const int a = (int)(f & 3); f >>= 2;
+  const int wn = (int)(f & 1); f >>= 1;
+  const int nt = (int)(f % ntn); f /= ntn;
+  const int slab = (int)(f % nslab); f /= nslab;
+  const int tap = (int)(f & 3), q = (int)(f >> 2);
+  const int n = nt * 128 + wn * 64 + a * 16 + (lane & 15);
+  const int k = slab * 64 + kh * 32 + (lane >> 4) * 8;
+  *reinterpret_cast<uint4*>(wf + t * 8) = *reinterpret_cast<const uint4*>(wpar + (((long long)q * Nrows + n) * 4 + tap) * Cin + k);
+}
+
 int d_num_cus() {
   static std::mutex mu;
   static std::map<int, int> cus;
@@ -771,7 +861,8 @@ template <int FLAGS>
 void launch_c3d(const ConvParams& p, hipStream_t s) {
   auto kern = conv3x3d_kernel<FLAGS>;
   ensure_dyn_smem(reinterpret_cast<const void*>(kern), (int)D_LDS);
-  const int units = p.B * (p.Hout >> 4) * (p.Wout >> 4) * (p.N >> 7);
+  constexpr bool UPS = (FLAGS & D_UPS) != 0;
+  const int units = UPS ? p.B * (p.Hin >> 4) * (p.Win >> 4) * 4 * (p.N >> 7) : p.B * (p.Hout >> 4) * (p.Wout >> 4) * (p.N >> 7);
   // Run length (units per workgroup): 1 where the executor says its graph shares the chip (the sampler's decode beside the next UNet pass),
   // else 0 = one workgroup per CU walking its whole share; LDIFF_C3D_RUN overrides.  The kernel alone is
   // fastest fully persistent (0.43 of the MFMA peak against 0.42), but the sampler decodes on a side stream beside the next UNet pass, and a
@@ -782,7 +873,9 @@ void launch_c3d(const ConvParams& p, hipStream_t s) {
   int grid = units < d_num_cus() ? units : d_num_cus();
   if (run_cap > 0 && units > grid * run_cap) grid = (units + run_cap - 1) / run_cap;
   const double bytes = (double)p.B * p.Hin * p.Win * p.C1 * 2.0 + (double)p.N * p.K * 2.0 + (double)p.M * p.N * 2.0 + (p.res ? (double)p.M * p.N * 2.0 : 0.0);
-  ProfScope prof("conv3x3<16x16d,128,gn>", 2.0 * p.M * (double)p.N * (p.K + p.Cs), bytes + (double)p.M * p.Cs * 2.0 + (double)p.N * p.Cs * 2.0, s);
+  // (D_UPS: executed flops -- four taps per output pixel -- as the parity-folded 16 x 16 kernel counts them)
+  ProfScope prof(UPS ? "conv3x3<16x16d,128,ups>" : "conv3x3<16x16d,128,gn>", UPS ? 2.0 * p.M * (double)p.N * 4.0 * p.C1 : 2.0 * p.M * (double)p.N * (p.K + p.Cs),
+                 bytes + (double)p.M * p.Cs * 2.0 + (double)p.N * p.Cs * 2.0, s);
   hipLaunchKernelGGL(kern, dim3(grid), dim3(512), D_LDS, s, p, units);
   HIP_CHECK(hipGetLastError());
 }
@@ -792,6 +885,11 @@ void launch_c3d(const ConvParams& p, hipStream_t s) {
 void launch_pack_frag_weights_sc(const f16* wsc, f16* wf, int N, int Cin, int Cs, int ld_wsc, hipStream_t s) {
   const long long total = (long long)(Cs >> 6) * (N >> 7) * 16 * 64;
   hipLaunchKernelGGL(pack_frag_weights_sc_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, wsc, wf, N, Cin, Cs, ld_wsc);
+  HIP_CHECK(hipGetLastError());
+}
+void launch_pack_frag_weights_par(const f16* wpar, f16* wf, int N, int Nrows, int Cin, hipStream_t s) {
+  const long long total = (long long)16 * (Cin >> 6) * (N >> 7) * 16 * 64;
+  hipLaunchKernelGGL(pack_frag_weights_par_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, wpar, wf, N, Nrows, Cin);
   HIP_CHECK(hipGetLastError());
 }
 void launch_pack_frag_weights(const f16* w, f16* wf, int N, int Cin, hipStream_t s) {
@@ -804,23 +902,40 @@ void launch_pack_frag_weights(const f16* w, f16* wf, int N, int Cin, hipStream_t
 bool conv3x3d_selected(const ConvParams& p) {
   static const int mode = [] { const char* e = getenv("LDIFF_CONV3X3_DATAFLOW"); return e ? atoi(e) : 1; }();
   if (mode == 0) return false;
-  if (p.ks != 3 || p.stride != 1 || p.pad_t != 1 || p.pad_l != 1 || p.ups != 0 || p.w_par || p.splitk > 1) return false;
-  if (!p.gn_scale || !p.silu_in || p.x2 || p.C2 != 0 || p.C1 % 64 != 0 || p.N % 128 != 0 || p.Nrows < p.N) return false;
-  if (p.Hout % 16 != 0 || p.Wout % 16 != 0 || p.Hin != p.Hout || p.Win != p.Wout) return false;
+  if (p.ks != 3 || p.stride != 1 || p.pad_t != 1 || p.pad_l != 1 || p.splitk > 1) return false;
+  if (p.x2 || p.C2 != 0 || p.C1 % 64 != 0 || p.N % 128 != 0 || p.Nrows < p.N) return false;
+  const bool ups = p.ups != 0;
+  if (ups) {   // nearest-2x upsample folded into the conv (ConvParams::w_par): no prologue, no residual, no time embedding; LDIFF_C3D_UPS=0: the 16 x 16 ping-pong kernel
+    // Where it is chosen: measured against the 16 x 16 ping-pong kernel on one box (profiles/r05_conv3x3d_upsample.txt) it wins 11 % on the 256^2 -> 512^2 conv with one
+    // persistent workgroup per CU and nothing (0 ... +4 % time) on the smaller maps or with one-unit runs beside the UNet stream -- a parity unit streams a whole halo
+    // image for four taps instead of nine, so the producers' DMA per MFMA is 2.25 times the plain conv's; the whole step, where the decode runs one-unit workgroups, gets
+    // 0.3-0.9 % SLOWER.  So it is OFF unless asked for: ConvParams::c3d_ups = 1 (tests, timing) or LDIFF_C3D_UPS=1 for the whole process.  (A choice by short_runs would
+    // also give the pipelined and the serial sampler different kernels for one layer, and bench.py checks the two bit for bit.)
+    static const int env = [] { const char* e = getenv("LDIFF_C3D_UPS"); return e ? (atoi(e) != 0 ? 1 : -1) : 0; }();
+    const int want = p.c3d_ups ? p.c3d_ups : env;
+    if (want <= 0) return false;
+    if (!p.w_par || p.gn_scale || p.res || p.temb || p.xs || p.Hin % 16 != 0 || p.Win % 16 != 0 || p.Hout != 2 * p.Hin || p.Wout != 2 * p.Win) return false;
+  } else {
+    if (p.w_par || !p.gn_scale || !p.silu_in) return false;
+    if (p.Hout % 16 != 0 || p.Wout % 16 != 0 || p.Hin != p.Hout || p.Win != p.Wout) return false;
+  }
   if (p.out_f32 || p.y_lo || p.res_lo || (p.ldy & 7) || (p.res && (p.ld_res & 7))) return false;
   if (p.xs && (p.res || p.Cs % 64 != 0 || p.Cs <= 0 || ((p.lds ? p.lds : p.Cs) & 7) || (long long)p.B * p.Hin * p.Win * (p.lds ? p.lds : p.Cs) * 2 >= (1LL << 31))) return false;
   const long long px = (long long)p.B * p.Hin * p.Win;
   if (px * (p.ld1 ? p.ld1 : p.C1) * 2 >= (1LL << 31) || (long long)p.M * p.ldy * 2 >= (1LL << 31) || (p.res && (long long)p.M * p.ld_res * 2 >= (1LL << 31))) return false;
   if ((long long)p.Nrows * 9 * p.C1 * 2 >= (1LL << 31)) return false;
-  const long long units = (long long)p.B * (p.Hout >> 4) * (p.Wout >> 4) * (p.N >> 7);
+  const long long units = (long long)p.B * (p.Hin >> 4) * (p.Win >> 4) * (p.N >> 7) * (ups ? 4 : 1);
   if (mode == 2) return true;
   const int cus = d_num_cus();
   const long long rounds = (units + cus - 1) / cus;
   return units >= cus && units * 100 >= rounds * cus * 88;   // the runs must split evenly over the CUs
 }
 // (+ the folded shortcut's blocks and, behind them, one unread step of padding: the consumers load one step ahead)
-size_t conv3x3d_frag_bytes(const ConvParams& p) { return (size_t)p.N * (9 * p.C1 + p.Cs) * sizeof(f16) + (p.Cs ? (size_t)(p.N >> 7) * 16384 + 16384 : 0); }
-int conv3x3d_stats_blocks(const ConvParams& p) { return (p.Hout >> 4) * (p.Wout >> 4) * 2; }   // one row block per consumer wave pair (8 x 16 pixels)
+size_t conv3x3d_frag_bytes(const ConvParams& p) {
+  if (p.ups) return (size_t)p.N * 16 * p.C1 * sizeof(f16) + (size_t)(p.N >> 7) * 16384 + 16384;   // 4 parities x 4 taps (+ one unread step behind the last)
+  return (size_t)p.N * (9 * p.C1 + p.Cs) * sizeof(f16) + (p.Cs ? (size_t)(p.N >> 7) * 16384 + 16384 : 0);
+}
+int conv3x3d_stats_blocks(const ConvParams& p) { return p.ups ? (p.Hin >> 4) * (p.Win >> 4) * 8 : (p.Hout >> 4) * (p.Wout >> 4) * 2; }   // one row block per consumer wave pair (8 x 16 pixels)
 #ifdef C3D_STAMPS
 extern "C" int ldiff_debug_c3d_stamps(unsigned long long* out) {   // diagnostic build only
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(c3d_dbg), sizeof(unsigned long long) * 48);
@@ -828,8 +943,10 @@ extern "C" int ldiff_debug_c3d_stamps(unsigned long long* out) {   // diagnostic
 #endif
 void launch_conv3x3d(const ConvParams& p, hipStream_t s) {
   LDIFF_CHECK(p.w_frag != nullptr, LDIFF_ERR_INVALID, "conv3x3 (dataflow): the caller did not provide the fragment-packed weights (launch_pack_frag_weights)");
-  const int f = (p.res ? D_RES : 0) | (p.stats ? D_STATS : 0) | (p.xs ? D_SC : 0);
-  if (f == 0) launch_c3d<0>(p, s);
+  const int f = (p.res ? D_RES : 0) | (p.stats ? D_STATS : 0) | (p.xs ? D_SC : 0) | (p.ups ? D_UPS : 0);
+  if (f == D_UPS) launch_c3d<D_UPS>(p, s);
+  else if (f == (D_UPS | D_STATS)) launch_c3d<D_UPS | D_STATS>(p, s);
+  else if (f == 0) launch_c3d<0>(p, s);
   else if (f == 1) launch_c3d<1>(p, s);
   else if (f == 2) launch_c3d<2>(p, s);
   else if (f == 3) launch_c3d<3>(p, s);

@@ -43,6 +43,7 @@ struct MatW {   // [Nrows][K] fp16 K-major + fp32 bias
   mutable Derived dup;            //   split operand: [Nrows][taps][2*Cin] (same weights against the hi and the lo half); key = C1 of a concat
   mutable Derived dup_par;        //   parity weights of the duplicated matrix
   mutable Derived frag;           //   MFMA-fragment-packed copy for the dataflow conv3x3 kernel (kernels_conv3x3d.hip)
+  mutable Derived frag_par;       //   ... of the parity weights (upsampling convs on the dataflow kernel)
   mutable Derived frag_sc;        //   ... with a folded shortcut's weights behind the nine taps (key = the shortcut matrix's address bits) and the summed bias
   mutable float* bias_sc = nullptr;
   mutable Derived gfrag;          //   MFMA-fragment-packed copy for the dataflow GEMM (kernels_gemm_df.hip)
@@ -125,6 +126,7 @@ class Exec {
   const f16* derived_dup(const MatW& w, int C1_logical, int C2_logical);
   const f16* derived_par(const MatW& w, const f16* src, int Cin, Derived& d);
   const f16* derived_frag(const MatW& w, const ConvParams& p);
+  const f16* derived_frag_par(const MatW& w, const ConvParams& p);   // ... of the parity-folded weights p.w_par (ups = 1)
   const f16* derived_frag_sc(const MatW& w, const MatW& sc, const ConvParams& p, const float** bias_sum);   // ... + the folded shortcut
   const f16* derived_tiled(const MatW& w, int N);
   const f16* derived_gfrag(const MatW& w, const f16* src, int K, Derived& d, int key);   // fragment-packed copy of `src` [Nrows][K] for the dataflow GEMM

@@ -323,6 +323,21 @@ const f16* Exec::derived_frag(const MatW& w, const ConvParams& p) {
   }
   return w.frag.p;
 }
+const f16* Exec::derived_frag_par(const MatW& w, const ConvParams& p) {
+  const int gen = weights_gen ? *weights_gen : 0;
+  if (!w.frag_par.p) {
+    void* q = nullptr;
+    HIP_CHECK(hipMalloc(&q, conv3x3d_frag_bytes(p)));
+    HIP_CHECK(hipMemset(q, 0, conv3x3d_frag_bytes(p)));   // (the padding step behind the last block is loaded, never used)
+    owned.push_back(q);
+    w.frag_par.p = (f16*)q;
+  }
+  if (w.frag_par.gen != gen) {   // first use, or the checkpoint was reloaded since (p.w_par has been rebuilt by derived_par just before)
+    launch_pack_frag_weights_par(p.w_par, w.frag_par.p, p.N, p.Nrows, p.C1, s);
+    w.frag_par.gen = gen;
+  }
+  return w.frag_par.p;
+}
 const f16* Exec::derived_frag_sc(const MatW& w, const MatW& sc, const ConvParams& p, const float** bias_sum) {
   const int gen = weights_gen ? *weights_gen : 0;
   if (!w.frag_sc.p) {
@@ -409,6 +424,7 @@ Act Exec::conv(const MatW& w, const Act& x, const Act* x2, const ConvOpts& o) {
   LDIFF_CHECK(p.C1 + p.C2 == Cin_eff, LDIFF_ERR_INVALID, "conv: input has %d channels, weight expects %d", p.C1 + p.C2, Cin_eff);
   p.B = x.B; p.Hin = x.H; p.Win = x.W;
   p.ks = w.ks; p.stride = o.stride; p.ups = o.ups;
+  p.short_runs = short_runs ? 1 : 0;   // (before anything that asks which kernel takes the launch: the choice may depend on it)
   p.pad_t = o.pad_t < 0 ? (w.ks - 1) / 2 : o.pad_t;
   p.pad_l = o.pad_l < 0 ? (w.ks - 1) / 2 : o.pad_l;
   const int He = x.H << o.ups, We = x.W << o.ups;
@@ -481,7 +497,6 @@ Act Exec::conv(const MatW& w, const Act& x, const Act* x2, const ConvOpts& o) {
   }
   if (!o.out_f32 && p.splitk > 1) p.splitk_ws = tmp<float>((size_t)p.splitk * p.M * p.N);
   else p.splitk = 0;
-  p.short_runs = short_runs ? 1 : 0;
   if (o.sc_done) *o.sc_done = false;
   if (o.sc_x && o.sc_w && o.sc_done && !o.split_in && !o.res && !o.sc_x->split && o.sc_w->ks == 1 && o.sc_w->Nrows == w.Nrows) {
     // fold the block's 1x1 shortcut into this conv where the dataflow kernel takes the launch (LDIFF_C3D_FOLD_SC=0: never)
@@ -500,7 +515,7 @@ Act Exec::conv(const MatW& w, const Act& x, const Act* x2, const ConvOpts& o) {
     return Act{};
   }
   if (p.xs) {}
-  else if (!o.split_in && conv3x3_eligible(p) && conv3x3d_selected(p)) p.w_frag = derived_frag(w, p);   // dataflow kernel: MFMA-fragment-packed weights
+  else if (!o.split_in && conv3x3_eligible(p) && conv3x3d_selected(p)) p.w_frag = p.ups ? derived_frag_par(w, p) : derived_frag(w, p);   // dataflow kernel: MFMA-fragment-packed weights
   else if (!wfold && w.ks == 1 && !(o.split_in && x.lo8) && !conv3x3_eligible(p) && gemm_df_selected(p))   // dataflow GEMM: the same, of the matrix this launch reads
     p.w_frag = derived_gfrag(w, wsrc, p.K, o.split_in ? w.gfrag_dup : w.gfrag, o.split_in ? x.C : 0);
   launch_igemm(p, s);

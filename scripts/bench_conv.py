@@ -20,6 +20,8 @@ SHAPES = {
     "vae256_256_256_nogn": (8, 256, 0, 256, 256, 256, 3, 1, 0, 0),
     "vae512_256_128_gn": (8, 256, 0, 512, 512, 128, 3, 1, 0, 1),
     "vae512_up_256_256": (8, 256, 0, 256, 256, 256, 3, 1, 1, 0),
+    "vae256_up_512_512": (8, 512, 0, 128, 128, 512, 3, 1, 1, 0),
+    "vae128_up_512_512": (8, 512, 0, 64, 64, 512, 3, 1, 1, 0),
     "vae256_256_256_gn": (8, 256, 0, 256, 256, 256, 3, 1, 0, 1),
     "vae128_512_512_gn": (8, 512, 0, 128, 128, 512, 3, 1, 0, 1),
     "vae64_512_512_gn": (8, 512, 0, 64, 64, 512, 3, 1, 0, 1),

@@ -984,6 +984,54 @@ def test_conv3x3_dataflow_kernel(lib, shape, res, stats, temb):
             assert err <= 1e-4, f"launch {it}: fused statistics differ from the sums of the outputs by {err:.3e}"
 
 
+@pytest.mark.parametrize("shape", ["two_slabs_one_channel_tile", "four_slabs_two_channel_tiles", "two_slabs_one_channel_tile_short_runs", "one_slab"])
+@pytest.mark.parametrize("stats", [0, 1])
+def test_conv3x3_dataflow_kernel_upsample(lib, shape, stats):
+    """Upsample2D (nearest 2x) + conv3x3 of the VAE decoder on the producer / consumer kernel (ups = 1: four parity units per pixel tile, four pre-summed
+    taps each, raw operand, outputs interleaved into the 2H x 2W map) against torch's interpolate + conv2d; the fused statistics against the sums of the
+    kernel's own outputs; three launches each, bit-identical (progress words: a missing wait shows up as a now-and-then wrong tile)."""
+    short = shape.endswith("_short_runs")
+    B, Cin, H, W, Cout = {"two_slabs_one_channel_tile": (2, 128, 128, 128, 128), "four_slabs_two_channel_tiles": (1, 256, 64, 128, 256),
+                          "one_slab": (2, 64, 128, 128, 128)}[shape.replace("_short_runs", "")]
+    g = torch.Generator().manual_seed(stats + len(shape))
+    x = torch.randn((B, H, W, Cin), generator=g).to(torch.float16)
+    w = (torch.randn((Cout, 3, 3, Cin), generator=g) / math.sqrt(9 * Cin)).to(torch.float16)
+    bias = torch.randn(Cout, generator=g) * 0.1
+    up = F.interpolate(x.float().permute(0, 3, 1, 2), scale_factor=2.0, mode="nearest")
+    ref = F.conv2d(up, w.float().permute(0, 3, 1, 2), bias, padding=1)
+    xd, wd, bd = x.to(DEV), w.reshape(Cout, -1).contiguous().to(DEV), bias.to(DEV)
+    a_ = _lib.ConvArgs()
+    a_.x, a_.C1, a_.B, a_.Hin, a_.Win, a_.Hout, a_.Wout = xd.data_ptr(), Cin, B, H, W, 2 * H, 2 * W
+    a_.ks, a_.stride, a_.pad_t, a_.pad_l, a_.ups, a_.c3d_ups = 3, 1, 1, 1, 1, 1
+    a_.w, a_.N, a_.Nrows, a_.bias = wd.data_ptr(), Cout, Cout, bd.data_ptr()
+    a_.short_runs = 1 if short else 0
+    y = torch.empty((B, 2 * H, 2 * W, Cout), dtype=torch.float16, device=DEV)
+    a_.y, a_.ldy = y.data_ptr(), Cout
+    if stats:
+        R = lib.ldiff_op_conv_stats_blocks(C.byref(a_))
+        assert R > 0
+        st = torch.empty((B, Cout, R, 2), device=DEV)
+        a_.stats = st.data_ptr()
+    first = None
+    for it in range(3):
+        y.fill_(float("nan"))
+        if stats:
+            st.fill_(float("nan"))
+        _lib.check(lib.ldiff_op_conv(C.byref(a_), sp()))
+        torch.cuda.synchronize()
+        # (the four taps of a parity are sums of up to four fp16 weights, rounded to fp16 once more: 6e-4, as for the other parity-folded kernels)
+        assert_close(y.float().cpu().permute(0, 3, 1, 2), ref, f"{shape} launch {it}")
+        if first is None:
+            first = y.clone()
+        assert torch.equal(y, first), f"launch {it} differs from the first"
+        if stats:
+            sums = st.double().cpu().sum(dim=2)
+            yd = y.double().cpu()
+            want = torch.stack([yd.sum(dim=(1, 2)), (yd * yd).sum(dim=(1, 2))], dim=-1)
+            assert torch.isfinite(sums).all(), f"launch {it}: statistics not written everywhere"
+            assert ((sums - want).abs() / (want.abs() + 4 * H * W * 1e-3)).max().item() <= 1e-4
+
+
 @pytest.mark.parametrize("shape", ["vae_256_to_128", "vae_512_to_256", "one_slab_each", "vae_256_to_128_short_runs", "pitched_source"])
 @pytest.mark.parametrize("stats", [0, 1])
 def test_conv3x3_dataflow_kernel_with_folded_shortcut(lib, shape, stats):

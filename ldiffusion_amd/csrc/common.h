@@ -54,6 +54,7 @@ struct ConvParams {
   int ks, stride, pad_t, pad_l, ups;
   const f16* w;      // [Nrows, K] K-major, Nrows = roundup(N,16), rows >= N zero
   int N, Nrows, K;   // N = columns stored (multiple of 4)
+  int nt_hint = 0;   // dataflow conv: stream source, residual and output past L2 (set by its launcher)
   int c3d_ups = 0;   // upsampling conv on the dataflow kernel: 1 = wherever eligible (tests, timing); 0 / -1 = no (conv3x3d_selected: it does not pay in the step)
   int n_real = 0;    // output channels of the layer before that rounding (0: not stated; kernels that need it decline)
   const float* gn_scale;  // [B, Cin] or nullptr

@@ -165,6 +165,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3d_kernel(const ConvParams p, co
   if (wave >= 4) {
     // ================================================= PRODUCERS =================================================
     const int pw = wave - 4;
+    // tensors that no cache level holds until their next use stream past L2 (non-temporal halo DMA, residual reads and stores: launch_c3d decides, ConvParams::nt_hint):
+    // the weight fragments every unit re-reads stay resident instead
+    const bool nt = p.nt_hint != 0;
     const int ld1 = p.ld1 ? p.ld1 : p.C1;
     const __amdgpu_buffer_rsrc_t scrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.gn_scale, 0, (int)((long long)p.B * Cin * 4), 0x00020000);
     const __amdgpu_buffer_rsrc_t shrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.gn_shift, 0, (int)((long long)p.B * Cin * 4), 0x00020000);
@@ -259,7 +262,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3d_kernel(const ConvParams p, co
             if ((sc.vbits >> r) & 1u) voff = ((hy * W + hx) * lds2 + (((lane & 7) ^ d_swzx(hx)) << 3)) * 2;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(sc.xrsrc2, (lptr_t*)dst, 16, voff, (sc.c - nslab) * 128, 0, 0);
           } else
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(sc.xrsrc, (lptr_t*)dst, 16, voff, sc.c * 128, 0, 0);
+            { if (nt) __builtin_amdgcn_raw_ptr_buffer_load_lds(sc.xrsrc, (lptr_t*)dst, 16, voff, sc.c * 128, 0, 2); else __builtin_amdgcn_raw_ptr_buffer_load_lds(sc.xrsrc, (lptr_t*)dst, 16, voff, sc.c * 128, 0, 0); }
 #endif
           ++n;
         }
@@ -330,7 +333,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3d_kernel(const ConvParams p, co
       u32x4 R[16];
       if constexpr (RES) {   // (nothing of this wave's is in flight here: the compiler's own waits for these loads are exact)
 #pragma unroll
-        for (int j = 0; j < 16; ++j) R[j] = __builtin_amdgcn_raw_buffer_load_b128(rrsrc, rlane + (int)(rbase + (unsigned)(((j >> 1) * W + (j & 1) * 8) * p.ld_res) * 2u), 0, 0);
+        for (int j = 0; j < 16; ++j) {
+          const int ro = rlane + (int)(rbase + (unsigned)(((j >> 1) * W + (j & 1) * 8) * p.ld_res) * 2u);
+          R[j] = nt ? __builtin_amdgcn_raw_buffer_load_b128(rrsrc, ro, 0, 2) : __builtin_amdgcn_raw_buffer_load_b128(rrsrc, ro, 0, 0);
+        }
       }
       while ((int)flags_min_now(eflags) < i + 1) { __builtin_amdgcn_s_sleep(2); DACC(8, 1); }
       u32x4 U[16];
@@ -365,7 +371,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3d_kernel(const ConvParams p, co
         }
         // (offset in the VGPR and a wait state behind the store: with an SGPR soffset a VALU write of the data registers right after a
         // 16-byte store is seen by the store -- profiles/r02_conv3x3_pingpong.md)
-        __builtin_amdgcn_raw_buffer_store_b128(o, yrsrc, ylane + (int)(ybase + (unsigned)(((j >> 1) * yrow + (j & 1) * 8 * ypx) * p.ldy) * 2u), 0, 0);
+        {
+          const int so = ylane + (int)(ybase + (unsigned)(((j >> 1) * yrow + (j & 1) * 8 * ypx) * p.ldy) * 2u);
+          if (nt) __builtin_amdgcn_raw_buffer_store_b128(o, yrsrc, so, 0, 2); else __builtin_amdgcn_raw_buffer_store_b128(o, yrsrc, so, 0, 0);
+        }
         asm volatile("s_nop 1" ::: "memory");
         if constexpr (ST) {
 #pragma unroll
@@ -876,7 +885,14 @@ void launch_c3d(const ConvParams& p, hipStream_t s) {
   // (D_UPS: executed flops -- four taps per output pixel -- as the parity-folded 16 x 16 kernel counts them)
   ProfScope prof(UPS ? "conv3x3<16x16d,128,ups>" : "conv3x3<16x16d,128,gn>", UPS ? 2.0 * p.M * (double)p.N * 4.0 * p.C1 : 2.0 * p.M * (double)p.N * (p.K + p.Cs),
                  bytes + (double)p.M * p.Cs * 2.0 + (double)p.N * p.Cs * 2.0, s);
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), D_LDS, s, p, units);
+  // Non-temporal streaming where source AND output are beyond what L2 / the MALL keep between layers (>= 192 MB each: the 256^2 and 512^2 maps of the decoder at B = 8):
+  // same box, one unit per workgroup, residual + statistics: 128 -> 128 @512^2 889 -> 849 us, 256 -> 128 @512^2 1249 -> 1210, 256 -> 256 @256^2 628 -> 602; on the 128^2 /
+  // 64^2 maps (the four channel tiles of a pixel tile re-read its halo from L2) it costs 0 ... 4 % (profiles/r05_conv3x3d_cache_hints.txt).  LDIFF_C3D_NT=0 / 1: never / always.
+  static const int nt_env = [] { const char* e = getenv("LDIFF_C3D_NT"); return e ? (atoi(e) != 0 ? 1 : 0) : -1; }();
+  ConvParams q = p;
+  const double in_b = (double)p.B * p.Hin * p.Win * p.C1 * 2.0, out_b = (double)p.M * p.N * 2.0;
+  q.nt_hint = nt_env >= 0 ? nt_env : ((p.short_runs || (in_b >= 192e6 && out_b >= 192e6)) ? 1 : 0);   // beside the UNet stream: always (whole step, same box: 155.5 / 155.0 ms without, 154.4 / 153.1 with the size rule, 152.8 / 153.6 always)
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), D_LDS, s, q, units);
   HIP_CHECK(hipGetLastError());
 }
 

@@ -19,6 +19,16 @@
  *     stream); no hidden synchronisation.  A handle is thread-compatible, not thread-safe; handles on different
  *     devices are independent (no process-wide device state in the library).
  *   - there is no CPU fallback anywhere: a missing GPU or code object is an error.
+ *   - Non-finite detection.  Activations are stored as fp16 (also under precision 1 / 2: the hi half of a split tensor is an fp16), so a checkpoint /
+ *     input whose activations leave +-65504 overflows where the reference's fp32 graph does not -- e.g. the SD-v1.x decoder fed z / 0.18215 of UN-scaled
+ *     latents (pixel_latent_vector.py:73,81).  Every graph therefore carries a sticky flag, set on the device by the GroupNorm-statistics kernels when a
+ *     group's totals are not finite (every activation reaches one: an inf from a conv / GEMM epilogue, or the NaN it becomes downstream; no extra launch,
+ *     no extra read).  It is reported as LDIFF_ERR_NONFINITE (-4; python: RuntimeError subclass NonFiniteError)
+ *       (a) by ldiff_{unet,vae,pipeline}_check_finite(handle, stream): synchronises `stream` (and the decode side stream), returns the verdict
+ *           for everything enqueued so far and clears the flag -- the python shims call it wherever they hand results to the host;
+ *       (b) at the latest by the NEXT ldiff_unet_forward / ldiff_vae_encode / ldiff_vae_decode / ldiff_sample on the handle, at entry, for work that has
+ *           completed by then (no synchronisation; the flag is cleared when reported).
+ *     The results of a flagged call are garbage.  LDIFF_TRACE_ABSMAX=1 prints max |activation| per graph stage to stderr (diagnostic; synchronises).
  */
 #ifndef LDIFF_H
 #define LDIFF_H
@@ -27,10 +37,10 @@
 extern "C" {
 #endif
 
-#define LDIFF_VERSION 152 /* 0.1.5.2: + ldiff_conv_args.n_real (tap-folded conv_out kernel), c3d_ups (upsampling convs on the dataflow kernel); 0.1.5.1: dataflow GEMM (gemm_df), shortcut conv folded into the dataflow conv3x3 (sc_*) */
+#define LDIFF_VERSION 160 /* 0.1.6.0: + non-finite detection (LDIFF_ERR_NONFINITE, ldiff_*_check_finite), ldiff_conv_args.splitk (split launches emit statistics); 0.1.5.2: + ldiff_conv_args.n_real (tap-folded conv_out kernel), c3d_ups (upsampling convs on the dataflow kernel); 0.1.5.1: dataflow GEMM (gemm_df), shortcut conv folded into the dataflow conv3x3 (sc_*) */
 #define LDIFF_MAX_BLOCKS 8
 
-typedef enum { LDIFF_OK = 0, LDIFF_ERR_INVALID = -1, LDIFF_ERR_RUNTIME = -2, LDIFF_ERR_STATE = -3 } ldiff_status;
+typedef enum { LDIFF_OK = 0, LDIFF_ERR_INVALID = -1, LDIFF_ERR_RUNTIME = -2, LDIFF_ERR_STATE = -3, LDIFF_ERR_NONFINITE = -4 } ldiff_status;
 typedef enum { LDIFF_F32 = 0, LDIFF_F16 = 1, LDIFF_BF16 = 2 } ldiff_dtype; /* host dtypes accepted by *_load */
 
 int ldiff_version(void);
@@ -85,6 +95,8 @@ int ldiff_unet_forward(ldiff_unet*, const void* sample_dev, int B, int h, int w,
  * added to the skip connections, and one tensor added to the mid block's output (either may be absent: n_down = 0 / NULL).  The
  * pointers must stay valid until that forward has been enqueued; they are consumed by it. */
 int ldiff_unet_set_additional_residuals(ldiff_unet*, const void* const* down_dev, int n_down, const void* mid_dev);
+/* non-finite detector (see the conventions above): LDIFF_OK or LDIFF_ERR_NONFINITE for all forwards enqueued on `stream` so far; clears the flag */
+int ldiff_unet_check_finite(ldiff_unet*, void* stream);
 void ldiff_unet_destroy(ldiff_unet*);
 
 /* ------------------------------------------------------------------------------------------------
@@ -121,6 +133,8 @@ int ldiff_vae_encode(ldiff_vae*, const void* x_dev, int B, int H, int W, void* m
  *   luma_u8     [B,n_slots,8h,8w] u8, slot = PIL convert("L") of rgb_u8           (pixel_latent_vector.py:85) */
 int ldiff_vae_decode(ldiff_vae*, const void* z_dev, int B, int h, int w, float z_scale, void* sample_nchw, void* image_nhwc,
                      void* rgb_u8, void* luma_u8, int n_slots, int slot, void* stream);
+/* non-finite detector: LDIFF_OK or LDIFF_ERR_NONFINITE for all encodes / decodes enqueued so far (on `stream` and on the decode side stream) */
+int ldiff_vae_check_finite(ldiff_vae*, void* stream);
 void ldiff_vae_destroy(ldiff_vae*);
 
 /* ------------------------------------------------------------------------------------------------
@@ -186,6 +200,8 @@ int ldiff_pipeline_join(ldiff_pipeline*, void* stream);
  * features_u8 [B,N,H,W] (luma of every pass), rgb_u8 [B,H,W,3] (last pass). */
 int ldiff_sample(ldiff_pipeline*, const void* images, int B, int H, int W, int n_passes, void* latents_out, void* features_u8,
                  void* rgb_u8, void* stream);
+/* non-finite detector over both graphs of the pipeline: joins a deferred decode, synchronises `stream`, LDIFF_OK or LDIFF_ERR_NONFINITE; clears the flags */
+int ldiff_pipeline_check_finite(ldiff_pipeline*, void* stream);
 /* PLMS timesteps the sampler will visit for n_passes (host); returns the count written. */
 int ldiff_plms_timesteps(int n_passes, int64_t* out, int cap);
 void ldiff_pipeline_destroy(ldiff_pipeline*);
@@ -230,6 +246,9 @@ typedef struct {
                                                        not pay in the sampler's step) */
   int n_real;                                       /* output channels of the layer where N (the stored columns, a multiple of 4) rounds them up; 0 = not stated.  The tap-folded
                                                        3x3 kernel for <= 3 output channels (the VAE's conv_out) runs only where this says so */
+  int splitk;                                       /* 0 = the executors' plan (none when `stats` is given: this entry point's historical behaviour); 2..16 = that many K splits
+                                                       (tests, timing): fp32 partials + the reduce kernel, which then also emits `stats` in blocks of 32 rows
+                                                       (ldiff_op_conv_stats_blocks accounts for it; needs 32 | Hout * Wout).  fp16 output, no GEGLU, no parity-folded upsampling */
 } ldiff_conv_args;
 int ldiff_op_conv(const ldiff_conv_args*, void* stream);
 /* row blocks per image the launch would emit statistics for (0 = unsupported for this shape) */

@@ -37,7 +37,7 @@ class ConvArgs(C.Structure):
                 ("res", C.c_void_p), ("ld_res", C.c_int), ("y", C.c_void_p), ("ldy", C.c_int), ("out_f32", C.c_int), ("stats", C.c_void_p),
                 ("geglu", C.c_int), ("ld1", C.c_int), ("ld2", C.c_int), ("res_lo", C.c_int), ("y_lo", C.c_int), ("short_runs", C.c_int),
                 ("lo8_slab0", C.c_int), ("lo8_scale", C.c_void_p), ("gemm_df", C.c_int),
-                ("sc_x", C.c_void_p), ("sc_C", C.c_int), ("sc_ld", C.c_int), ("sc_w", C.c_void_p), ("sc_bias", C.c_void_p), ("c3d_ups", C.c_int), ("n_real", C.c_int)]
+                ("sc_x", C.c_void_p), ("sc_C", C.c_int), ("sc_ld", C.c_int), ("sc_w", C.c_void_p), ("sc_bias", C.c_void_p), ("c3d_ups", C.c_int), ("n_real", C.c_int), ("splitk", C.c_int)]
 
 
 # name -> (restype, argtypes); every symbol include/ldiff.h declares
@@ -55,6 +55,7 @@ SIGNATURES = {
     "ldiff_unet_set_context": (I, [P, P, I, I, P]),
     "ldiff_unet_forward": (I, [P, P, I, I, I, F, P, P]),
     "ldiff_unet_set_additional_residuals": (I, [P, C.POINTER(P), I, P]),
+    "ldiff_unet_check_finite": (I, [P, P]),
     "ldiff_unet_destroy": (None, [P]),
     "ldiff_vae_create": (I, [C.POINTER(P), C.POINTER(VaeCfg), I]),
     "ldiff_vae_load": (I, [P, C.c_char_p, P, I, C.POINTER(I64), I]),
@@ -63,6 +64,7 @@ SIGNATURES = {
     "ldiff_vae_missing_name": (C.c_char_p, [P, I]),
     "ldiff_vae_encode": (I, [P, P, I, I, I, P, P]),
     "ldiff_vae_decode": (I, [P, P, I, I, I, F, P, P, P, P, I, I, P]),
+    "ldiff_vae_check_finite": (I, [P, P]),
     "ldiff_vae_destroy": (None, [P]),
     "ldiff_pndm_step": (I, [C.POINTER(F), C.POINTER(P), I, P, I64, P]),
     "ldiff_pndm_alphas_cumprod": (I, [C.POINTER(F), I]),
@@ -78,6 +80,7 @@ SIGNATURES = {
     "ldiff_pipeline_set_overlap": (I, [P, I]),
     "ldiff_pipeline_join": (I, [P, P]),
     "ldiff_sample": (I, [P, P, I, I, I, I, P, P, P, P]),
+    "ldiff_pipeline_check_finite": (I, [P, P]),
     "ldiff_plms_timesteps": (I, [I, C.POINTER(I64), I]),
     "ldiff_pipeline_destroy": (None, [P]),
     "ldiff_op_conv": (I, [C.POINTER(ConvArgs), P]),
@@ -154,6 +157,11 @@ def load() -> C.CDLL:
     return lib
 
 
+class NonFiniteError(RuntimeError):
+    """LDIFF_ERR_NONFINITE: an activation left fp16's range (or turned NaN) somewhere in a graph; the call's results are invalid
+    (include/ldiff.h, "Non-finite detection")."""
+
+
 def check(rc: int) -> None:
     """Map ldiff_status to the exceptions the reference raises: bad shapes -> ValueError, else RuntimeError."""
     if rc == 0:
@@ -161,6 +169,8 @@ def check(rc: int) -> None:
     msg = load().ldiff_last_error().decode("utf-8", "replace")
     if rc == -1:
         raise ValueError(msg)
+    if rc == -4:
+        raise NonFiniteError(f"ldiff error {rc}: {msg}")
     raise RuntimeError(f"ldiff error {rc}: {msg}")
 
 

@@ -10,6 +10,14 @@
 
 const char* ldiff_error_message();
 
+// non-finite detector, reporting rule (b) of include/ldiff.h: an entry point that finds the flag of EARLIER, completed work set reports it once
+static void report_nonfinite(NonFiniteFlag& nf, const char* what) {
+  LDIFF_CHECK(!nf.test_and_clear(), LDIFF_ERR_NONFINITE,
+              "%s: a non-finite activation (fp16 overflow: |x| > 65504, or NaN) was detected in work enqueued earlier on this handle; its results are invalid. "
+              "Activations are stored as fp16 in every precision mode (set_precision 1 / 2 add mantissa bits, not range): rescale the input / checkpoint, "
+              "and use LDIFF_TRACE_ABSMAX=1 to see which stage overflows", what);
+}
+
 #define API_BEGIN try {
 #define API_END                                                  \
   }                                                              \
@@ -73,6 +81,7 @@ int ldiff_unet_set_context(ldiff_unet* u, const void* ctx_dev, int B_ctx, int L,
 int ldiff_unet_forward(ldiff_unet* u, const void* sample_dev, int B, int h, int w, float timestep, void* out_dev, void* stream) {
   API_BEGIN
   LDIFF_CHECK(u, LDIFF_ERR_INVALID, "unet_forward: null handle");
+  report_nonfinite(u->nf, "unet_forward");
   u->forward((const float*)sample_dev, B, h, w, timestep, (float*)out_dev, (hipStream_t)stream);
   API_END
 }
@@ -87,6 +96,14 @@ int ldiff_unet_set_additional_residuals(ldiff_unet* u, const void* const* down_d
     u->extra_down.push_back((const float*)down_dev[i]);
   }
   u->extra_mid = (const float*)mid_dev;
+  API_END
+}
+int ldiff_unet_check_finite(ldiff_unet* u, void* stream) {
+  API_BEGIN
+  LDIFF_CHECK(u, LDIFF_ERR_INVALID, "unet_check_finite: null handle");
+  HIP_CHECK(hipSetDevice(u->device));
+  HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
+  report_nonfinite(u->nf, "unet_check_finite");
   API_END
 }
 void ldiff_unet_destroy(ldiff_unet* u) {
@@ -131,6 +148,7 @@ const char* ldiff_vae_missing_name(ldiff_vae* v, int i) { return v ? v->ws.missi
 int ldiff_vae_encode(ldiff_vae* v, const void* x_dev, int B, int H, int W, void* moments_dev, void* stream) {
   API_BEGIN
   LDIFF_CHECK(v, LDIFF_ERR_INVALID, "vae_encode: null handle");
+  report_nonfinite(v->nf, "vae_encode");
   v->encode((const float*)x_dev, B, H, W, (float*)moments_dev, (hipStream_t)stream);
   API_END
 }
@@ -138,9 +156,19 @@ int ldiff_vae_decode(ldiff_vae* v, const void* z_dev, int B, int h, int w, float
                      void* luma_u8, int n_slots, int slot, void* stream) {
   API_BEGIN
   LDIFF_CHECK(v, LDIFF_ERR_INVALID, "vae_decode: null handle");
+  report_nonfinite(v->nf, "vae_decode");
   v->wait_side((hipStream_t)stream);   // a sampler with a deferred join may still be decoding on the side stream (same workspace)
   v->decode((const float*)z_dev, B, h, w, z_scale, (float*)sample_nchw, (float*)image_nhwc, (uint8_t*)rgb_u8, (uint8_t*)luma_u8, n_slots, slot,
             (hipStream_t)stream);
+  API_END
+}
+int ldiff_vae_check_finite(ldiff_vae* v, void* stream) {
+  API_BEGIN
+  LDIFF_CHECK(v, LDIFF_ERR_INVALID, "vae_check_finite: null handle");
+  HIP_CHECK(hipSetDevice(v->device));
+  HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
+  if (v->side_stream) HIP_CHECK(hipStreamSynchronize(v->side_stream));
+  report_nonfinite(v->nf, "vae_check_finite");
   API_END
 }
 void ldiff_vae_destroy(ldiff_vae* v) {
@@ -321,6 +349,8 @@ int ldiff_sample(ldiff_pipeline* p, const void* images, int B, int H, int W, int
   ldiff_unet* u = p->unet;
   ldiff_vae* v = p->vae;
   HIP_CHECK(hipSetDevice(u->device));
+  report_nonfinite(u->nf, "sample (unet)");
+  report_nonfinite(v->nf, "sample (vae)");
   int64_t ts[1024];
   const int nts = plms_timesteps(n_passes, ts, 1024);
   const int f = 1 << (v->cfg.n_blocks - 1), lat = v->cfg.latent_channels;
@@ -432,6 +462,20 @@ int ldiff_sample(ldiff_pipeline* p, const void* images, int B, int H, int W, int
   if (latents_out) HIP_CHECK(hipMemcpyAsync(latents_out, z, nlat * sizeof(float), hipMemcpyDeviceToDevice, s));
   API_END
 }
+int ldiff_pipeline_check_finite(ldiff_pipeline* p, void* stream) {
+  API_BEGIN
+  LDIFF_CHECK(p, LDIFF_ERR_INVALID, "pipeline_check_finite: null pipeline");
+  HIP_CHECK(hipSetDevice(p->unet->device));
+  if (p->join_pending) { HIP_CHECK(hipStreamWaitEvent((hipStream_t)stream, p->ev_decoded, 0)); p->join_pending = false; }
+  HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
+  if (p->vae->side_stream) HIP_CHECK(hipStreamSynchronize(p->vae->side_stream));
+  const bool bad_u = p->unet->nf.test_and_clear(), bad_v = p->vae->nf.test_and_clear();
+  LDIFF_CHECK(!bad_u && !bad_v, LDIFF_ERR_NONFINITE,
+              "pipeline_check_finite: a non-finite activation (fp16 overflow: |x| > 65504, or NaN) was detected in the %s graph; the results of that call are invalid. "
+              "Activations are stored as fp16 in every precision mode (set_precision 1 / 2 add mantissa bits, not range): rescale the input / checkpoint, "
+              "and use LDIFF_TRACE_ABSMAX=1 to see which stage overflows", bad_u && bad_v ? "UNet and VAE" : bad_u ? "UNet" : "VAE");
+  API_END
+}
 void ldiff_pipeline_destroy(ldiff_pipeline* p) {
   if (!p) return;
   (void)hipDeviceSynchronize();
@@ -485,6 +529,12 @@ int ldiff_op_conv(const ldiff_conv_args* a, void* stream) {
   API_BEGIN
   ConvParams p;
   conv_args_to_params(a, p);
+  if (a->splitk) {   // an explicit split count (tests, timing): validated here, the kernels take it as the executors' plans
+    LDIFF_CHECK(a->splitk >= 2 && a->splitk <= 16 && !p.out_f32 && !p.geglu && !p.ups && !p.xs && !p.lo8_slab0 && p.df_force <= 0, LDIFF_ERR_INVALID,
+                "op_conv: splitk = %d needs 2..16 splits, an fp16 output and a plain 3x3 / 1x1 / strided launch", a->splitk);
+    LDIFF_CHECK(a->splitk <= (conv3x3_eligible(p) ? (p.C1 + p.C2) / 64 : (p.K + 63) / 64), LDIFF_ERR_INVALID, "op_conv: more splits than K steps");
+    p.splitk = a->splitk;
+  }
   p.stats_R = p.stats ? conv_stats_blocks_per_image(p) : 0;
   LDIFF_CHECK(!p.stats || p.stats_R > 0, LDIFF_ERR_INVALID, "op_conv: fused statistics are not supported for this shape");
   // same split-K plan and 2x-upsample folding the executors use.  This test/bench entry point has no handle to own the scratch, so
@@ -511,7 +561,8 @@ int ldiff_op_conv(const ldiff_conv_args* a, void* stream) {
   }
   const bool df_asked = p.df_force > 0;
   if (df_asked) LDIFF_CHECK(!conv3x3_eligible(p) && gemm_df_selected(p), LDIFF_ERR_INVALID, "op_conv: gemm_df asked for a launch the dataflow GEMM does not take");
-  if (!p.stats && !p.out_f32 && !df_asked) p.splitk = conv3x3_eligible(p) ? conv3x3_splitk_plan(p) : gemm_dma_eligible(p) ? gemm_dma_splitk_plan(p) : igemm_splitk_plan(p);
+  // (a folded shortcut was validated against the dataflow kernel above: a split-K plan would take the launch away from it)
+  if (!p.splitk && !p.stats && !p.out_f32 && !df_asked && !p.xs) p.splitk = conv3x3_eligible(p) ? conv3x3_splitk_plan(p) : gemm_dma_eligible(p) ? gemm_dma_splitk_plan(p) : igemm_splitk_plan(p);
   if (p.splitk > 1) p.splitk_ws = (float*)op_scratch(st, 1, (size_t)p.splitk * p.M * p.N * sizeof(float));
   if (!conv3x3_eligible(p) && gemm_df_selected(p)) {   // dataflow GEMM: fragment-packed weights, per call as above.  LDIFF_OP_CACHE_FRAG=1 (timing scripts
     // only): pack once per (matrix address, shape) -- stale as soon as the caller rewrites the matrix in place, which the tests do
@@ -537,6 +588,7 @@ int ldiff_op_conv_stats_blocks(const ldiff_conv_args* a) {
     ConvParams p;
     conv_args_to_params(a, p);
     if (p.ups && conv3x3_eligible(p)) p.w_par = p.w;   // (what ldiff_op_conv will do: the kernels choose by null / non-null only)
+    if (a->splitk > 1) p.splitk = a->splitk;
     return conv_stats_blocks_per_image(p);
   } catch (const LdiffError& e) { return e.code; }
 }

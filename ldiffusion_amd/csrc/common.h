@@ -109,7 +109,25 @@ bool conv3x3_eligible(const ConvParams& p);
 int conv3x3_splitk_plan(const ConvParams& p);
 int gemm_dma_splitk_plan(const ConvParams& p);           // ... and for the LDS-DMA GEMM (1x1 convs / linears with few tiles and a long K)
 int igemm_splitk_plan(const ConvParams& p);              // same contract for the register-staged implicit GEMM (stride-2 convs with few tiles)
-void launch_splitk_reduce(const ConvParams& p, hipStream_t s);   // sums p.splitk fp32 partials of splitk_ws and applies the epilogue
+void launch_splitk_reduce(const ConvParams& p, hipStream_t s);   // sums p.splitk fp32 partials of splitk_ws and applies the epilogue (+ the fused GroupNorm statistics: R = H W / 32)
+// Split count of a launch whose tiles do not fill the chip (round 6).  What bounds such a launch is not bytes: a workgroup takes its operand slices
+// (16 KiB per K-step) at ~0.95 us per step whatever the ring depth or the slice layout, from HBM and L2 alike (scripts/micro/hbm_ring.hip,
+// profiles/r06_hbm_ring.txt: the same 30 MB take 22 us on 80 workgroups, 13 on 160, 10.6 on 240, 8.9 on 480), so the lever is the NUMBER of workgroups --
+// against the fp32 partials a finer cut writes and the reduce launch reads.  Returns the S in [s_old, s_cap] with the shortest modelled time
+//     T(S) = 4 us + ceil(steps / S) * 0.95 us * max(1, tiles S / 330)  +  [S > 1] * (4 us + 2 * S * partial_bytes / 3 TB/s)
+// and s_old (the rule of rounds 2-5, which the B = 8 shapes were tuned with) unless the model sees at least 15 % less.
+inline int splitk_by_model(long long tiles, int steps, int min_steps, double partial_bytes, int s_old, int s_cap = 16) {
+  auto T = [&](int S) {
+    const double wgs = (double)tiles * S, per = (steps + S - 1) / S;
+    return 4.0 + per * 0.95 * (wgs > 330.0 ? wgs / 330.0 : 1.0) + (S > 1 ? 4.0 + 2.0 * S * partial_bytes / 3.0e6 : 0.0);
+  };
+  if (s_old < 1) s_old = 1;
+  int best = s_old;
+  double tb = T(s_old);
+  for (int S = s_old + 1; S <= s_cap && steps / S >= min_steps; ++S)
+    if (T(S) < tb) { tb = T(S); best = S; }
+  return tb <= 0.85 * T(s_old) ? best : s_old;
+}
 // nearest-2x upsample + conv3x3 == four 2x2 convs on the source grid (one per output parity) with pre-summed taps:
 // w_par[q][n][t][c] from w[n][ky][kx][c]  (2.25x fewer MACs than gathering 9 taps from the upsampled image)
 void launch_make_parity_weights(const f16* w, f16* w_par, int Nrows, int Cin, hipStream_t s);                  // 1 = no split; >1 needs splitk_ws of splitk*M*N floats
@@ -166,7 +184,7 @@ bool attention_prescale_supported(int d);
 struct SrcView { const f16* p; int C, ld, lo; };
 void launch_gn_stats(SrcView x1, SrcView x2 /* p == nullptr: none */, int B, int HW, int groups, float eps,
                      const float* gamma, const float* beta, float* partial /*workspace*/, size_t partial_bytes,
-                     float* scale, float* shift, hipStream_t s);
+                     float* scale, float* shift, hipStream_t s, int* nonfinite = nullptr /* sticky flag of the owning handle: set when a total is not finite */);
 size_t gn_partial_bytes(int B, int HW, int C);
 void launch_layernorm(SrcView x, f16* y, int rows, const float* gamma, const float* beta, float eps, hipStream_t s);
 // y[m, c] = act(x[m, c] * scale[b, c] + shift[b, c]) over the channel concat of one or two sources, written plain (y_lo = 0,
@@ -291,7 +309,7 @@ __device__ __forceinline__ float gelu_erf(float g) { return 0.5f * g * (1.0f + e
 // statistics pass of kernels_norm.hip).
 int conv_stats_blocks_per_image(const ConvParams& p);
 void launch_gn_finalize(const float* part1, int R1, int C1, const float* part2, int R2, int C2, int B, int HW, int groups, float eps,
-                        const float* gamma, const float* beta, float* scale, float* shift, hipStream_t s);
+                        const float* gamma, const float* beta, float* scale, float* shift, hipStream_t s, int* nonfinite = nullptr);
 
 #ifdef __HIPCC__
 // GroupNorm-apply (+SiLU) of TWO fp16 elements (one dword) -> one packed fp16 dword, six single-issue VALU instructions per element:

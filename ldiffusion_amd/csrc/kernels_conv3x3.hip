@@ -715,20 +715,17 @@ __global__ __launch_bounds__(256, BN > 128 ? 1 : 2) void conv3x3w_kernel(const C
 
 
 // split-K reduction + epilogue: y[m, n..n+3] = sum_s ws[s][m][n..] + bias + temb + res
-__global__ __launch_bounds__(256) void splitk_reduce_kernel(const ConvParams p) {
-  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  const int n4 = p.N >> 2;
-  if (i >= (long long)p.M * n4) return;
-  const long long m = i / n4;
-  const int n = (int)(i - m * n4) * 4;
-  // every partial (and the epilogue's operands below) is loaded BEFORE the first add: as a plain `for s: v += load` the compiler waits for each load
-  // in turn, eight dependent memory round trips per thread = 14.6 us per launch on 40 launches of a UNet pass (round 5; the sum order is unchanged)
+// One row's four columns: every partial (and the epilogue's operands) is loaded BEFORE the first add -- as a plain `for s: v += load` the compiler waits
+// for each load in turn, S dependent memory round trips per thread (14.6 us per launch on 40 launches of a UNet pass, round 5); the sum order is s = 0, 1, ...
+constexpr int SPLITK_MAX = 16;
+template <int SM>   // SM = 8: plans of up to eight splits (every launch before round 6); 16: the finer cuts of the small grids
+__device__ __forceinline__ f32x4 splitk_row(const ConvParams& p, long long m, int n) {
   const float* wsp = p.splitk_ws + m * p.N + n;
   const long long sstride = (long long)p.M * p.N;
-  f32x4 part[8];
+  f32x4 part[SM];
   const int S = p.splitk;
 #pragma unroll
-  for (int s = 0; s < 8; ++s) part[s] = *reinterpret_cast<const f32x4*>(wsp + (s < S ? s : S - 1) * sstride);   // (unconditional: a slot beyond S re-reads the last one, unused)
+  for (int s = 0; s < SM; ++s) part[s] = *reinterpret_cast<const f32x4*>(wsp + (s < S ? s : S - 1) * sstride);   // (unconditional: a slot beyond S re-reads the last one, unused)
   // (null operands read a valid dummy address -- the partials -- and are masked out: no branch, hence no wait, between the loads)
   const float4 tb = *reinterpret_cast<const float4*>(p.bias ? p.bias + n : wsp);
   const float4 tt = *reinterpret_cast<const float4*>(p.temb ? p.temb + (m / ((long long)p.Hout * p.Wout)) * p.ld_temb + n : wsp);
@@ -736,25 +733,80 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const ConvParams p) 
   const f16x4 rl = *reinterpret_cast<const f16x4*>((p.res && p.res_lo) ? p.res + m * p.ld_res + p.res_lo + n : reinterpret_cast<const f16*>(wsp));
   f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int s = 0; s < 8; ++s) if (s < S) v += part[s];
-  for (int s = 8; s < S; ++s) v += *reinterpret_cast<const f32x4*>(wsp + s * sstride);   // (plans stop at 8 splits; kept for callers of the op entry)
+  for (int s = 0; s < SM; ++s) if (s < S) v += part[s];
   if (p.bias) { v[0] += tb.x; v[1] += tb.y; v[2] += tb.z; v[3] += tb.w; }
   if (p.temb) { v[0] += tt.x; v[1] += tt.y; v[2] += tt.z; v[3] += tt.w; }
   if (p.res) {
     v += up4(rh);
     if (p.res_lo) v += up4(rl);
   }
-  if (p.out_f32) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.y) + m * p.ldy + n) = v;
-  else {
-    const f16x4 o = cvt4(v);
-    *reinterpret_cast<f16x4*>(reinterpret_cast<f16*>(p.y) + m * p.ldy + n) = o;
-    if (p.y_lo) *reinterpret_cast<f16x4*>(reinterpret_cast<f16*>(p.y) + m * p.ldy + p.y_lo + n) = cvt4(v - up4(o));
+  return v;
+}
+// stores the row's four columns; returns what the consumer will read (the statistics are of THAT: hi + lo ~ v for a split tensor, else the fp16 value)
+__device__ __forceinline__ f32x4 splitk_store(const ConvParams& p, long long m, int n, const f32x4& v) {
+  if (p.out_f32) { *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.y) + m * p.ldy + n) = v; return v; }
+  const f16x4 o = cvt4(v);
+  *reinterpret_cast<f16x4*>(reinterpret_cast<f16*>(p.y) + m * p.ldy + n) = o;
+  if (p.y_lo) { *reinterpret_cast<f16x4*>(reinterpret_cast<f16*>(p.y) + m * p.ldy + p.y_lo + n) = cvt4(v - up4(o)); return v; }
+  return up4(o);
+}
+template <int SM>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const ConvParams p) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int n4 = p.N >> 2;
+  if (i >= (long long)p.M * n4) return;
+  const long long m = i / n4;
+  const int n = (int)(i - m * n4) * 4;
+  splitk_store(p, m, n, splitk_row<SM>(p, m, n));
+}
+// The same with the fused GroupNorm partial statistics of the output (common.h: stats[((b N + n) R + r) 2 + {0, 1}], r = (m % HW) / 32, R = HW / 32 --
+// the layout of the GEMM kernels' epilogues): a split-K launch's own epilogue never sees final values, so before round 6 every such tensor paid a
+// separate statistics pass (gn_stats: 27 launches per UNet pass at B = 8, 43 at B = 1 where nearly every conv is split).  grid (M / 32, ceil(N / 64)),
+// thread (row pair rr, column quad cq): rows rr and rr + 16 of the block, four columns; the 16 row-threads of a column combine through LDS in fixed order.
+template <int SM>
+__global__ __launch_bounds__(256) void splitk_reduce_stats_kernel(const ConvParams p) {
+  __shared__ float2 red[16][64];
+  const int tid = threadIdx.x, cq = tid & 15, rr = tid >> 4;
+  const int n = blockIdx.y * 64 + cq * 4;
+  const long long m0 = (long long)blockIdx.x * 32;
+  float sm[4] = {0.f, 0.f, 0.f, 0.f}, sq[4] = {0.f, 0.f, 0.f, 0.f};
+  if (n < p.N) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const long long m = m0 + rr + h * 16;
+      const f32x4 o = splitk_store(p, m, n, splitk_row<SM>(p, m, n));
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { sm[r] += o[r]; sq[r] = __builtin_fmaf(o[r], o[r], sq[r]); }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) red[rr][cq * 4 + r] = make_float2(sm[r], sq[r]);
+  __syncthreads();
+  if (tid < 64 && blockIdx.y * 64 + tid < p.N) {
+    float a = 0.f, q = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { a += red[k][tid].x; q += red[k][tid].y; }
+    const int hw = p.Hout * p.Wout;
+    const long long b = m0 / hw;
+    const int rblk = (int)(m0 - b * hw) >> 5;
+    *reinterpret_cast<float2*>(p.stats + ((b * p.N + blockIdx.y * 64 + tid) * (long long)p.stats_R + rblk) * 2) = make_float2(a, q);
   }
 }
 
 void launch_splitk_reduce_impl(const ConvParams& p, hipStream_t s) {
-  const long long n = (long long)p.M * (p.N >> 2);
-  hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p);
+  LDIFF_CHECK(p.splitk >= 2 && p.splitk <= SPLITK_MAX && p.splitk_ws && (p.N & 3) == 0, LDIFF_ERR_INVALID, "split-K reduce: %d splits (at most %d)", p.splitk, SPLITK_MAX);
+  if (p.stats) {
+    const int hw = p.Hout * p.Wout;
+    LDIFF_CHECK(!p.out_f32 && hw % 32 == 0 && p.stats_R == hw / 32 && p.M % 32 == 0, LDIFF_ERR_INVALID, "split-K reduce: fused statistics need 32 | H W and R = H W / 32 (R = %d)", p.stats_R);
+    const dim3 grid((unsigned)(p.M / 32), (unsigned)((p.N + 63) / 64));
+    if (p.splitk <= 8) hipLaunchKernelGGL(splitk_reduce_stats_kernel<8>, grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL(splitk_reduce_stats_kernel<16>, grid, dim3(256), 0, s, p);
+  } else {
+    const long long n = (long long)p.M * (p.N >> 2);
+    const dim3 grid((unsigned)((n + 255) / 256));
+    if (p.splitk <= 8) hipLaunchKernelGGL(splitk_reduce_kernel<8>, grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL(splitk_reduce_kernel<16>, grid, dim3(256), 0, s, p);
+  }
   HIP_CHECK(hipGetLastError());
 }
 
@@ -794,11 +846,7 @@ void launch_c3(const ConvParams& p, hipStream_t s) {
   q.tiles_m = tiles * npar; q.img_fast = conv3x3_img_fast(p, tiles / p.B, ntn, BN) ? 1 : 0;
   hipLaunchKernelGGL(kern, dim3(tiles * ntn * npar, S, 1), dim3(256), smem, s, q);
   HIP_CHECK(hipGetLastError());
-  if (S > 1) {
-    const long long n = (long long)p.M * (p.N >> 2);
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p);
-    HIP_CHECK(hipGetLastError());
-  }
+  if (S > 1) launch_splitk_reduce_impl(p, s);
 }
 
 template <int BN, bool GN>
@@ -826,11 +874,7 @@ void launch_c3w(const ConvParams& p, hipStream_t s) {
   q.tiles_m = tiles * npar; q.div_tm = recip(tiles * npar); q.img_fast = conv3x3_img_fast(p, tiles / p.B, ntn, BN) ? 1 : 0;
   hipLaunchKernelGGL(kern, dim3(tiles * ntn * npar, S, 1), dim3(256), smem, s, q);
   HIP_CHECK(hipGetLastError());
-  if (S > 1) {
-    const long long n = (long long)p.M * (p.N >> 2);
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p);
-    HIP_CHECK(hipGetLastError());
-  }
+  if (S > 1) launch_splitk_reduce_impl(p, s);
 }
 template <int BN>
 void launch_c3w_gn(const ConvParams& p, hipStream_t s) {
@@ -898,19 +942,29 @@ int conv3x3_splitk_plan(const ConvParams& p) {
   int S = 512 / (wgs > 0 ? wgs : 1);
   if (S > nslab / 4) S = nslab / 4;
   if (S > 8) S = 8;
+  if (S < 1) S = 1;
+  // small grids (batch 1 / 2, and the 8 x 8 level at any batch): a finer cut where the model of common.h sees it (whole slabs: a split starts at a slab)
+  static const bool fine = [] { const char* e = getenv("LDIFF_SPLITK_FINE"); return !e || atoi(e) != 0; }();
+  if (fine && wgs > 0 && wgs * S < 256) {
+    int Sm = splitk_by_model(wgs, nslab * 9, 9, (double)p.M * p.N * 4.0, S);
+    while (Sm > S && nslab / Sm < 1) --Sm;
+    S = Sm;
+  }
   return S >= 2 ? S : 1;
 }
 
 void launch_conv3x3(const ConvParams& p, hipStream_t s) {
-  LDIFF_CHECK(p.splitk <= 1 || (p.splitk_ws && !p.stats), LDIFF_ERR_INVALID, "conv3x3: split-K needs a workspace and cannot emit fused statistics");
+  LDIFF_CHECK(p.splitk <= 1 || p.splitk_ws, LDIFF_ERR_INVALID, "conv3x3: split-K needs a workspace");   // (fused statistics of a split launch: by the reduce kernel)
   LDIFF_CHECK(!p.w_par || (p.ups == 1 && p.splitk <= 1), LDIFF_ERR_INVALID, "conv3x3: parity weights need ups=1 and no split-K");
   if (p.lo8_slab0) {   // split operand with an fp8 lo half: only the 16 x 16 ping-pong kernel reads that layout
     LDIFF_CHECK(p.splitk <= 1 && conv3x3p_selected(p), LDIFF_ERR_INVALID, "conv3x3: an fp8 lo half needs the 16 x 16 ping-pong kernel (C1=%d N=%d %dx%d)", p.C1, p.N, p.Hout, p.Wout);
     launch_conv3x3p(p, s);
     return;
   }
-  if (conv3x3n_selected(p)) { launch_conv3x3n(p, s); return; }
+  if (conv3x3n_selected(p)) { LDIFF_CHECK(!p.xs, LDIFF_ERR_INVALID, "conv3x3: a folded shortcut (xs) needs the dataflow kernel"); launch_conv3x3n(p, s); return; }
   if (conv3x3d_selected(p)) { launch_conv3x3d(p, s); return; }
+  // every kernel below ignores ConvParams::xs while the caller has already summed the shortcut's bias into p.bias: refuse instead of a silently wrong sum
+  LDIFF_CHECK(!p.xs, LDIFF_ERR_INVALID, "conv3x3: a folded shortcut (xs) needs the dataflow kernel, which does not take this launch (split-K %d)", p.splitk);
   if (conv3x3p_selected(p)) { launch_conv3x3p(p, s); return; }
   const bool wide = c3_tile_w(p) == 16;
   const int bn = (p.N % 128 != 0 && p.N % 160 == 0) ? 160 : (p.N <= 32 ? 32 : (p.N <= 64 ? 64 : 128));

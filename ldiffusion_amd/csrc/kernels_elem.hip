@@ -323,6 +323,32 @@ void launch_zero_bytes(void* p, size_t bytes, hipStream_t s) {
   HIP_CHECK(hipGetLastError());
 }
 
+// ---- diagnostic: max |value| of an activation (Exec::trace, LDIFF_TRACE_ABSMAX=1); split tensors as hi + lo ----
+__global__ __launch_bounds__(256) void absmax_kernel(const f16* __restrict__ x, long long rows, int C, int ld, int lo, float* __restrict__ out) {
+  const long long n = rows * C;
+  float m = 0.f;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const long long r = i / C;
+    const int c = (int)(i - r * C);
+    float v = (float)x[r * ld + c];
+    if (lo) v += (float)x[r * ld + lo + c];
+    v = __builtin_fabsf(v);
+    m = (v > m || v != v) ? v : m;   // NaN sticks
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { const float t = __shfl_xor(m, o); m = (t > m || t != t) ? t : m; }
+  if ((threadIdx.x & 63) == 0) {
+    if (m != m) atomicExch(reinterpret_cast<unsigned*>(out), 0x7fc00000u);
+    else atomicMax(reinterpret_cast<unsigned*>(out), __builtin_bit_cast(unsigned, m));   // non-negative floats order like their bit patterns
+  }
+}
+void launch_absmax(const f16* x, long long rows, int C, int ld, int lo, float* out, hipStream_t s) {
+  launch_zero_bytes(out, 4, s);
+  if (rows * C == 0) return;
+  hipLaunchKernelGGL(absmax_kernel, dim3(1024), dim3(256), 0, s, x, rows, C, ld ? ld : C, lo, out);
+  HIP_CHECK(hipGetLastError());
+}
+
 // ---- mask tail: argmax over classes (segmentor.py:536; softmax is monotone) ----------------------
 __global__ void argmax_u8_kernel(const float* __restrict__ logits, int B, int C, int HW, uint8_t* __restrict__ mask) {
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;

@@ -322,7 +322,7 @@ void launch_g(const ConvParams& p, hipStream_t s) {
   const double bytes = (double)p.M * p.K * 2.0 + (double)p.N * p.K * 2.0 + (double)p.M * p.N * (p.out_f32 || p.y_lo ? 4.0 : 2.0) + (p.res ? (double)p.M * p.N * (p.res_lo ? 4.0 : 2.0) : 0.0);
   ProfScope prof(pname.c_str(), 2.0 * p.M * (double)p.N * p.K, bytes, s);
   const int S = p.splitk > 1 ? p.splitk : 1;
-  LDIFF_CHECK(S == 1 || (p.splitk_ws && !p.stats && !p.geglu && !p.out_f32 && p.w_bstride == 0), LDIFF_ERR_INVALID, "gemm: split-K needs a workspace and a plain fp16 epilogue");
+  LDIFF_CHECK(S == 1 || (p.splitk_ws && !p.geglu && !p.out_f32 && p.w_bstride == 0), LDIFF_ERR_INVALID, "gemm: split-K needs a workspace and a plain fp16 epilogue");   // (fused statistics of a split launch: by the reduce kernel)
   ConvParams q = p;
   q.tiles_m = ntm; q.img_fast = gemm_m_fast(p, ntm, ntn) ? 1 : 0;
   hipLaunchKernelGGL(kern, dim3(ntm * ntn, S), dim3(256), smem, s, q);
@@ -344,7 +344,8 @@ bool gemm_dma_eligible(const ConvParams& p) {
 // Split-K for the LDS-DMA GEMM, same rule as igemm_splitk_plan: only where the tiles leave most workgroup slots empty and K is long
 // (1x1 shortcut convs over the concat input at the 8x8 level: M = 512, K = 2560 or 5120 on split operands)
 int gemm_dma_splitk_plan(const ConvParams& p) {
-  if (p.out_f32 || p.stats || p.geglu || p.w_bstride != 0 || p.M <= 0 || !gemm_dma_eligible(p)) return 1;
+  if (p.out_f32 || p.geglu || p.w_bstride != 0 || p.M <= 0 || !gemm_dma_eligible(p)) return 1;
+  if (p.stats && (p.Hout * p.Wout) % 32 != 0) return 1;   // the reduce kernel emits them in 32-row blocks
   auto tiles = [&](int bm, int bn) { return (long long)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn); };
   if (tiles(128, 64) >= 384) return 1;
   const int nk = p.K / 64;
@@ -356,7 +357,11 @@ int gemm_dma_splitk_plan(const ConvParams& p) {
   if (S256 >= 2 && tiles(128, 128) * S256 >= 384) return S256;
   const int S128 = splits(tiles(128, 64));
   if (S128 >= 2 && tiles(128, 64) * S128 >= 384) return S128;
-  const int S64 = splits(tiles(64, 64));
+  int S64 = splits(tiles(64, 64));
+  if (S64 < 1) S64 = 1;
+  // small grids (batch 1 / 2; the 8 x 8 level): a finer cut where the model of common.h sees it
+  static const bool fine = [] { const char* e = getenv("LDIFF_SPLITK_FINE"); return !e || atoi(e) != 0; }();
+  if (fine && tiles(64, 64) * S64 < 256) S64 = splitk_by_model(tiles(64, 64), nk, 4, (double)p.M * p.N * 4.0, S64);
   return S64 >= 2 ? S64 : 1;
 }
 

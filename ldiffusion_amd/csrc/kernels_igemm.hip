@@ -279,7 +279,7 @@ static void launch_cfg(const ConvParams& p, hipStream_t s) {
   const double bytes = in_bytes + (double)p.N * p.K * esz + (double)p.M * p.N * (p.out_f32 || p.y_lo ? 4.0 : esz) + (p.res ? (double)p.M * p.N * (p.res_lo ? 4.0 : esz) : 0.0);
   ProfScope prof(pname.c_str(), 2.0 * p.M * (double)p.N * p.K, bytes, s);
   const int S = p.splitk > 1 ? p.splitk : 1;
-  LDIFF_CHECK(S == 1 || (p.splitk_ws && !p.stats && !p.geglu), LDIFF_ERR_INVALID, "igemm: split-K needs a workspace and cannot emit fused statistics");
+  LDIFF_CHECK(S == 1 || (p.splitk_ws && !p.geglu), LDIFF_ERR_INVALID, "igemm: split-K needs a workspace");   // (fused statistics of a split launch: by the reduce kernel)
   hipLaunchKernelGGL(kern, dim3(ntm * ntn, S), dim3(256), smem, s, p);
   HIP_CHECK(hipGetLastError());
   if (S > 1) launch_splitk_reduce(p, s);
@@ -296,15 +296,17 @@ int conv3x3_stats_blocks(const ConvParams& p);
 
 int conv_stats_blocks_per_image(const ConvParams& p) {
   if (p.out_f32) return 0;
-  if (conv3x3_eligible(p)) return conv3x3_stats_blocks(p);
   const int hw = p.Hout * p.Wout;
+  if (p.splitk > 1) return hw % 32 == 0 ? hw / 32 : 0;   // a split launch: the reduce kernel's 32-row blocks, whichever kernel wrote the partials
+  if (conv3x3_eligible(p)) return conv3x3_stats_blocks(p);
   return hw % 32 == 0 ? hw / 32 : 0;
 }
 
 // Split-K for the register-staged kernel: only where its launcher picks 64x64 tiles, the tiles leave most workgroup slots empty and the
 // K loop is long (stride-2 3x3 convs of the UNet's 16x16 -> 8x8 level: 160 tiles x 180-360 K-steps)
 int igemm_splitk_plan(const ConvParams& p) {
-  if (p.out_f32 || p.stats || p.geglu || p.M <= 0) return 1;
+  if (p.out_f32 || p.geglu || p.M <= 0) return 1;
+  if (p.stats && (p.Hout * p.Wout) % 32 != 0) return 1;   // the reduce kernel emits them in 32-row blocks
   if (conv3x3_eligible(p) || gemm_dma_eligible(p)) return 1;
   auto tiles = [&](int bm, int bn) { return (long long)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn); };
   if (tiles(128, 64) >= 384) return 1;

@@ -12,6 +12,13 @@
 
 #define GN_PIX_PER_CHUNK_MIN 32
 
+// Non-finite detector (include/ldiff.h "Non-finite detection"): every activation of a graph passes through GroupNorm statistics sooner or later (an fp16
+// inf written by a conv / GEMM epilogue, or the NaN it turns into downstream, makes the sums below non-finite), and the workgroup that finalizes a
+// group sees its totals in fp64 anyway: one predicated store into the handle's sticky flag, no extra read, no extra launch.
+__device__ __forceinline__ void flag_nonfinite(int* flag, double a, double q) {
+  if (flag && !(a > -1e300 && a < 1e300 && q < 1e300)) *flag = 1;   // (written negated: NaN fails every comparison)
+}
+
 static int gn_chunks(int HW) {
   // ~1024 blocks at (B=8, HW=4096); cap the chunk count so the partial buffer stays small at 512x512.
   int pix = GN_PIX_PER_CHUNK_MIN;
@@ -90,7 +97,7 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(SrcView s1, SrcView s2,
 // grid (groups, B); block 64: one wave per (b, group).
 __global__ __launch_bounds__(64) void gn_finalize_kernel(const float* __restrict__ partial, int nchunk, int C, int groups, int HW, float eps,
                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                         float* __restrict__ scale, float* __restrict__ shift) {
+                                                         float* __restrict__ scale, float* __restrict__ shift, int* __restrict__ nonfinite) {
   const int grp = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
   const int Cg = C / groups, c0 = grp * Cg;
   double a = 0.0, q = 0.0;
@@ -102,6 +109,7 @@ __global__ __launch_bounds__(64) void gn_finalize_kernel(const float* __restrict
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o); q += __shfl_xor(q, o); }
+  if (lane == 0) flag_nonfinite(nonfinite, a, q);
   const double n = (double)HW * Cg;
   const double mean = a / n;
   double var = q / n - mean * mean;
@@ -119,7 +127,8 @@ __global__ __launch_bounds__(64) void gn_finalize_kernel(const float* __restrict
 // partial sums are contiguous, so a (image, group) block streams Cg contiguous runs.
 __global__ __launch_bounds__(256) void gn_finalize2_kernel(const float* __restrict__ p1, int R1, int C1, const float* __restrict__ p2, int R2, int C2,
                                                            int groups, int HW, float eps, const float* __restrict__ gamma,
-                                                           const float* __restrict__ beta, float* __restrict__ scale, float* __restrict__ shift) {
+                                                           const float* __restrict__ beta, float* __restrict__ scale, float* __restrict__ shift,
+                                                           int* __restrict__ nonfinite) {
   const int grp = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
   const int C = C1 + C2, Cg = C / groups, c0 = grp * Cg, c1 = c0 + Cg;
   // the partials of the group's channels are (up to) two contiguous runs of float2: channels [c0, min(c1, C1)) of part 1 and
@@ -146,6 +155,7 @@ __global__ __launch_bounds__(256) void gn_finalize2_kernel(const float* __restri
   __syncthreads();
   a = red[0][0] + red[0][1] + red[0][2] + red[0][3];
   q = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+  if (tid == 0) flag_nonfinite(nonfinite, a, q);
   const double n = (double)HW * Cg;
   const double mean = a / n;
   double var = q / n - mean * mean;
@@ -159,10 +169,10 @@ __global__ __launch_bounds__(256) void gn_finalize2_kernel(const float* __restri
 }
 
 void launch_gn_finalize(const float* part1, int R1, int C1, const float* part2, int R2, int C2, int B, int HW, int groups, float eps,
-                        const float* gamma, const float* beta, float* scale, float* shift, hipStream_t s) {
+                        const float* gamma, const float* beta, float* scale, float* shift, hipStream_t s, int* nonfinite) {
   LDIFF_CHECK((C1 + C2) % groups == 0 && part1 && R1 > 0 && (C2 == 0 || (part2 && R2 > 0)), LDIFF_ERR_INVALID, "gn_finalize: bad arguments");
   ProfScope prof("gn_finalize", 0.0, 8.0 * B * ((double)R1 * C1 + (double)R2 * C2), s);
-  hipLaunchKernelGGL(gn_finalize2_kernel, dim3(groups, B), dim3(256), 0, s, part1, R1, C1, part2, R2, C2, groups, HW, eps, gamma, beta, scale, shift);
+  hipLaunchKernelGGL(gn_finalize2_kernel, dim3(groups, B), dim3(256), 0, s, part1, R1, C1, part2, R2, C2, groups, HW, eps, gamma, beta, scale, shift, nonfinite);
   HIP_CHECK(hipGetLastError());
 }
 
@@ -173,7 +183,8 @@ static inline SrcView norm_view(SrcView v) { if (v.p && v.ld == 0) v.ld = v.C; r
 // never straddles the two sources because C1 % 8 == 0), fp32 per thread, fp64 across threads.  The two-launch form (partial + finalize)
 // costs 18-30 us on these tensors of 1-10 MB: both launches are latency-, not bandwidth-bound.
 __global__ __launch_bounds__(256) void gn_small_kernel(SrcView s1, SrcView s2, int HW, int groups, float eps, const float* __restrict__ gamma,
-                                                       const float* __restrict__ beta, float* __restrict__ scale, float* __restrict__ shift) {
+                                                       const float* __restrict__ beta, float* __restrict__ scale, float* __restrict__ shift,
+                                                       int* __restrict__ nonfinite) {
   const int grp = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
   const int C1 = s1.C, C = C1 + (s2.p ? s2.C : 0), Cg = C / groups, c0 = grp * Cg, c1 = c0 + Cg;
   const int k0 = c0 >> 3, nk = ((c1 + 7) >> 3) - k0;   // chunks [k0, k0 + nk) overlap the group
@@ -198,6 +209,7 @@ __global__ __launch_bounds__(256) void gn_small_kernel(SrcView s1, SrcView s2, i
   __syncthreads();
   da = red[0][0] + red[0][1] + red[0][2] + red[0][3];
   dq = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+  if (tid == 0) flag_nonfinite(nonfinite, da, dq);
   const double n = (double)HW * Cg;
   const double mean = da / n;
   double var = dq / n - mean * mean;
@@ -211,7 +223,7 @@ __global__ __launch_bounds__(256) void gn_small_kernel(SrcView s1, SrcView s2, i
 }
 
 void launch_gn_stats(SrcView x1, SrcView x2, int B, int HW, int groups, float eps, const float* gamma,
-                     const float* beta, float* partial, size_t partial_bytes, float* scale, float* shift, hipStream_t s) {
+                     const float* beta, float* partial, size_t partial_bytes, float* scale, float* shift, hipStream_t s, int* nonfinite) {
   x1 = norm_view(x1); x2 = norm_view(x2);
   if (!x2.p) x2.C = 0;
   const int C1 = x1.C, C2 = x2.C, C = C1 + C2;
@@ -225,7 +237,7 @@ void launch_gn_stats(SrcView x1, SrcView x2, int B, int HW, int groups, float ep
   static const bool small_batch = [] { const char* e = getenv("LDIFF_GN_SMALL_BATCH"); return !e || atoi(e) != 0; }();
   if ((HW <= 1024 && B * groups >= 64) || (small_batch && B * groups < 256 && HW <= 4096)) {
     ProfScope prof("gn_stats", 3.0 * B * HW * (double)C, 2.0 * B * HW * ((double)C1 * (x1.lo ? 2 : 1) + (double)C2 * (x2.lo ? 2 : 1)), s);
-    hipLaunchKernelGGL(gn_small_kernel, dim3(groups, B), dim3(256), 0, s, x1, x2, HW, groups, eps, gamma, beta, scale, shift);
+    hipLaunchKernelGGL(gn_small_kernel, dim3(groups, B), dim3(256), 0, s, x1, x2, HW, groups, eps, gamma, beta, scale, shift, nonfinite);
     HIP_CHECK(hipGetLastError());
     return;
   }
@@ -235,7 +247,7 @@ void launch_gn_stats(SrcView x1, SrcView x2, int B, int HW, int groups, float ep
   ProfScope prof("gn_stats", 3.0 * B * HW * (double)C, 2.0 * B * HW * ((double)C1 * (x1.lo ? 2 : 1) + (double)C2 * (x2.lo ? 2 : 1)), s);
   hipLaunchKernelGGL(gn_partial_kernel, dim3(nchunk, B, C2 ? 2 : 1), dim3(256), smem, s, x1, x2, HW, pix, nchunk, partial);
   HIP_CHECK(hipGetLastError());
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3(groups, B), dim3(64), 0, s, partial, nchunk, C, groups, HW, eps, gamma, beta, scale, shift);
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(groups, B), dim3(64), 0, s, partial, nchunk, C, groups, HW, eps, gamma, beta, scale, shift, nonfinite);
   HIP_CHECK(hipGetLastError());
 }
 

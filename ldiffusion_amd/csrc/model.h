@@ -90,6 +90,15 @@ class WeightStore {
   mutable std::vector<std::string> missing_cache_;
 };
 
+// Sticky non-finite detector of a handle (include/ldiff.h "Non-finite detection").  One int per graph in host-mapped pinned memory: the device sets it
+// (a plain store of 1 from a GroupNorm finalize workgroup whose totals are not finite), the host reads it without a device round trip.
+struct NonFiniteFlag {
+  int* words = nullptr;   // [4], host pointer == device pointer (hipHostMallocMapped under unified addressing)
+  void create();
+  void destroy();
+  bool test_and_clear();  // true if any word was set (only meaningful for work that has completed)
+};
+
 struct ConvOpts {
   int stride = 1, pad_t = -1 /* -1 => (ks-1)/2 */, pad_l = -1, ups = 0;
   int Hout = -1, Wout = -1;     // override output size (asymmetric-pad downsample)
@@ -120,6 +129,9 @@ class Exec {
   std::vector<void*> owned;   // lazily built derived weights (parity weights of the upsampler convs)
   const int* weights_gen = nullptr;   // -> WeightStore::generation of the owning model
   bool short_runs = false;            // this graph runs beside another stream's (ConvParams::short_runs)
+  int* nonfinite = nullptr;           // -> the owning handle's sticky non-finite flag (host-mapped; set by the GroupNorm finalize kernels, NonFiniteFlag below)
+  const char* trace_tag = nullptr;    // LDIFF_TRACE_ABSMAX=1: name of the graph whose stages trace() reports (diagnostic, synchronises)
+  void trace(const char* stage, const Act& a);   // max |value| of a stage's output to stderr when LDIFF_TRACE_ABSMAX is set; otherwise nothing
   ~Exec();
   void ensure_gn_partial(size_t bytes);
   Act new_act(int B, int H, int W, int C, bool split = false, bool lo8 = false);
@@ -178,6 +190,7 @@ struct ldiff_unet {
   ResnetW mid_res[2];
   TransformerW mid_attn;
   std::vector<TransformerW*> all_tf;
+  NonFiniteFlag nf;
   int ctx_B = 0, ctx_L = 0, ctx_gen = 0;
   f16* ctx_buf = nullptr; size_t ctx_cap = 0;     // all kv_ctx live in one allocation
   void build();
@@ -219,6 +232,8 @@ struct ldiff_vae {
   // Two workspaces: the decoder's and the encoder's.  A pipelined sampler decodes batch k on the side stream while the encoder
   // of batch k+1 already runs on the caller's stream; ex() is the one the running graph builder uses.
   Exec ex_dec, ex_enc;
+  NonFiniteFlag nf;   // word 0: encoder graph, word 1: decoder graph
+  ~ldiff_vae() { nf.destroy(); }
   Exec* cur = &ex_dec;
   Exec& ex() { return *cur; }
   // side stream for decodes that only feed the feature tensor (ldiff_sample); ev_side = "everything queued on it so far is done"

@@ -214,7 +214,42 @@ const char* WeightStore::missing_name(int i) const {
   return missing_cache_[i].c_str();
 }
 
+// ---- non-finite flag ------------------------------------------------------------------------------
+void NonFiniteFlag::create() {
+  if (words) return;
+  HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&words), 4 * sizeof(int), hipHostMallocMapped));
+  for (int i = 0; i < 4; ++i) words[i] = 0;
+}
+void NonFiniteFlag::destroy() {
+  if (words) (void)hipHostFree(words);
+  words = nullptr;
+}
+bool NonFiniteFlag::test_and_clear() {
+  if (!words) return false;
+  bool any = false;
+  for (int i = 0; i < 4; ++i) {
+    volatile int* w = words + i;
+    if (*w) { any = true; *w = 0; }
+  }
+  return any;
+}
+
 // ---- Exec: op helpers --------------------------------------------------------------------------
+void launch_absmax(const f16* x, long long rows, int C, int ld, int lo, float* out, hipStream_t s);   // kernels_elem.hip
+void Exec::trace(const char* stage, const Act& a) {
+  static const bool on = [] { const char* e = getenv("LDIFF_TRACE_ABSMAX"); return e && atoi(e) != 0; }();
+  if (!on || !a.p || a.lo8) return;
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (s) (void)hipStreamIsCapturing(s, &cs);
+  if (cs != hipStreamCaptureStatusNone) return;
+  float* d = tmp<float>(1);
+  launch_absmax(a.p, a.rows(), a.C, a.ld(), a.lo(), d, s);
+  float h = 0.f;
+  HIP_CHECK(hipMemcpyAsync(&h, d, sizeof(float), hipMemcpyDeviceToHost, s));
+  HIP_CHECK(hipStreamSynchronize(s));
+  arena.free(d);
+  fprintf(stderr, "[absmax] %-8s %-28s [%d,%d,%d,%d]%s max|x| = %.6g (fp16 limit 65504)\n", trace_tag ? trace_tag : "", stage, a.B, a.H, a.W, a.C, a.split ? " split" : "", (double)h);
+}
 Exec::~Exec() {
   if (gn_partial) (void)hipFree(gn_partial);
   for (void* q : owned) (void)hipFree(q);
@@ -245,12 +280,12 @@ GNss Exec::gn(const Act& x, const Act* x2, const NormW& w, int groups, float eps
   g.shift = tmp<float>((size_t)x.B * C);
   if (x.st && (!x2 || x2->st)) {   // statistics were accumulated by the producing kernels: finalize only, no extra read
     launch_gn_finalize(x.st, x.st_R, x.C, x2 ? x2->st : nullptr, x2 ? x2->st_R : 0, x2 ? x2->C : 0, x.B, x.H * x.W, groups, eps, w.g, w.b,
-                       g.scale, g.shift, s);
+                       g.scale, g.shift, s, nonfinite);
     return g;
   }
   LDIFF_CHECK(gn_partial_bytes(x.B, x.H * x.W, C) <= gn_partial_cap, LDIFF_ERR_RUNTIME, "group norm workspace too small");
   launch_gn_stats(x.view(), x2 ? x2->view() : SrcView{nullptr, 0, 0, 0}, x.B, x.H * x.W, groups, eps, w.g, w.b, gn_partial, gn_partial_cap, g.scale,
-                  g.shift, s);
+                  g.shift, s, nonfinite);
   return g;
 }
 void Exec::release(GNss& g) {
@@ -350,7 +385,11 @@ const f16* Exec::derived_frag_sc(const MatW& w, const MatW& sc, const ConvParams
     owned.push_back(q);
     w.bias_sc = (float*)q;
   }
+  // key: the shortcut matrix this copy was packed with and its width (a conv2 reused with another shortcut would otherwise read stale / too few weights)
+  const int key = (int)((reinterpret_cast<uintptr_t>(sc.w) >> 4) & 0x3fffffff) ^ (p.Cs << 20);
+  LDIFF_CHECK(w.frag_sc.gen < 0 || w.frag_sc.key == key, LDIFF_ERR_RUNTIME, "conv: the folded-shortcut weights of this layer were packed for another shortcut matrix");
   if (w.frag_sc.gen != gen) {   // first use, or the checkpoint was reloaded since
+    w.frag_sc.key = key;
     launch_pack_frag_weights(w.w, w.frag_sc.p, p.N, p.C1, s);
     launch_pack_frag_weights_sc(sc.w, w.frag_sc.p, p.N, p.C1, p.Cs, sc.K, s);
     launch_add_vectors(w.b, sc.b, w.bias_sc, w.Nrows, s);
@@ -483,9 +522,9 @@ Act Exec::conv(const MatW& w, const Act& x, const Act* x2, const ConvOpts& o) {
     p.y = y.p; p.ldy = y.ld(); p.y_lo = y.lo();
     if (o.ups && conv3x3_eligible(p))   // nearest-2x upsample folded algebraically (4 parity convs with pre-summed taps)
       p.w_par = derived_par(w, wsrc, Cin_eff, o.split_in ? w.dup_par : w.par);
-    // split-K launches write raw partials: the GroupNorm statistics of such a tensor come from the separate pass (Exec::gn)
+    // split-K launches write raw partials: their reduce kernel applies the epilogue and (round 6) emits the GroupNorm statistics too, in 32-row blocks
     p.splitk = conv3x3_eligible(p) ? conv3x3_splitk_plan(p) : gemm_dma_eligible(p) ? gemm_dma_splitk_plan(p) : igemm_splitk_plan(p);
-    if (o.want_stats && C == p.N && p.N == w.N && p.splitk <= 1) {
+    if (o.want_stats && C == p.N && p.N == w.N) {
       const int R = conv_stats_blocks_per_image(p);
       if (R > 0) {
         y.st = tmp<float>((size_t)x.B * R * p.N * 2);
@@ -503,7 +542,7 @@ Act Exec::conv(const MatW& w, const Act& x, const Act* x2, const ConvOpts& o) {
     static const bool fold = [] { const char* e = getenv("LDIFF_C3D_FOLD_SC"); return !e || atoi(e) != 0; }();
     ConvParams q = p;
     q.xs = o.sc_x->p; q.Cs = o.sc_x->C; q.lds = o.sc_x->ld();
-    if (fold && o.sc_w->K == q.Cs && conv3x3_eligible(q) && conv3x3d_selected(q)) {
+    if (fold && o.sc_w->K == q.Cs && conv3x3_eligible(q) && conv3x3d_selected(q)) {   // (selected() is false under a split-K plan: q.splitk was decided above)
       p = q;
       p.w_frag = derived_frag_sc(w, *o.sc_w, p, &p.bias);
       *o.sc_done = true;
@@ -586,6 +625,7 @@ Act Exec::resnet(const ResnetW& r, const Act& x, const Act* skip, const float* t
     h = conv(r.c1, x, skip, o1);
   }
   release(g1);
+  trace("  resnet.conv1", h);
   GNss g2 = gn(h, nullptr, r.n2, groups, eps);
   Act sc;
   const Act* resp = &x;
@@ -674,6 +714,9 @@ static TransformerW make_transformer(WeightStore& ws, const std::string& p, int 
 
 void ldiff_unet::build() {
   ex.weights_gen = &ws.generation;
+  nf.create();
+  ex.nonfinite = nf.words;
+  ex.trace_tag = "unet";
   const int nb = cfg.n_blocks;
   const int* boc = cfg.block_out_channels;
   const int temb_dim = boc[0] * 4, ctx = cfg.cross_attention_dim, lpb = cfg.layers_per_block;
@@ -866,6 +909,7 @@ void ldiff_unet::GraphCache::drop() {
   exec = nullptr; graph = nullptr; uses = 0;
 }
 ldiff_unet::~ldiff_unet() {
+  nf.destroy();
   gc.drop();
   if (gc.in) (void)hipFree(gc.in);
   if (gc.out) (void)hipFree(gc.out);
@@ -973,10 +1017,14 @@ void ldiff_unet::forward_impl(const float* x, int B, int h, int w, float tval, c
 
   std::vector<Act> skips{cur};
   bool cur_is_skip = true;
+  int stage_no = 0;
   auto advance = [&](Act nxt) {
     if (!cur_is_skip) ex.release(cur);
     cur = nxt;
     cur_is_skip = false;
+    char nm[32];
+    snprintf(nm, sizeof(nm), "stage %d", stage_no++);
+    ex.trace(nm, cur);
   };
   for (int i = 0; i < nb; ++i) {
     for (size_t j = 0; j < down_res[i].size(); ++j) {
@@ -1078,6 +1126,9 @@ void ldiff_vae::wait_side(hipStream_t s) {
 void ldiff_vae::build() {
   ex_dec.weights_gen = &ws.generation;
   ex_enc.weights_gen = &ws.generation;
+  nf.create();
+  ex_enc.nonfinite = nf.words; ex_dec.nonfinite = nf.words + 1;
+  ex_enc.trace_tag = "vae.enc"; ex_dec.trace_tag = "vae.dec";
   const int nb = cfg.n_blocks, lpb = cfg.layers_per_block, lat = cfg.latent_channels;
   const int* boc = cfg.block_out_channels;
   LDIFF_CHECK(nb >= 1 && nb <= LDIFF_MAX_BLOCKS, LDIFF_ERR_INVALID, "vae: n_blocks=%d out of range", nb);
@@ -1180,18 +1231,22 @@ void ldiff_vae::encode(const float* x, int B, int H, int W, float* moments, hipS
   oci.want_stats = true; oci.split_in = split_first; oci.split_out = st;
   Act cur = ex().conv(e_conv_in, x16, nullptr, oci);
   ex().release(x16);
-  auto advance = [&](Act nxt) { ex().release(cur); cur = nxt; };
+  ex().trace("conv_in", cur);
+  auto advance = [&](Act nxt, const char* stage) { ex().release(cur); cur = nxt; ex().trace(stage, cur); };
   for (int i = 0; i < nb; ++i) {
-    for (auto& r : e_res[i]) advance(rb(r, cur));
+    char nm[64];
+    int j = 0;
+    for (auto& r : e_res[i]) { snprintf(nm, sizeof(nm), "down_blocks.%d.resnets.%d", i, j++); advance(rb(r, cur), nm); }
     if (i != nb - 1) {
       ConvOpts o;  // Downsample2D(padding=0): F.pad(x,(0,1,0,1)) then stride-2 conv without padding
       o.stride = 2; o.pad_t = 0; o.pad_l = 0; o.Hout = cur.H / 2; o.Wout = cur.W / 2; o.want_stats = true; o.split_in = st; o.split_out = st;
-      advance(ex().conv(e_down[i], cur, nullptr, o));
+      snprintf(nm, sizeof(nm), "down_blocks.%d.downsamplers.0", i);
+      advance(ex().conv(e_down[i], cur, nullptr, o), nm);
     }
   }
-  advance(rb(e_mid[0], cur));
-  advance(mid_attention(e_attn, cur));
-  advance(rb(e_mid[1], cur));
+  advance(rb(e_mid[0], cur), "mid.resnets.0");
+  advance(mid_attention(e_attn, cur), "mid.attentions.0");
+  advance(rb(e_mid[1], cur), "mid.resnets.1");
   GNss g = ex().gn(cur, nullptr, e_norm_out, cfg.norm_num_groups, 1e-6f);
   Act m;   // [B,h,w,8] (2*latent channels)
   if (full) {
@@ -1258,16 +1313,20 @@ void ldiff_vae::decode(const float* z, int B, int h, int w, float z_scale, float
   odi.want_stats = true; odi.split_in = split_first; odi.split_out = st;
   Act cur = ex().conv(d_conv_in, pq, nullptr, odi);
   ex().release(pq);
-  auto advance = [&](Act nxt) { ex().release(cur); cur = nxt; };
-  advance(rb(d_mid[0], cur));
-  advance(mid_attention(d_attn, cur));
-  advance(rb(d_mid[1], cur));
+  ex().trace("conv_in", cur);
+  auto advance = [&](Act nxt, const char* stage) { ex().release(cur); cur = nxt; ex().trace(stage, cur); };
+  advance(rb(d_mid[0], cur), "mid.resnets.0");
+  advance(mid_attention(d_attn, cur), "mid.attentions.0");
+  advance(rb(d_mid[1], cur), "mid.resnets.1");
   for (int i = 0; i < nb; ++i) {
-    for (auto& r : d_res[i]) advance(rb(r, cur));
+    char nm[64];
+    int j = 0;
+    for (auto& r : d_res[i]) { snprintf(nm, sizeof(nm), "up_blocks.%d.resnets.%d", i, j++); advance(rb(r, cur), nm); }
     if (i != nb - 1) {
       ConvOpts o;
       o.ups = 1; o.want_stats = true; o.split_in = st; o.split_out = st;
-      advance(ex().conv(d_up[i], cur, nullptr, o));
+      snprintf(nm, sizeof(nm), "up_blocks.%d.upsamplers.0", i);
+      advance(ex().conv(d_up[i], cur, nullptr, o), nm);
     }
   }
   GNss g = ex().gn(cur, nullptr, d_norm_out, cfg.norm_num_groups, 1e-6f);

@@ -88,6 +88,12 @@ class UNet2DConditionModel:
         _lib.check(self._lib.ldiff_unet_set_graph(self._h, int(bool(on))))
         return self
 
+    def check_finite(self):
+        """Synchronises the current stream and raises NonFiniteError if a forward enqueued so far produced a non-finite activation
+        (fp16 overflow; include/ldiff.h "Non-finite detection")."""
+        _lib.check(self._lib.ldiff_unet_check_finite(self._h, _lib.stream_ptr()))
+        return self
+
     @property
     def graph_replays(self) -> int:
         return int(self._lib.ldiff_unet_graph_replays(self._h))
@@ -249,6 +255,12 @@ class AutoencoderKL:
         `precision` so that a caller that changes it for one call can put back what was there."""
         _lib.check(self._lib.ldiff_vae_set_precision(self._h, int(encoder), int(decoder)))
         self.precision = (int(encoder), int(decoder))
+        return self
+
+    def check_finite(self):
+        """Synchronises the current stream (and the decode side stream) and raises NonFiniteError if an encode / decode enqueued so far produced
+        a non-finite activation (fp16 overflow -- e.g. a decoder fed z / 0.18215 of un-scaled latents; include/ldiff.h "Non-finite detection")."""
+        _lib.check(self._lib.ldiff_vae_check_finite(self._h, _lib.stream_ptr()))
         return self
 
     def eval(self):

@@ -56,7 +56,9 @@ class StableDiffusionImg2ImgPipeline:
     def decode_latents(self, latents):
         """(1/scaling_factor * z) -> vae.decode -> (x/2+0.5).clamp(0,1) -> NHWC float32 numpy on the host."""
         _, image, _ = self.vae._decode(latents, 1.0 / self.vae.config.scaling_factor, want_image=True)
-        return image.cpu().numpy()
+        host = image.cpu().numpy()
+        self.vae.check_finite()   # the copy above has synchronised already: an fp16 overflow in the decoder raises here instead of returning a garbage image
+        return host
 
     @staticmethod
     def numpy_to_pil(images):
@@ -89,6 +91,13 @@ class LaplaceSampler:
     def join(self):
         """Make the current stream wait for the decodes of this sampler's last sample() call (mode 2)."""
         _lib.check(self._lib.ldiff_pipeline_join(self._h, _lib.stream_ptr()))
+        self._pending = None
+
+    def check_finite(self):
+        """Joins a deferred decode, synchronises the current stream and raises NonFiniteError if the UNet or the VAE produced a non-finite
+        activation in any sample() so far (include/ldiff.h "Non-finite detection").  Call it where the results leave the device; sample() itself
+        never synchronises (a flagged call is otherwise reported by the next call on the handles)."""
+        _lib.check(self._lib.ldiff_pipeline_check_finite(self._h, _lib.stream_ptr()))
         self._pending = None
 
     def timesteps(self, num_inference_steps: int):

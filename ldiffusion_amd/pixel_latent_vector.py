@@ -88,6 +88,7 @@ def pixel_latent_vector(pipeline, vae=None, unet=None, num_inference_steps=5, tr
         x = torch.cat(images, 0).to(dev, dtype=torch.float32)
         out = s.sample(x, text_embeddings.to(dev), num_inference_steps, want_features=True, want_rgb=False)
         s.join()   # a caller's sampler in overlap mode 2 defers the side-stream join: the decodes must have written every plane before the copy
+        s.check_finite()   # the features are about to leave the device: an fp16 overflow in either graph raises instead of exporting garbage
         feats = out["features"].cpu()
         for b in range(x.shape[0]):
             lab = labels[b]

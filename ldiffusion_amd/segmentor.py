@@ -192,6 +192,7 @@ class Segmentor:
             text_embeddings = self._get_text_embeddings(PROMPT, 1, pipeline, unet)
         out = self._one_pass(x, text_embeddings, pipeline, unet)
         decoded = Image.fromarray(out["rgb"][0].cpu().numpy())
+        self._sampler.check_finite()   # fp16 overflow in either graph raises here instead of yielding a plausible-looking mask
         model_input = (out["rgb"].permute(0, 3, 1, 2).float() / 255.0 - mean) / std
         logits = head(model_input)
         mask = argmax_mask(logits)[0].cpu().numpy()
@@ -244,6 +245,7 @@ class Segmentor:
                 text_embeddings = self._get_text_embeddings(PROMPT, 1, pipeline, unet)
             rgb = self._one_pass((x - mean) / std, text_embeddings, pipeline, unet)["rgb"]   # [1,1024,1024,3] u8, on the device
             decoded = Image.fromarray(rgb[0].cpu().numpy())
+            self._sampler.check_finite()   # fp16 overflow in either graph raises here instead of yielding a plausible-looking mask
         else:                                                                                 # non-square: no diffusion (segmentor.py:449-450)
             rgb = torch.from_numpy(np.array(image, np.uint8))[None].to(self.device)
             decoded = image

@@ -50,5 +50,8 @@ def copy_or_convert_image(img, src_path, dst_path, pipeline=None, unet=None, use
     elif emb.shape[-1] != base.config.cross_attention_dim:
         raise ValueError(f"copy_or_convert_image: text embeddings of width {emb.shape[-1]} for a UNet with cross_attention_dim "
                          f"{base.config.cross_attention_dim} (the reference passes the text-alignment wrapper here)")
-    out = _sampler(pipeline, base).sample((x - mean) / std, emb.to(device=device, dtype=torch.float32)[:1], 1, want_features=False, want_rgb=True)
-    Image.fromarray(out["rgb"][0].cpu().numpy()).save(dst_path)
+    sampler = _sampler(pipeline, base)
+    out = sampler.sample((x - mean) / std, emb.to(device=device, dtype=torch.float32)[:1], 1, want_features=False, want_rgb=True)
+    rgb = out["rgb"][0].cpu().numpy()
+    sampler.check_finite()   # fp16 overflow in either graph raises instead of writing a garbage PNG
+    Image.fromarray(rgb).save(dst_path)

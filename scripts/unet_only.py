@@ -7,7 +7,8 @@ from ldiffusion_amd import configs, weights
 from ldiffusion_amd.models import UNet2DConditionModel
 ucfg = configs.SD15_UNET
 unet = UNet2DConditionModel(ucfg, weights.synthetic_state_dict(weights.unet_param_shapes(ucfg), 42, fp16_values=True), "cuda:0")
-lat = torch.randn((8, 4, 64, 64), device="cuda:0")
+B = int(os.environ.get("LDIFF_UNET_B", "8"))   # batch (default 8; 1 = the reference's own batch)
+lat = torch.randn((B, 4, 64, 64), device="cuda:0")
 ctx = torch.randn((1, 6, 768), device="cuda:0") * 0.5
 for _ in range(3):
     unet(lat, 501, ctx)
@@ -17,4 +18,4 @@ N = 20
 for _ in range(N):
     unet(lat, 501, ctx)
 torch.cuda.synchronize()
-print(f"unet step: wall per pass {(time.perf_counter() - t0) / N * 1e3:.2f} ms over {N} passes ({N + 3} passes in the process)")
+print(f"unet step (B={B}): wall per pass {(time.perf_counter() - t0) / N * 1e3:.2f} ms over {N} passes ({N + 3} passes in the process)")

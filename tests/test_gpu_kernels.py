@@ -587,13 +587,21 @@ FUSED_STATS_CASES = {
     "conv3x3_x16_tile": (8, 64, 128, 128, 128, 3, 1),
     "conv3x3_p16_one_tile_per_workgroup": (1, 64, 256, 256, 128, 3, 1),
     "conv3x3_p16_ragged_72x88": (8, 64, 72, 88, 128, 3, 1),
+    # round 6: split-K launches -- the statistics come from the reduce kernel (32-row blocks), whichever kernel wrote the partials
+    "conv3x3_8x8_split4": (3, 256, 8, 8, 128, 3, 1, 4),
+    "conv3x3_8x8_split16_of_20_slabs": (1, 1280, 8, 8, 128, 3, 1, 16),
+    "conv3x3_16x16_split2_320": (2, 128, 16, 16, 320, 3, 1, 2),
+    "gemm_dma_1x1_split3": (2, 512, 16, 16, 256, 1, 1, 3),
+    "gemm_dma_1x1_split9_tail_rows": (1, 1280, 8, 8, 320, 1, 1, 9),
+    "igemm_stride2_split2": (2, 64, 32, 32, 64, 3, 2, 2),
 }
 
 
 @pytest.mark.parametrize("name", list(FUSED_STATS_CASES))
 def test_fused_groupnorm_statistics(lib, name):
     """Statistics accumulated in the producer's epilogue + finalize == F.group_norm of the (fp16) output it wrote."""
-    B, C1, H, W, Cout, ks, stride = FUSED_STATS_CASES[name]
+    B, C1, H, W, Cout, ks, stride = FUSED_STATS_CASES[name][:7]
+    splitk = FUSED_STATS_CASES[name][7] if len(FUSED_STATS_CASES[name]) > 7 else 0
     g = torch.Generator().manual_seed(zlib.crc32(name.encode()) % 1000)
     x = torch.randn((B, C1, H, W), generator=g)
     w = torch.randn((Cout, C1, ks, ks), generator=g) / math.sqrt(C1 * ks * ks)
@@ -606,8 +614,13 @@ def test_fused_groupnorm_statistics(lib, name):
     a_.x, a_.C1, a_.B, a_.Hin, a_.Win, a_.Hout, a_.Wout = xd.data_ptr(), C1, B, H, W, Ho, Wo
     a_.ks, a_.stride, a_.pad_t, a_.pad_l = ks, stride, ks // 2, ks // 2
     a_.w, a_.N, a_.Nrows, a_.bias, a_.y, a_.ldy = wd.data_ptr(), Cout, Cout, bd.data_ptr(), y.data_ptr(), Cout
+    if splitk:   # the unsplit launch first: the split one must reproduce its output (fp32 partial sums in another association)
+        _lib.check(lib.ldiff_op_conv(C.byref(a_), sp()))
+        y_unsplit = y.clone()
+        y.fill_(float("nan"))
+        a_.splitk = splitk
     R = lib.ldiff_op_conv_stats_blocks(C.byref(a_))
-    assert R > 0
+    assert R > 0 and (not splitk or R == Ho * Wo // 32)
     st = torch.full((B, Cout, R, 2), float("nan"), device=DEV)
     a_.stats = st.data_ptr()
     _lib.check(lib.ldiff_op_conv(C.byref(a_), sp()))
@@ -618,6 +631,8 @@ def test_fused_groupnorm_statistics(lib, name):
                                         scale.data_ptr(), shift.data_ptr(), sp()))
     torch.cuda.synchronize()
     assert torch.isfinite(st).all()
+    if splitk:
+        assert torch.isfinite(y).all() and (y.float() - y_unsplit.float()).abs().max() <= 2e-3 * y_unsplit.float().abs().max()
     yr = y.float().cpu().permute(0, 3, 1, 2)
     got = yr * scale.cpu()[:, :, None, None] + shift.cpu()[:, :, None, None]
     ref = F.group_norm(yr, 32, gamma, beta, 1e-5)

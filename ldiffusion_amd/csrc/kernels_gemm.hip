@@ -135,6 +135,35 @@ __global__ __launch_bounds__(256, 2) void gemm_dma_kernel(const ConvParams p) {
     for (int i = 0; i < A_NP; ++i) a_voff[i] = a_row[i] * (pitch2 * 2) + a_sw[i];
   }
   issue(kt0, std::integral_constant<int, 0>{});
+  // 64 x 64 tiles (the small launches: 5-40 K steps of ~1 us): the epilogue's operands -- bias, residual hi / lo -- are fetched HERE, under the first
+  // slice's round trip, instead of as one more dependent round trip behind the K loop (8 registers at this tile size; the larger tiles have none to spare)
+  constexpr bool EARLY = BM * BN <= 64 * 64;
+  const int ncol_e = n0 + wave_n * (BN / 2) + g * 4;
+  f32x4 bb_e[EARLY ? NT : 1];
+  f16x4 rr_e[EARLY ? MT : 1][EARLY ? NT : 1], rl_e[EARLY ? MT : 1][EARLY ? NT : 1];
+  if constexpr (EARLY) {
+    if (S == 1) {
+#pragma unroll
+      for (int a = 0; a < NT; ++a) {
+        float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (bvec && ncol_e + a * 16 < p.N) t = *reinterpret_cast<const float4*>(bvec + ncol_e + a * 16);
+        bb_e[a] = (f32x4){t.x, t.y, t.z, t.w};
+      }
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        const int mm = m0 + wave_m * (BM / 2) + m * 16 + l15;
+#pragma unroll
+        for (int a = 0; a < NT; ++a) {
+          rr_e[m][a] = (f16x4){(f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f};
+          rl_e[m][a] = rr_e[m][a];
+          if (p.res && mm < p.M && ncol_e + a * 16 < p.N) {
+            rr_e[m][a] = *reinterpret_cast<const f16x4*>(p.res + (long long)mm * p.ld_res + ncol_e + a * 16);
+            if (p.res_lo) rl_e[m][a] = *reinterpret_cast<const f16x4*>(p.res + (long long)mm * p.ld_res + p.res_lo + ncol_e + a * 16);
+          }
+        }
+      }
+    }
+  }
   __syncthreads();
   auto step = [&](int kt, auto bufc) {
     constexpr int buf = decltype(bufc)::value;
@@ -189,9 +218,12 @@ __global__ __launch_bounds__(256, 2) void gemm_dma_kernel(const ConvParams p) {
   f32x4 bb[NT];
 #pragma unroll
   for (int a = 0; a < NT; ++a) {
-    float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (bvec && ncol + a * 16 < p.N) t = *reinterpret_cast<const float4*>(bvec + ncol + a * 16);
-    bb[a] = (f32x4){t.x, t.y, t.z, t.w};
+    if constexpr (EARLY) bb[a] = bb_e[a];
+    else {
+      float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (bvec && ncol + a * 16 < p.N) t = *reinterpret_cast<const float4*>(bvec + ncol + a * 16);
+      bb[a] = (f32x4){t.x, t.y, t.z, t.w};
+    }
   }
   int mrow[MT];
 #pragma unroll
@@ -200,7 +232,12 @@ __global__ __launch_bounds__(256, 2) void gemm_dma_kernel(const ConvParams p) {
     mrow[m] = mm < p.M ? mm : -1;
   }
   f16x4 rr[MT][NT], rl[MT][NT];
-  if (p.res) {
+  if constexpr (EARLY) {
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int a = 0; a < NT; ++a) { rr[m][a] = rr_e[m][a]; rl[m][a] = rl_e[m][a]; }
+  } else if (p.res) {
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll

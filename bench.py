@@ -300,6 +300,7 @@ def main():
     # ---- UNet step alone (the metric's second half: UNet-step HBM GB/s vs peak), HIP events on the launch stream ----
     unet_ms = unet_eager_ms = None
     unet_small = {}
+    unet_nodes = {}
     if not args.no_unet_step:
         def time_unet(lat, reps=5):
             for _ in range(3):
@@ -314,7 +315,8 @@ def main():
 
         def unet_step_at(b, reps=5):
             lat = torch.randn((b, 4, img // 8, img // 8), device=dev)
-            g_ms = time_unet(lat, reps)            # product default: hipGraph replay of the ~900 launches
+            g_ms = time_unet(lat, reps)            # product default: hipGraph replay of the pass's launches
+            unet_nodes[b] = pipe.unet.graph_nodes
             pipe.unet.set_graph(False)
             e_ms = time_unet(lat, reps)
             pipe.unet.set_graph(True)
@@ -395,13 +397,14 @@ def main():
         result["unet_step"] = {"ms": unet_ms, "batch": PATCHES_PER_GPU,
                                "hbm_GBps": ub / (unet_ms * 1e-3) / 1e9, "hbm_frac": ub / (unet_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                                "tflops": uf / (unet_ms * 1e-3) / 1e12, "mfma_frac": uf / (unet_ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS,
-                               "ms_eager_launches": unet_eager_ms, "launch": "hipGraph replay (ms) vs the same kernels launched one by one (ms_eager_launches)"}
+                               "ms_eager_launches": unet_eager_ms, "launches": unet_nodes.get(PATCHES_PER_GPU),
+                               "launch": "hipGraph replay (ms) vs the same kernels launched one by one (ms_eager_launches); launches = nodes of the captured graph"}
         for b, (g_ms, e_ms) in unet_small.items():
             bb = UNET_WEIGHT_BYTES + b * UNET_ACT_BYTES_PER_SAMPLE
             result[f"unet_step_b{b}"] = {"ms": g_ms, "batch": b, "hbm_GBps": bb / (g_ms * 1e-3) / 1e9, "hbm_frac": bb / (g_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                                          "tflops": b * UNET_FLOP_PER_SAMPLE / (g_ms * 1e-3) / 1e12,
                                          "mfma_frac": b * UNET_FLOP_PER_SAMPLE / (g_ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS,
-                                         "ms_eager_launches": e_ms,
+                                         "ms_eager_launches": e_ms, "launches": unet_nodes.get(b),
                                          "algorithmic_bytes": bb}
     if world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(ucfg, vcfg, usd, vsd, img, N_PASSES)

@@ -82,6 +82,7 @@ int ldiff_unet_set_precision(ldiff_unet*, int mode);
  * eagerly.  Forwards issued while per-launch profiling is enabled, or on a stream that is itself being captured, run eagerly. */
 int ldiff_unet_set_graph(ldiff_unet*, int on);
 int64_t ldiff_unet_graph_replays(ldiff_unet*); /* forwards served by graph replay so far */
+int64_t ldiff_unet_graph_nodes(ldiff_unet*);   /* kernel launches of the currently captured forward (0: none captured yet) */
 /* number of expected tensors not loaded yet; names via ldiff_unet_missing_name(i) */
 int ldiff_unet_missing(ldiff_unet*);
 const char* ldiff_unet_missing_name(ldiff_unet*, int i);

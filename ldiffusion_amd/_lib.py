@@ -50,6 +50,7 @@ SIGNATURES = {
     "ldiff_unet_set_precision": (I, [P, I]),
     "ldiff_unet_set_graph": (I, [P, I]),
     "ldiff_unet_graph_replays": (I64, [P]),
+    "ldiff_unet_graph_nodes": (I64, [P]),
     "ldiff_unet_missing": (I, [P]),
     "ldiff_unet_missing_name": (C.c_char_p, [P, I]),
     "ldiff_unet_set_context": (I, [P, P, I, I, P]),

@@ -70,6 +70,7 @@ int ldiff_unet_set_graph(ldiff_unet* u, int on) {
   API_END
 }
 int64_t ldiff_unet_graph_replays(ldiff_unet* u) { return u ? (int64_t)u->gc.replays : -1; }
+int64_t ldiff_unet_graph_nodes(ldiff_unet* u) { return u ? (int64_t)u->gc.nodes : -1; }
 int ldiff_unet_missing(ldiff_unet* u) { return u ? u->ws.missing() : -1; }
 const char* ldiff_unet_missing_name(ldiff_unet* u, int i) { return u ? u->ws.missing_name(i) : ""; }
 int ldiff_unet_set_context(ldiff_unet* u, const void* ctx_dev, int B_ctx, int L, void* stream) {

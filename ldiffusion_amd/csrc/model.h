@@ -214,7 +214,7 @@ struct ldiff_unet {
     hipStream_t cap_stream = nullptr;
     float *in = nullptr, *out = nullptr, *t = nullptr;
     size_t in_cap = 0;
-    long long replays = 0, captures = 0;
+    long long replays = 0, captures = 0, nodes = 0;   // nodes: kernel launches of the captured forward
     void drop();
   } gc;
   ~ldiff_unet();

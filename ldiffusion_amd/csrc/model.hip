@@ -960,6 +960,12 @@ void ldiff_unet::forward(const float* x, int B, int h, int w, float tval, float*
     }
     HIP_CHECK(hipStreamEndCapture(gc.cap_stream, &g));
     gc.graph = g;
+    {
+      size_t n_nodes = 0;
+      if (hipGraphGetNodes(g, nullptr, &n_nodes) == hipSuccess) gc.nodes = (long long)n_nodes;
+      static const bool debug = getenv("LDIFF_DEBUG") != nullptr;
+      if (debug) fprintf(stderr, "[ldiff_unet] captured forward B=%d %dx%d precision %d: %lld graph nodes (= kernel launches per pass)\n", B, h, w, precision, gc.nodes);
+    }
     HIP_CHECK(hipGraphInstantiate(&gc.exec, g, nullptr, nullptr, 0));
     gc.uses = 2;
     ++gc.captures;

@@ -98,6 +98,11 @@ class UNet2DConditionModel:
     def graph_replays(self) -> int:
         return int(self._lib.ldiff_unet_graph_replays(self._h))
 
+    @property
+    def graph_nodes(self) -> int:
+        """Kernel launches of the currently captured forward (0 before the first capture)."""
+        return int(self._lib.ldiff_unet_graph_nodes(self._h))
+
     # ---- checkpoint surface ----
     def load_state_dict(self, sd, strict=True):
         _load_state_dict(self._lib, self._lib.ldiff_unet_load, self._h, sd, weights.unet_param_shapes(self._cfg))

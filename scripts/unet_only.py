@@ -18,4 +18,4 @@ N = 20
 for _ in range(N):
     unet(lat, 501, ctx)
 torch.cuda.synchronize()
-print(f"unet step (B={B}): wall per pass {(time.perf_counter() - t0) / N * 1e3:.2f} ms over {N} passes ({N + 3} passes in the process)")
+print(f"unet step (B={B}): wall per pass {(time.perf_counter() - t0) / N * 1e3:.2f} ms over {N} passes ({N + 3} passes in the process); {unet.graph_nodes} launches per pass (hipGraph nodes)")

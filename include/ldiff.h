@@ -317,6 +317,9 @@ int ldiff_op_gn_train_bwd(const void* x, const void* dy, const void* gamma, cons
 int ldiff_op_ln_bwd(const void* x, const void* dy, const void* gamma, void* dx, void* dgamma, void* dbeta, int rows, int C, float eps, void* stream);
 /* GEGLU backward: x [M, 2*C4] = [h | gate], dy [M, C4] -> dx [M, 2*C4] */
 int ldiff_op_geglu_bwd(const void* x, const void* dy, void* dx, int64_t M, int C4, void* stream);
+/* SiLU on n float16 elements and its backward (the time-embedding MLP of the step: time_embedding.act, the SiLU in front of every time_emb_proj) */
+int ldiff_op_silu(const void* x, void* y, int64_t n, void* stream);
+int ldiff_op_silu_bwd(const void* x, const void* dy, void* dx, int64_t n, void* stream);
 /* softmax(scale Q K^T) V backward for short sequences (Lq * Lk <= 8192: the 8x8-latent fine-tuning step); layouts as ldiff_op_attention */
 int ldiff_op_attention_bwd(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, const void* dO, int ldo, void* dq, void* dk, void* dv,
                            int B, int heads, int Lq, int Lk, int d, int64_t q_bstride, int64_t kv_bstride, int64_t o_bstride, float scale, void* stream);

@@ -105,6 +105,8 @@ SIGNATURES = {
     "ldiff_op_gn_train_bwd": (I, [P, P, P, P, P, P, P, P, P, I, I, I, I, I, P]),
     "ldiff_op_ln_bwd": (I, [P, P, P, P, P, P, I, I, F, P]),
     "ldiff_op_geglu_bwd": (I, [P, P, P, I64, I, P]),
+    "ldiff_op_silu": (I, [P, P, I64, P]),
+    "ldiff_op_silu_bwd": (I, [P, P, P, I64, P]),
     "ldiff_op_attention_bwd": (I, [P, I, P, I, P, I, P, I, P, P, P, I, I, I, I, I, I64, I64, I64, F, P]),
     "ldiff_op_adamw": (I, [P, P, P, P, I64, F, F, F, F, F, I, P]),
     "ldiff_op_pack_weight": (I, [P, P, I, I, I, I, I, I, P]),

@@ -314,6 +314,32 @@ class GegluFn(torch.autograd.Function):
         return dx
 
 
+class SiluFn(torch.autograd.Function):
+    """y = x * sigmoid(x) on float16 tensors of any shape (ldiff_op_silu / ldiff_op_silu_bwd): the two activations of the time-embedding MLP,
+    the last elementwise ops of the step that used to run through ATen."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = x.contiguous()
+        _check_act(x, "silu input")
+        y = torch.empty_like(x)
+        _lib.check(_lib.load().ldiff_op_silu(x.data_ptr(), y.data_ptr(), x.numel(), _sp()))
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = torch.empty_like(x)
+        _lib.check(_lib.load().ldiff_op_silu_bwd(x.data_ptr(), dy.data_ptr(), dx.data_ptr(), x.numel(), _sp()))
+        return dx
+
+
+def silu(x):
+    return SiluFn.apply(x)
+
+
 class AttentionFn(torch.autograd.Function):
     """softmax(q k^T / sqrt(d)) v per head on float16 [B, L, heads*d] tensors (K/V given per batch entry, not broadcast)."""
 

@@ -724,6 +724,18 @@ int ldiff_op_geglu_bwd(const void* x, const void* dy, void* dx, int64_t M, int C
   launch_geglu_bwd((const f16*)x, (const f16*)dy, (f16*)dx, M, C4, (hipStream_t)stream);
   API_END
 }
+int ldiff_op_silu(const void* x, void* y, int64_t n, void* stream) {
+  API_BEGIN
+  LDIFF_CHECK(x && y && n >= 0, LDIFF_ERR_INVALID, "op_silu: bad arguments");
+  launch_silu_f16((const f16*)x, (f16*)y, n, (hipStream_t)stream);
+  API_END
+}
+int ldiff_op_silu_bwd(const void* x, const void* dy, void* dx, int64_t n, void* stream) {
+  API_BEGIN
+  LDIFF_CHECK(x && dy && dx && n >= 0, LDIFF_ERR_INVALID, "op_silu_bwd: bad arguments");
+  launch_silu_bwd_f16((const f16*)x, (const f16*)dy, (f16*)dx, n, (hipStream_t)stream);
+  API_END
+}
 int ldiff_op_attention_bwd(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, const void* dO, int ldo, void* dq, void* dk, void* dv,
                            int B, int heads, int Lq, int Lk, int d, int64_t q_bstride, int64_t kv_bstride, int64_t o_bstride, float scale, void* stream) {
   API_BEGIN

@@ -235,6 +235,8 @@ void launch_gn_train_bwd(const f16* x, const f16* dy, const float* gamma, const 
                          float* dbeta, int B, int HW, int C, int G, int silu, hipStream_t s);
 void launch_ln_bwd(const f16* x, const f16* dy, const float* gamma, f16* dx, float* dgamma, float* dbeta, int rows, int C, float eps, hipStream_t s);
 void launch_geglu_bwd(const f16* x, const f16* dy, f16* dx, long long M, int C4, hipStream_t s);
+void launch_silu_f16(const f16* x, f16* y, long long n, hipStream_t s);                        // y = x sigma(x) on fp16 elements
+void launch_silu_bwd_f16(const f16* x, const f16* dy, f16* dx, long long n, hipStream_t s);    // dx = dy sigma(x) (1 + x (1 - sigma(x)))
 void launch_attn_bwd(const AttnParams& p, const f16* dO, f16* dq, f16* dk, f16* dv, hipStream_t s);
 void launch_pack_weight(const float* w, f16* dst, int Cout, int Cin, int k, int R, int Cp, int mode, hipStream_t s);
 void launch_unpack_wgrad(const float* g, float* dw, int Cout, int Cin, int k, int Cx, int ldg, hipStream_t s);

@@ -592,3 +592,27 @@ void launch_infonce(const float* feat, int B, int n, long long HW, const int* bi
   hipLaunchKernelGGL(infonce_kernel, dim3(T), dim3(256), smem, s, feat, n, HW, bi, ai, pi, ni, T, t_dev, K, 1.0f / temperature, loss, dfeat);
   HIP_CHECK(hipGetLastError());
 }
+
+// ---- SiLU on fp16 rows and its backward (the time-embedding MLP of the fine-tuning step: train.py TrainableUNet.forward) ----
+__global__ void silu_f16_kernel(const f16* __restrict__ x, f16* __restrict__ y, long long n) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float v = (float)x[i];
+  y[i] = (f16)(v / (1.0f + expf(-v)));
+}
+__global__ void silu_bwd_f16_kernel(const f16* __restrict__ x, const f16* __restrict__ dy, f16* __restrict__ dx, long long n) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float v = (float)x[i], sg = 1.0f / (1.0f + expf(-v));
+  dx[i] = (f16)((float)dy[i] * sg * (1.0f + v * (1.0f - sg)));   // d/dx x sigma(x) = sigma (1 + x (1 - sigma))
+}
+void launch_silu_f16(const f16* x, f16* y, long long n, hipStream_t s) {
+  if (n == 0) return;
+  hipLaunchKernelGGL(silu_f16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, y, n);
+  HIP_CHECK(hipGetLastError());
+}
+void launch_silu_bwd_f16(const f16* x, const f16* dy, f16* dx, long long n, hipStream_t s) {
+  if (n == 0) return;
+  hipLaunchKernelGGL(silu_bwd_f16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, dy, dx, n);
+  HIP_CHECK(hipGetLastError());
+}

@@ -131,6 +131,10 @@ __global__ __launch_bounds__(256) void gn_finalize2_kernel(const float* __restri
                                                            int* __restrict__ nonfinite) {
   const int grp = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
   const int C = C1 + C2, Cg = C / groups, c0 = grp * Cg, c1 = c0 + Cg;
+  // gamma / beta of this thread's first output channel go out with the partials (one round trip instead of a second, dependent one behind the
+  // reduction: the launch is a pure latency chain, 6.5 us of which the kernel boundary is 1.5)
+  const bool own = c0 + tid < c1;
+  const float g_own = own ? gamma[c0 + tid] : 0.f, b_own = own ? beta[c0 + tid] : 0.f;
   // the partials of the group's channels are (up to) two contiguous runs of float2: channels [c0, min(c1, C1)) of part 1 and
   // [max(c0, C1), c1) of part 2.  All loads of a run are independent (a per-channel loop would chain Cg memory round trips:
   // 10-60 of them on the UNet levels, where R is small and most threads idle).
@@ -161,7 +165,12 @@ __global__ __launch_bounds__(256) void gn_finalize2_kernel(const float* __restri
   double var = q / n - mean * mean;
   if (var < 0.0) var = 0.0;
   const float rstd = (float)(1.0 / sqrt(var + (double)eps));
-  for (int c = c0 + tid; c < c0 + Cg; c += 256) {
+  if (own) {
+    const float gsc = g_own * rstd;
+    scale[(long long)b * C + c0 + tid] = gsc;
+    shift[(long long)b * C + c0 + tid] = b_own - (float)mean * gsc;
+  }
+  for (int c = c0 + tid + 256; c < c0 + Cg; c += 256) {
     const float gsc = gamma[c] * rstd;
     scale[(long long)b * C + c] = gsc;
     shift[(long long)b * C + c] = beta[c] - (float)mean * gsc;

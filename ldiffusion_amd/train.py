@@ -119,8 +119,8 @@ class TrainableUNet(_Graph):
         if cfg["flip_sin_to_cos"]:
             emb = torch.cat([emb[half:], emb[:half]])
         emb = emb[None].expand(B, -1).to(torch.float16).contiguous()
-        temb = self.lin("time_embedding.linear_2", F.silu(self.lin("time_embedding.linear_1", emb)))
-        temb_act = F.silu(temb).contiguous()
+        temb = self.lin("time_embedding.linear_2", ag.silu(self.lin("time_embedding.linear_1", emb)))
+        temb_act = ag.silu(temb)
         x = self.conv("conv_in", _nhwc16(sample.to(self.device, torch.float32)))
         skips = [x]
         for i, bt in enumerate(cfg["down_block_types"]):
@@ -413,6 +413,13 @@ def finish_step(params, opt_state, lr, weight_decay, max_grad_norm, optimizer=No
     return True
 
 
+def text_projection(text_hidden, weight, bias):
+    """The trainable projection of the CLIP hidden states onto the UNet's cross-attention width (segmentor.py:33-35, ldiffusion.py:142-146:
+    nn.Linear(768, cross_attention_dim)) on the library's GEMM with its dgrad / wgrad (float16 operands, fp32 accumulate, float32 parameter
+    gradients) -- every FLOP of the step is in libldiff_hip.so; the UNet consumes the context as float16 anyway."""
+    return ag.linear(text_hidden.to(torch.float16).contiguous(), weight, bias)
+
+
 def train_step(unet, vae_dec, proj, z0, text_hidden, timesteps, abar, u_list, pairs, opt_state, lr=1e-5, weight_decay=0.01, loss_fn=None,
                max_grad_norm=None, seed=0, offset=0, loss_scale=None, optimizer=None):
     """One fine-tuning step (ldiffusion.py:209-255): text projection -> V5 features -> loss -> backward through the VAE decoder and the
@@ -425,7 +432,7 @@ def train_step(unet, vae_dec, proj, z0, text_hidden, timesteps, abar, u_list, pa
         loss_scale = opt_state.setdefault("loss_scale", LOSS_SCALE)
     for p in params:
         p.grad = None
-    ctx = F.linear(text_hidden, proj[0], proj[1])
+    ctx = text_projection(text_hidden, proj[0], proj[1])
     feats, rgb = v5_features(unet, vae_dec, z0, ctx, timesteps, abar, u_list, seed=seed, offset=offset)
     loss = contrastive_loss(feats, pairs) if loss_fn is None else loss_fn(feats, rgb)
     (loss * loss_scale).backward()
@@ -479,7 +486,7 @@ class GraphedStep:
         try:
             self.plan_unet.run()
             with ag.packed_weights(self.plan_unet, self.plan_dec):
-                ctx = F.linear(self.hidden, pw, pb)
+                ctx = text_projection(self.hidden, pw, pb)
                 feats, _ = v5_features(self.unet, self.vae_dec, None, ctx, self.timesteps, self.abar, out_hw=self.out_hw, noisy_list=self.noisy)
                 loss = ag.InfoNceFn.apply(feats, self.bi, self.ai, self.pi, self.ni, self.temperature, self.count)
                 leaves = [v for v in alias.values() if v.requires_grad] + [pw, pb]   # the order of self.params

@@ -143,6 +143,22 @@ def test_geglu_backward():
     assert max(e) <= TOL
 
 
+def test_silu_backward():
+    """ldiff_op_silu / ldiff_op_silu_bwd (the time-embedding MLP's activations of the fine-tuning step) against autograd over F.silu."""
+    g = torch.Generator().manual_seed(6)
+    x = r16(torch.randn((3, 1280), generator=g) * 3.0)
+    xr = x.clone().requires_grad_(True)
+    yr = F.silu(xr)
+    G = r16(torch.randn(yr.shape, generator=g))
+    (yr * G).sum().backward()
+    xd = x.to(torch.float16).to(DEV).requires_grad_(True)
+    y = ag.silu(xd)
+    (y.float() * G.to(DEV)).sum().backward()
+    e = (rel(y, yr), rel(xd.grad, xr.grad))
+    print(f"silu: y {e[0]:.2e} dx {e[1]:.2e}")
+    assert max(e) <= TOL and y.dtype == torch.float16 and xd.grad.dtype == torch.float16
+
+
 @pytest.mark.parametrize("B,heads,Lq,Lk,d", [(2, 8, 64, 64, 40), (2, 8, 16, 16, 80), (2, 8, 4, 4, 160), (2, 8, 64, 6, 40), (2, 1, 64, 64, 512), (1, 8, 1, 1, 32)])
 def test_attention_backward(B, heads, Lq, Lk, d):
     g = torch.Generator().manual_seed(Lq + d)

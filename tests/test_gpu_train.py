@@ -90,7 +90,7 @@ def _compare_step(sd15, tol_feat, tol_loss, tol_grad, min_cos):
     unet = train.TrainableUNet(ucfg, usd, DEV)
     dec = train.FrozenVAEDecoder(vcfg, vsd, DEV)
     pw, pb = proj_w.to(DEV).requires_grad_(True), proj_b.to(DEV).requires_grad_(True)
-    ctx = F.linear(hidden.to(DEV), pw, pb)
+    ctx = train.text_projection(hidden.to(DEV), pw, pb)   # the product path: the library's GEMM (the oracle side above is F.linear in fp32)
     feats, _ = train.v5_features(unet, dec, z0.to(DEV), ctx, ts, sch.alphas_cumprod, [u.to(DEV) for u in u_list])
     loss = train.contrastive_loss(feats, pairs)
     (loss * train.LOSS_SCALE).backward()                       # as train_step does: float16 activation gradients behind a static loss scale
@@ -171,7 +171,7 @@ def test_graphed_step_equals_the_eager_step():
     for name, (z, h, ul, pr) in (("capture", (z0, hidden, u_list, pairs)), ("replay", batch2)):
         for p_ in params:
             p_.grad = None
-        ctx = F.linear(h.to(DEV), pw, pb)
+        ctx = train.text_projection(h.to(DEV), pw, pb)
         feats, _ = train.v5_features(unet, dec, z.to(DEV), ctx, ts, sch.alphas_cumprod, [u.to(DEV) for u in ul])
         loss = train.contrastive_loss(feats, pr)
         (loss * train.LOSS_SCALE).backward()
@@ -179,13 +179,18 @@ def test_graphed_step_equals_the_eager_step():
         got_loss = gstep(z.to(DEV), h.to(DEV), pr, [u.to(DEV) for u in ul])
         torch.cuda.synchronize()
         e_l = abs(got_loss.item() - loss.item()) / abs(loss.item())
-        worst = 0.0
-        for p_, r in zip(params, ref):
+        worst, where = 0.0, -1
+        for i_, (p_, r) in enumerate(zip(params, ref)):
             assert (p_.grad is None) == (r is None)
             if r is not None:
-                worst = max(worst, ((p_.grad - r).abs().max() / r.abs().max().clamp_min(1e-20)).item())
-        print(f"graphed step ({name}): loss {got_loss.item():.6f} vs eager {loss.item():.6f} ({e_l:.1e}); worst parameter-gradient difference {worst:.1e} of the tensor's max")
-        assert e_l <= 1e-5 and worst <= 1e-3
+                e_ = ((p_.grad - r).abs().max() / r.abs().max().clamp_min(1e-20)).item()
+                if e_ > worst:
+                    worst, where = e_, i_
+        print(f"graphed step ({name}): loss {got_loss.item():.6f} vs eager {loss.item():.6f} ({e_l:.1e}); worst parameter-gradient difference {worst:.1e} of the tensor's max "
+              f"(parameter {where} of {len(params)}, shape {tuple(params[where].shape)})")
+        # (the loss kernel's atomic adds reorder between runs; behind them every activation gradient is float16, so a reordered sum flips roundings downstream --
+        # since round 6 also in the text projection's own wgrad, which runs on the library's float16 GEMM instead of ATen's float32 one)
+        assert e_l <= 1e-5 and worst <= 3e-3
     state = {}
     l0 = train.train_step_graphed(gstep, z0.to(DEV), hidden.to(DEV), [u.to(DEV) for u in u_list], pairs, state, lr=1e-4)
     l1 = train.train_step_graphed(gstep, z0.to(DEV), hidden.to(DEV), [u.to(DEV) for u in u_list], pairs, state, lr=1e-4)

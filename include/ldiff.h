@@ -76,7 +76,7 @@ int ldiff_unet_load(ldiff_unet*, const char* name, const void* host_ptr, int dty
  *   1 = residual stream kept as fp16 hi|lo pairs (adds to fp32 round-off), stream-carrying contractions on split operands (default)
  *   2 = every conv / linear operand split (K doubled): ~1e-4 */
 int ldiff_unet_set_precision(ldiff_unet*, int mode);
-/* One forward is ~900 kernel launches.  With graphs on (default) the launch sequence of a (B, h, w, precision, context)
+/* One forward is ~390-450 kernel launches (384 at B = 8, 443 at B = 1 at SD-v1.5 size: ldiff_unet_graph_nodes).  With graphs on (default) the launch sequence of a (B, h, w, precision, context)
  * configuration is captured into a hipGraph on its second use and replayed from then on (input, timestep and output pass through
  * handle-owned staging buffers: any caller pointers, any timestep; bit-identical results).  Off: every forward is launched
  * eagerly.  Forwards issued while per-launch profiling is enabled, or on a stream that is itself being captured, run eagerly. */

@@ -1327,6 +1327,11 @@ def test_config1_b8_bench_mode_against_oracle():
     torch.cuda.synchronize()
     s1.set_overlap(1); s2.set_overlap(1)
     assert pipe.unet.graph_replays >= 5
+    # launches of one UNet pass = nodes of the captured graph (round 6: 384 at this configuration; the round-5 verdict's bound is 550): a change that
+    # splits a fused launch again, or sends the split-K tensors back to a separate statistics pass, shows here
+    print(f"UNet pass at B={B}: {pipe.unet.graph_nodes} launches (hipGraph nodes)")
+    assert 0 < pipe.unet.graph_nodes <= 420
+    sp_nf = s1.check_finite()   # the bench configuration stays inside fp16's range (non-finite detector of both graphs)
     for o in outs:
         for k in ("latents", "features", "rgb"):
             assert torch.equal(o[k], serial[k]), f"pipelined batch differs from the serial run in {k}"

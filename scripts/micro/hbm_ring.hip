@@ -45,6 +45,23 @@ __global__ __launch_bounds__(256) void ring_kernel(const char* base, long long w
   if (acc == 0x12345678u) sink[0] = acc;
 }
 
+// The same bytes by plain global_load_dwordx4 into registers, UNR loads in flight per thread (no LDS, no barrier): what a small GEMM that takes its
+// MFMA fragments straight from memory would see.  A workgroup reads `bytes` contiguous bytes of its own.
+template <int UNR>
+__global__ __launch_bounds__(256) void direct_kernel(const char* base, long long wg_stride, int bytes, unsigned* sink) {
+  const uint4* p = reinterpret_cast<const uint4*>(base + (long long)blockIdx.x * wg_stride) + threadIdx.x;
+  const int n = bytes / 4096;   // loads per thread
+  unsigned acc = 0;
+  for (int i = 0; i < n; i += UNR) {
+    uint4 v[UNR];
+#pragma unroll
+    for (int j = 0; j < UNR; ++j) v[j] = p[(i + j) * 256];
+#pragma unroll
+    for (int j = 0; j < UNR; ++j) acc += v[j].x ^ v[j].w;
+  }
+  if (acc == 0x12345678u) sink[0] = acc;
+}
+
 static char* g_buf;
 static size_t g_bytes;
 static unsigned* g_sink;
@@ -77,6 +94,31 @@ void run(int grid, int steps, int work) {
   const double us = sum / (reps - 1) * 1e3;
   printf("%s%s wgs %4d  steps %3d  work %d  stages %d  nt %d : %7.1f us per launch  (best %6.1f)  %6.2f TB/s  %5.2f us per step\n", g_warm ? "warm " : "", TILED ? "tiled" : "rows ", grid, steps, work, STAGES, NT, us,
          best * 1e3, launch_bytes / (us * 1e-6) / 1e12, us / steps);
+}
+
+template <int UNR>
+void run_direct(int grid, int kib) {
+  const long long wg_stride = (long long)kib * 1024;
+  const size_t launch_bytes = (size_t)grid * wg_stride;
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  float sum = 0.f;
+  const int reps = 6;
+  for (int r = 0; r < reps; ++r) {
+    if (g_cursor + launch_bytes > g_bytes) g_cursor = 0;
+    const char* src = g_buf + g_cursor;
+    if (!g_warm) g_cursor += launch_bytes;
+    CK(hipEventRecord(e0));
+    hipLaunchKernelGGL(direct_kernel<UNR>, dim3(grid), dim3(256), 0, 0, src, wg_stride, kib * 1024, g_sink);
+    CK(hipEventRecord(e1));
+    CK(hipDeviceSynchronize());
+    float ms = 0;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    if (r) sum += ms;
+  }
+  const double us = sum / (reps - 1) * 1e3;
+  printf("%sdirect wgs %4d  %4d KiB per workgroup  %2d loads in flight per thread : %7.1f us per launch  %6.2f TB/s  %6.1f GB/s per workgroup\n", g_warm ? "warm " : "", grid, kib, UNR, us,
+         launch_bytes / (us * 1e-6) / 1e12, wg_stride / (us * 1e-6) / 1e9);
 }
 
 template <int NT>
@@ -119,5 +161,11 @@ int main() {
   }
   g_warm = false;
   for (int work : {0, 2}) { run<2, 0>(20, 20, work); run<2, 0>(320, 5, work); }
+  // plain register loads, all of a workgroup's bytes as deep in flight as the registers allow: 80 KiB = a 64 x 64 tile at K = 320, 320 KiB at K = 1280
+  for (int w = 0; w < 2; ++w) {
+    g_warm = w != 0;
+    run_direct<4>(320, 80); run_direct<8>(320, 80); run_direct<16>(320, 80);
+    run_direct<8>(80, 320); run_direct<16>(80, 320); run_direct<16>(20, 320); run_direct<16>(160, 160); run_direct<16>(640, 40);
+  }
   return 0;
 }

@@ -328,6 +328,19 @@ def main():
         for b in (1, 2):
             unet_small[b] = unet_step_at(b, 10)
 
+    # ---- the reference's own batch (one patch per call: pixel_latent_vector.py:63, segmentor.py:96), whole sampler, untimed extra: latency per patch ----
+    sample_b1_ms = None
+    if not args.no_unet_step and rank == 0:
+        one = images[:1].contiguous()
+        for _ in range(2):
+            sampler.sample(one, ctx, N_PASSES, want_features=True, want_rgb=True)
+        torch.cuda.synchronize()
+        tb = time.perf_counter()
+        for _ in range(5):
+            sampler.sample(one, ctx, N_PASSES, want_features=True, want_rgb=True)
+        torch.cuda.synchronize()
+        sample_b1_ms = (time.perf_counter() - tb) / 5 * 1e3
+
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
@@ -406,6 +419,10 @@ def main():
                                          "mfma_frac": b * UNET_FLOP_PER_SAMPLE / (g_ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS,
                                          "ms_eager_launches": e_ms, "launches": unet_nodes.get(b),
                                          "algorithmic_bytes": bb}
+    if sample_b1_ms is not None:
+        result["sample_b1"] = {"ms_per_patch": sample_b1_ms, "patches_per_sec": 1e3 / sample_b1_ms,
+                               "what": f"one {img}x{img} patch per call through the whole {N_PASSES}-pass sampler (the reference's own batch: pixel_latent_vector.py:63), "
+                                       "decodes beside the next UNet pass, joined per call; wall time per call, untimed extra (not the headline)"}
     if world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(ucfg, vcfg, usd, vsd, img, N_PASSES)
     print(json.dumps(result), flush=True)

@@ -341,6 +341,8 @@ def main():
         torch.cuda.synchronize()
         sample_b1_ms = (time.perf_counter() - tb) / 5 * 1e3
 
+    if dist is not None:
+        dist.barrier()   # rank 0's untimed extras above are done: nobody tears the communicator down under a rank that still runs
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()

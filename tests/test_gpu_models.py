@@ -1431,3 +1431,23 @@ def test_pixel_latent_vector_entry_point_mirror(tiny, tmp_path):
         plv.pixel_latent_vector(tiny["pipe"], None, None, 2, train_loader=data, text_embeddings=ctx, out_dir=str(tmp_path / "c"))
     with pytest.raises(RuntimeError):
         plv.pixel_latent_vector(tiny["pipe"], None, None, 5, train_loader=None, text_embeddings=ctx)
+
+
+@pytest.mark.timeout(900)
+def test_bench_two_ranks_control_flow_on_one_gpu():
+    """bench.py's N > 1 path end to end on a one-GPU box: `python bench.py --gpus 2` starts its two ranks itself (torch.distributed.run, 127.0.0.1), both on
+    cuda:0 over gloo (LDIFF_BENCH_SHARED_GPU=1: test only -- the real run is one rank per GPU over RCCL), reduced-width graph.  Checks the contract of the
+    line: patch sharding, barrier + max over ranks, the mask all-gather, the serial-vs-pipelined result check, the non-finite check, rank 0 alone printing."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, LDIFF_BENCH_SHARED_GPU="1")
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--tiny", "--no-cpu-baseline"],
+                         env=env, capture_output=True, text=True, timeout=800)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "weak" and d["checked"] is True and d["check"]["finite"] is True
+    assert d["comm"]["world_size"] == 2 and d["config"]["parallelism"].startswith("dp2") and d["value"] > 0

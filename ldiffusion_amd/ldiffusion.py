@@ -93,6 +93,10 @@ class LDiffusionModel:
         # batch has the captured shape; anything else (content term, a short last batch, more triples than the capture holds) runs eagerly
         use_graph = bool(getattr(args, "use_graph", True)) and loss_obj.vgg is None
         gstep = None
+        # The reference's engine is DeepSpeed ZeRO stage 3 (ldiffusion.py:165-193): under a process group every rank owns 1/W of the float32 masters and
+        # of the AdamW moments, gradients are reduce-scattered, the parameters all-gathered in front of each forward (train.ShardedAdamW,
+        # partition_params).  Created BEFORE the GraphedStep: the parameters move into its flat buffer.  One process: the multi-tensor AdamW.
+        opt = T.ShardedAdamW(unet.parameters() + list(proj), lr=1e-5, weight_decay=0.01, partition_params=True) if self.is_distributed else None
         for epoch in range(num_epochs):
             if hasattr(train_loader, "sampler") and hasattr(train_loader.sampler, "set_epoch"):
                 train_loader.sampler.set_epoch(epoch)
@@ -126,16 +130,18 @@ class LDiffusionModel:
                     # never skipped per rank: a batch without sample triples still runs the (eager) step with zero gradients, so that every rank
                     # enters the same gradient collective (train.run_step)
                     val, _ = T.run_step(gstep, unet, dec, proj, latents, text_hidden, ts, self.pipeline.scheduler.alphas_cumprod, pairs, state,
-                                        lr=1e-5, weight_decay=0.01, max_grad_norm=1.0, seed=self.rank, offset=noise_offset)
+                                        lr=1e-5, weight_decay=0.01, max_grad_norm=1.0, seed=self.rank, offset=noise_offset, optimizer=opt)
                     total += val
                 else:
                     total += T.train_step(unet, dec, proj, latents, text_hidden, ts, self.pipeline.scheduler.alphas_cumprod, None, None, state, lr=1e-5,
-                                          weight_decay=0.01, loss_fn=loss_fn, max_grad_norm=1.0, seed=self.rank, offset=noise_offset)
+                                          weight_decay=0.01, loss_fn=loss_fn, max_grad_norm=1.0, seed=self.rank, offset=noise_offset, optimizer=opt)
                 noise_offset += len(ts) * latents.numel()   # v5_features draws offset + i * numel for pass i
             current = self._reduce_mean(total / max(1, len(train_loader)))
             if self._is_main_process():
                 print(f"Epoch [{epoch + 1}/{num_epochs}], Loss: {current:.4f}, Elapsed Time: {time.time() - start}s")
             if current < checkpoint:
+                if opt is not None:
+                    opt.gather()   # (a collective: every rank) the full parameters, for the checkpoint rank 0 writes
                 if self._is_main_process():
                     weights.save_model_dir(save_path, self.pipeline.unet._cfg, {k: p.detach().to("cpu") for k, p in unet.p.items()})
                     torch.save({"weight": proj[0].detach().to("cpu"), "bias": proj[1].detach().to("cpu")}, os.path.join(save_path, "proj_weights.pt"))

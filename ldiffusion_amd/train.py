@@ -298,9 +298,16 @@ class ShardedAdamW:
         AdamW on the slice only -- the two moment buffers exist for 1/W of the parameters per rank --,
         all-gather of the updated slices straight into the flat parameter buffer.
     Without a process group the slice is the whole buffer and no collective runs.  `update` is the elementwise AdamW of a contiguous range
-    (default: the HIP kernel); the CPU tests of the collective logic inject a torch formulation, the product never falls back to one."""
+    (default: the HIP kernel); the CPU tests of the collective logic inject a torch formulation, the product never falls back to one.
 
-    def __init__(self, params, lr=1e-5, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01, update=None):
+    `partition_params=True` is ZeRO stage 3's ownership (ldiffusion.py:165-193, "stage": 3): a rank OWNS only its 1/W slice of the float32 masters
+    (`master`, beside its slice of the two moments); the update writes the slice and nothing else, and the full parameters exist only between
+    `gather()` -- the all-gather in front of the forward, which `train_step` / `train_step_graphed` call -- and the next update.  The flat gather
+    buffer itself stays allocated (the captured step graph holds the parameters' addresses; 3.4 GB at SD-v1.5 size on a 288 GB part), so this is
+    ZeRO-3's communication pattern and ownership, not its memory saving; `poison_released=True` (tests) fills the buffer with NaN after every update
+    to prove that nothing reads parameters that were not gathered."""
+
+    def __init__(self, params, lr=1e-5, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01, update=None, partition_params=False, poison_released=False):
         self.params = list(params)
         self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
         self.update = update or _adamw_hip
@@ -326,6 +333,21 @@ class ShardedAdamW:
         self.gshard = torch.zeros(self.shard, dtype=torch.float32, device=dev)
         self.step_count = 0
         self.skipped = 0
+        self.partition_params, self.poison_released = bool(partition_params), bool(poison_released)
+        self.master = self.pshard.clone() if self.partition_params else None   # this rank's slice of the masters: the only copy it keeps between steps
+        self.gathered = True                                                     # the flat buffer was just built from the full parameters
+
+    def gather(self):
+        """ZeRO-3's all-gather in front of the forward (partition_params): every rank's master slice into the flat parameter buffer (the parameter
+        tensors are views of it).  No-op for replicated masters, and when the buffer is already current."""
+        if not self.partition_params or self.gathered:
+            return
+        dist = _dist()
+        if dist is not None:
+            dist.all_gather_into_tensor(self.flat, self.master)
+        else:
+            self.flat[: self.shard].copy_(self.master)
+        self.gathered = True
 
     def step(self, max_grad_norm=None):
         """Exchange, clip, update.  Returns the global gradient norm (after averaging, before clipping); a non-finite norm skips the update."""
@@ -356,6 +378,12 @@ class ShardedAdamW:
             if coef < 1.0:
                 self.gshard *= coef
         self.step_count += 1
+        if self.partition_params:   # the owned slice only; the full parameters come back with the next gather()
+            self.update(self.master, self.gshard, self.m, self.v, self.step_count, self.lr, self.betas, self.eps, self.weight_decay)
+            self.gathered = False
+            if self.poison_released:
+                self.flat.fill_(float("nan"))
+            return total
         self.update(self.pshard, self.gshard, self.m, self.v, self.step_count, self.lr, self.betas, self.eps, self.weight_decay)
         if dist is not None:
             dist.all_gather_into_tensor(self.flat, self.pshard.clone())
@@ -428,6 +456,8 @@ def train_step(unet, vae_dec, proj, z0, text_hidden, timesteps, abar, u_list, pa
     contrastive loss on the given sample triples `pairs`.  Returns the loss value.  `loss_scale` None: opt_state["loss_scale"] (starts at
     LOSS_SCALE, halved by finish_step whenever the exchanged gradient norm is not finite)."""
     params = unet.parameters() + list(proj)
+    if optimizer is not None:
+        optimizer.gather()   # parameter partitioning (ShardedAdamW partition_params): the all-gather in front of the forward
     if loss_scale is None:
         loss_scale = opt_state.setdefault("loss_scale", LOSS_SCALE)
     for p in params:
@@ -556,6 +586,8 @@ def train_step_graphed(gstep, z0, text_hidden, u_list, pairs, opt_state, lr=1e-5
     """`train_step` with forward + backward replayed from `gstep` (GraphedStep); exchange, clipping and AdamW as in the eager step, or --
     `optimizer` = a ShardedAdamW over `gstep.params` -- reduce-scatter, sharded AdamW, all-gather.  (A ShardedAdamW moves the parameters
     into its flat buffer: create it BEFORE the GraphedStep, whose graph and weight-layout plan hold the parameters' addresses.)"""
+    if optimizer is not None:
+        optimizer.gather()   # parameter partitioning (ShardedAdamW partition_params): the all-gather in front of the forward
     gstep.set_loss_scale(opt_state.setdefault("loss_scale", gstep.loss_scale))
     loss = gstep(z0, text_hidden, pairs, u_list, seed, offset)
     finish_step(gstep.params, opt_state, lr, weight_decay, max_grad_norm, optimizer=optimizer)

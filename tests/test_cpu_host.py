@@ -182,6 +182,29 @@ for step in range(1, 4):
     opt.step()
     for a, b in zip(pa, pb):
         assert torch.equal(a.data, b.data), (rank, step, (a.data - b.data).abs().max())
+# ZeRO-3 ownership (partition_params): a rank keeps only its slice of the masters; the full parameters exist only after gather().  Same gradients,
+# same results as the all-reduce path, bit for bit -- and with the released buffer poisoned, a forward without gather() would see NaN
+pc = [torch.nn.Parameter(t.clone()) for t in init]
+pd_ = [torch.nn.Parameter(t.clone()) for t in init]
+optz = train.ShardedAdamW(pd_, lr=1e-2, update=adamw, partition_params=True, poison_released=True)
+assert optz.master.numel() == optz.m.numel() == (sum(t.numel() for t in init) + 1) // 2
+mc, vc = [torch.zeros_like(t) for t in init], [torch.zeros_like(t) for t in init]
+for step in range(1, 4):
+    optz.gather()
+    for c, d in zip(pc, pd_):
+        assert torch.equal(c.data, d.data), (rank, step)                   # what the forward of this step reads
+    gr = torch.Generator().manual_seed(300 * step + rank)
+    for c, d in zip(pc, pd_):
+        g = torch.randn(c.shape, generator=gr)
+        c.grad, d.grad = g.clone(), g.clone()
+    train.allreduce_gradients(pc)
+    for c, m, v in zip(pc, mc, vc):
+        adamw(c.data, c.grad, m, v, step, 1e-2, (0.9, 0.999), 1e-8, 0.01)
+    optz.step()
+    assert all(torch.isnan(d.data).all() for d in pd_)                     # released: nothing but the owned slices survives the update
+optz.gather(); optz.gather()                                               # (idempotent)
+for c, d in zip(pc, pd_):
+    assert torch.equal(c.data, d.data), (rank, "final")
 # with clipping the two paths differ only by the rounding of the norm
 for a, b in zip(pa, pb):
     a.grad, b.grad = torch.ones_like(a) * (rank + 1), torch.ones_like(b) * (rank + 1)
@@ -195,7 +218,8 @@ open(os.path.join({out!r}, "grad%d.ok" % rank), "w").write("ok")
 
 def test_gradient_exchange_world_size_2_gloo(tmp_path):
     """The training step's collectives on gloo with two ranks: the flattened all-reduce of replicated parameters (shape-stable when a rank
-    has no gradient at all), and the reduce-scatter + sharded AdamW + all-gather path, which must reproduce the all-reduce path bit for bit."""
+    has no gradient at all), the reduce-scatter + sharded AdamW + all-gather path, and its ZeRO-3 form (partition_params: masters owned by slice,
+    all-gather in front of the forward) -- each must reproduce the all-reduce path bit for bit."""
     script = tmp_path / "gworker.py"
     script.write_text(_GRAD_WORKER.format(root=ROOT, out=str(tmp_path)))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",

@@ -264,8 +264,10 @@ unet = train.TrainableUNet(ucfg, usd, DEV)
 dec = train.FrozenVAEDecoder(vcfg, vsd, DEV)
 proj = (proj_w.to(DEV).requires_grad_(True), proj_b.to(DEV).requires_grad_(True))
 params = unet.parameters() + list(proj)
-opt = train.ShardedAdamW(params, lr=1e-4, weight_decay=0.01)            # before the capture: the parameters move into its flat buffer
+PART = os.environ.get("LDIFF_TEST_PARTITION") == "1"                   # ZeRO-3 ownership: masters owned by slice, all-gather in front of every forward
+opt = train.ShardedAdamW(params, lr=1e-4, weight_decay=0.01, partition_params=PART, poison_released=PART)   # before the capture: the parameters move into its flat buffer
 assert opt.world == 2 and opt.m.numel() == (sum(p.numel() for p in params) + 1) // 2
+assert (opt.master is not None and opt.master.numel() == opt.m.numel()) if PART else opt.master is None
 gstep = train.GraphedStep(unet, dec, proj, z0.shape[0], ts, sch.alphas_cumprod, latent_hw=8, text_len=hidden.shape[1], text_dim=hidden.shape[2],
                           max_triples=32, num_negatives=64)
 zr = (z0 * (1.0 + 0.3 * rank)).to(DEV)                                   # every rank its own batch
@@ -280,6 +282,9 @@ for it in range(3):
 torch.cuda.synchronize()
 assert kinds == (["graph", "eager", "graph"] if rank == 1 else ["graph"] * 3), (rank, kinds)
 assert opt.step_count == 3 and all(l == l for l in losses)
+if PART:
+    assert torch.isnan(opt.flat).all()                                   # released and poisoned after the last update: only the owned slices persist
+    opt.gather()
 assert all(not torch.equal(p.detach(), b) for p, b in zip(params[:4], before))
 flat = opt.flat.detach().to("cpu")
 other = [torch.empty_like(flat) for _ in range(2)]
@@ -293,12 +298,16 @@ open(os.path.join({out!r}, "train%d.ok" % rank), "w").write(repr(losses))
 
 
 @pytest.mark.timeout(900)
-def test_graphed_step_and_sharded_adamw_on_two_ranks(tmp_path):
+@pytest.mark.parametrize("partition", [False, True])
+def test_graphed_step_and_sharded_adamw_on_two_ranks(tmp_path, partition):
     """BASELINE configs[4]'s step on TWO ranks: GraphedStep (forward + loss + backward replayed from one HIP graph) + ShardedAdamW (reduce-scatter of
     the flat gradient bucket, AdamW on the rank's half with half of the moments, all-gather of the parameters) per rank, every rank its own
     batch, one rank with an all-background batch in the middle (it steps eagerly with zero gradients and must meet the same collectives).  Both
     ranks share the box's one GPU over gloo (CUDA tensors; probed: profiles/r04_gloo_cuda_probe.txt) -- on a node the same code runs over RCCL.
-    Asserted: no hang, three optimizer steps everywhere, bit-identical parameters on both ranks afterwards."""
+    Asserted: no hang, three optimizer steps everywhere, bit-identical parameters on both ranks afterwards.
+    partition = True: the ZeRO-3 form the reference's DeepSpeed config asks for (ldiffusion.py:165-193, stage 3) -- each rank owns its half of the float32
+    masters, the full parameters are all-gathered in front of every forward (graph replay and eager step alike), and the buffer is poisoned with NaN after
+    every update: a forward that read un-gathered parameters would produce a NaN loss."""
     import os, socket, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     with socket.socket() as sk:
@@ -307,7 +316,8 @@ def test_graphed_step_and_sharded_adamw_on_two_ranks(tmp_path):
     script = tmp_path / "two_rank_worker.py"
     script.write_text(_TWO_RANK_WORKER.format(root=root, out=str(tmp_path)))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)]
-    env = dict(os.environ, OMP_NUM_THREADS="4", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    env = dict(os.environ, OMP_NUM_THREADS="4", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"),
+               LDIFF_TEST_PARTITION="1" if partition else "0")
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=800, env=env)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert (tmp_path / "train0.ok").exists() and (tmp_path / "train1.ok").exists(), r.stdout[-2000:] + r.stderr[-2000:]

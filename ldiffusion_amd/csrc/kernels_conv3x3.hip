@@ -321,6 +321,22 @@ __device__ __forceinline__ void lds_wait(f16x8& a, f16x8& b, f16x8& c, f16x8& d,
 // of the LDS-active cycles).  The position is an XOR of the chunk index, so k-half 1 is still byte address ^ 64.
 __device__ __forceinline__ int swzx(int hx) { return (0xcb5888 >> (3 * (hx >> 1))) & 7; }
 
+#ifdef C3W_STAMPS   // diagnostic build only (scripts/build_c3w_stamps.sh, scripts/conv_stamps_w.py): where a (slab, tap) step of wave 0 of workgroup 0 goes
+__device__ unsigned long long c3w_dbg[16];
+__device__ __forceinline__ unsigned long long w_stamp() {
+  __builtin_amdgcn_sched_barrier(0);
+  unsigned long long t = __builtin_amdgcn_s_memtime();
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+  return t;
+}
+#define WSTAMP(v) const unsigned long long v = w_stamp()
+#define WACC(i, expr) wdbg[i] += (expr)
+#else
+#define WSTAMP(v)
+#define WACC(i, expr)
+#endif
+
 template <int BN, bool GN>
 __global__ __launch_bounds__(256, BN > 128 ? 1 : 2) void conv3x3w_kernel(const ConvParams p) {
   constexpr int TH = 8, TW = 16, BM = 128, HWD = 18, HP = 180, MT = 4, NT = BN / 32, A_IT = 6, NP = BN / 32;
@@ -359,6 +375,10 @@ __global__ __launch_bounds__(256, BN > 128 ? 1 : 2) void conv3x3w_kernel(const C
   const int sh = par ? 0 : p.ups;
   const int He = p.Hin << sh, We = p.Win << sh;
   const unsigned lds0 = (unsigned)(size_t)(lptr_t*)smem_raw;
+#ifdef C3W_STAMPS
+  unsigned long long wdbg[16] = {0};
+  WSTAMP(w_t0);
+#endif
 
   // ---- halo staging: thread owns chunk column kc of halo pixels hp = tid/8 + 32*i ----
   const int kc = tid & 7;
@@ -491,6 +511,7 @@ __global__ __launch_bounds__(256, BN > 128 ? 1 : 2) void conv3x3w_kernel(const C
         constexpr int NE = GN && STAGE && C0 < C1 ? (C1 - C0) * 4 : 0, EPG = (NE + NT - 1) / NT;   // NE element PAIRS (dwords), EPG per MFMA group
         unsigned pk[NE > 0 ? NE : 1];         // normalised elements, packed f16 pairs
         f16x8 wf[2][NT], xf[2][MT];
+        WSTAMP(s0);
         // k-half 0 up front; the k-half-1 reads go out between the first MFMA groups (an LDS instruction issues while the matrix pipe
         // works: all sixteen in front of the first MFMA cost ~100 cycles of every step)
         static_for<0, MT>([&](auto mc) { constexpr int m = decltype(mc)::value; lds_read128<(m + kyi) * ROWB>(xf[0][m], xc[kxi]); });
@@ -501,6 +522,7 @@ __global__ __launch_bounds__(256, BN > 128 ? 1 : 2) void conv3x3w_kernel(const C
         else if (stage) issue_w((c + 1) * 128, sp ^ (unsigned)(NTAPS & 1));
         if (T == 0 && stage) load_halo(c + 1);
         __builtin_amdgcn_sched_barrier(0);
+        WSTAMP(s1);   // (the stamp drains the LDS queue: the first MFMA group no longer waits for its operands inside the next segment)
         static_for<0, 2 * NT>([&](auto ic) {
           constexpr int kk = decltype(ic)::value / NT, a = decltype(ic)::value % NT;
           constexpr int WI = NT > 1 ? 1 : 0;   // the k-half-1 X reads follow group 0 of k-half 0, the W reads group WI
@@ -525,7 +547,10 @@ __global__ __launch_bounds__(256, BN > 128 ? 1 : 2) void conv3x3w_kernel(const C
           if constexpr (GN) v = make_uint4(pk[(i - C0) * 4], pk[(i - C0) * 4 + 1], pk[(i - C0) * 4 + 2], pk[(i - C0) * 4 + 3]);
           mask_store(ic, v, (unsigned)(HP * 128) - hbuf);
         });
+        WSTAMP(s2);
         __syncthreads();   // drains this step's weight DMA (vmcnt(0)) and publishes it
+        WSTAMP(s3);
+        WACC(1, s1 - s0); WACC(2, s2 - s1); WACC(3, s3 - s2); WACC(4, 1);
       });
       sp ^= (unsigned)(NTAPS & 1);
     };
@@ -534,6 +559,10 @@ __global__ __launch_bounds__(256, BN > 128 ? 1 : 2) void conv3x3w_kernel(const C
   };
   if (GN && silu) { if (par) run(std::true_type{}, std::true_type{}); else run(std::false_type{}, std::true_type{}); }
   else { if (par) run(std::true_type{}, std::false_type{}); else run(std::false_type{}, std::false_type{}); }
+#ifdef C3W_STAMPS
+  { WSTAMP(w_t1); wdbg[0] = w_t1 - w_t0; }   // kernel start -> end of the main loop (set-up and the first halo / weight round trip included; the epilogue is not)
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) for (int i = 0; i < 8; ++i) c3w_dbg[i] = wdbg[i];
+#endif
 
   if (S > 1) {   // raw fp32 partial sums; bias / time embedding / residual are applied by splitk_reduce_kernel
     const int ncol_s = n0 + wave_n * (BN / 2) + g * 4;
@@ -980,3 +1009,9 @@ void launch_conv3x3(const ConvParams& p, hipStream_t s) {
     else launch_c3_gn<8, 8, 128>(p, s);
   }
 }
+
+#ifdef C3W_STAMPS
+extern "C" int ldiff_debug_c3w_stamps(unsigned long long* out) {   // diagnostic build only
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(c3w_dbg), sizeof(unsigned long long) * 16);
+}
+#endif

@@ -341,8 +341,19 @@ template <int BN, bool GN>
 __global__ __launch_bounds__(256, BN > 128 ? 1 : 2) void conv3x3w_kernel(const ConvParams p) {
   constexpr int TH = 8, TW = 16, BM = 128, HWD = 18, HP = 180, MT = 4, NT = BN / 32, A_IT = 6, NP = BN / 32;
   constexpr int ROWB = HWD * 128;                                  // bytes per halo row
-  constexpr unsigned W_OFF = 2 * HP * 128, W_BYTES = BN * 128;     // LDS map: halo[2] | weights[2] | dump
-  constexpr unsigned DUMP = W_OFF + 2 * W_BYTES;                   // 96 lanes x 16 B: stores of lanes beyond the halo
+  // R3 (round 6; the 160-column kernel, which runs ONE workgroup per CU: nothing else covers a wave's issue time): THREE weight slots, the slice of step
+  // s + 2 fetched during step s, its DMA pieces issued BETWEEN the step's first MFMA groups instead of in front of them, and a counted vmcnt at the
+  // step's barrier that leaves those pieces in flight.  In-kernel stamps (scripts/conv_stamps_w.py, profiles/r06_conv3x3w_stamps.txt): a step of wave 0 was
+  // 28 % issue (mostly the five LDS-DMA pieces, 60+ cycles each), 67 % MFMA groups, 5 % barrier.  Nine taps per slab = a multiple of three: the slot of tap T
+  // is T % 3 whatever the slab.  (Parity mode, four taps, keeps the two-slot scheme.)
+#ifdef C3W_RING2   // (A/B build: the two-slot scheme everywhere)
+  constexpr bool R3 = false;
+#else
+  constexpr bool R3 = BN == 160;
+#endif
+  constexpr int NSLOT = R3 ? 3 : 2;
+  constexpr unsigned W_OFF = 2 * HP * 128, W_BYTES = BN * 128;     // LDS map: halo[2] | weights[NSLOT] | dump
+  constexpr unsigned DUMP = W_OFF + NSLOT * W_BYTES;               // 96 lanes x 16 B: stores of lanes beyond the halo
   constexpr int NF = NT + MT;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
 
@@ -445,6 +456,13 @@ __global__ __launch_bounds__(256, BN > 128 ? 1 : 2) void conv3x3w_kernel(const C
     n = n < p.Nrows ? n : p.Nrows - 1;   // rows beyond the matrix are never stored; keep the address in range
     w_voff[i] = (int)(((long long)n * Kw + swz8(r, pos) * 8) * 2) - (i & 3) * 1024;
   }
+  auto issue_w_piece = [&](auto ic, int soff, unsigned slot) {   // one 1-KiB piece of the slice (R3: issued between MFMA groups)
+    constexpr int i = decltype(ic)::value;
+    unsigned char* dst = smem_raw + W_OFF + slot * W_BYTES + wave * (BN * 32);
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (lptr_t*)(dst + (i >> 2) * 4096), 16, w_voff[i], soff, (i & 3) * 1024, 0);
+#endif
+  };
   auto issue_w = [&](int soff, unsigned slot) {   // soff: byte offset of (tap, slab) inside a weight row
     unsigned char* dst = smem_raw + W_OFF + slot * W_BYTES + wave * (BN * 32);
     static_for<0, NP>([&](auto ic) {
@@ -472,6 +490,7 @@ __global__ __launch_bounds__(256, BN > 128 ? 1 : 2) void conv3x3w_kernel(const C
   const unsigned w_lane = lds0 + W_OFF + (unsigned)(wrow * 128 + ((g ^ ((wrow >> 1) & 7)) << 4));
 
   issue_w(c_begin * 128, 0);
+  if (R3 && !par) issue_w((Cin + c_begin * 64) * 2, 1);   // three slots: step 1's slice too (a slab always has nine steps)
   static_for<0, A_IT>([&](auto ic) { xform_store(ic, 0u); });
   __syncthreads();
 
@@ -502,6 +521,7 @@ __global__ __launch_bounds__(256, BN > 128 ? 1 : 2) void conv3x3w_kernel(const C
       for (int j = 0; j < 3; ++j) { xc[j] = xb[j] + hbuf; xc1[j] = xc[j] ^ 64u; }   // chunk bit 2 = k-half: XOR commutes with the swizzle
       wc[0] = w_lane + sp * W_BYTES; wc[1] = w_lane + (sp ^ 1u) * W_BYTES;
       wc1[0] = wc[0] ^ 64u; wc1[1] = wc[1] ^ 64u;
+      constexpr bool RING3 = R3 && !PAR;
       static_for<0, NTAPS>([&](auto tc) {
         constexpr int T = decltype(tc)::value;
         constexpr int kyi = PAR ? (T >> 1) : T / 3, kxi = PAR ? (T & 1) : T % 3;
@@ -514,12 +534,19 @@ __global__ __launch_bounds__(256, BN > 128 ? 1 : 2) void conv3x3w_kernel(const C
         WSTAMP(s0);
         // k-half 0 up front; the k-half-1 reads go out between the first MFMA groups (an LDS instruction issues while the matrix pipe
         // works: all sixteen in front of the first MFMA cost ~100 cycles of every step)
+        // RING3: slot T % 3 (static); the slice of step + 2 goes out piece by piece between the first MFMA groups below
+        const unsigned wcur = RING3 ? w_lane + (unsigned)(T % 3) * W_BYTES : wc[T & 1], wcur1 = wcur ^ 64u;
+        constexpr int T2 = T + 2;                                  // the step whose slice is fetched during this one (RING3)
+        constexpr bool DMA_NOW = RING3 && (T2 < NTAPS || STAGE);   // ... if it exists: the same slab's tap T2, or tap T2 - 9 of the next slab
+        const int soff2 = T2 < NTAPS ? (T2 * Cin + c * 64) * 2 : ((T2 - NTAPS) * Cin + (c + 1) * 64) * 2;
         static_for<0, MT>([&](auto mc) { constexpr int m = decltype(mc)::value; lds_read128<(m + kyi) * ROWB>(xf[0][m], xc[kxi]); });
-        static_for<0, NT>([&](auto ac) { constexpr int a = decltype(ac)::value; lds_read128<a * 2048>(wf[0][a], wc[T & 1]); });
+        static_for<0, NT>([&](auto ac) { constexpr int a = decltype(ac)::value; lds_read128<a * 2048>(wf[0][a], wcur); });
         __builtin_amdgcn_sched_barrier(0);
         // next step's weight slice -> the other slot (read last in the previous step); issued while the operand reads fly
-        if (!LAST) issue_w(((T + 1) * Cin + c * 64) * 2, sp ^ (unsigned)((T + 1) & 1));
-        else if (stage) issue_w((c + 1) * 128, sp ^ (unsigned)(NTAPS & 1));
+        if constexpr (!RING3) {
+          if (!LAST) issue_w(((T + 1) * Cin + c * 64) * 2, sp ^ (unsigned)((T + 1) & 1));
+          else if (stage) issue_w((c + 1) * 128, sp ^ (unsigned)(NTAPS & 1));
+        }
         if (T == 0 && stage) load_halo(c + 1);
         __builtin_amdgcn_sched_barrier(0);
         WSTAMP(s1);   // (the stamp drains the LDS queue: the first MFMA group no longer waits for its operands inside the next segment)
@@ -534,7 +561,8 @@ __global__ __launch_bounds__(256, BN > 128 ? 1 : 2) void conv3x3w_kernel(const C
           for (int m = 0; m < MT; ++m)
             acc[a][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[kk][a], xf[kk][m], acc[a][m], 0, 0, 0);
           if constexpr (kk == 0 && a == 0) static_for<0, MT>([&](auto mc) { constexpr int m = decltype(mc)::value; lds_read128<(m + kyi) * ROWB>(xf[1][m], xc1[kxi]); });
-          if constexpr (kk == 0 && a == WI) static_for<0, NT>([&](auto bc) { constexpr int b2 = decltype(bc)::value; lds_read128<b2 * 2048>(wf[1][b2], wc1[T & 1]); });
+          if constexpr (kk == 0 && a == WI) static_for<0, NT>([&](auto bc) { constexpr int b2 = decltype(bc)::value; lds_read128<b2 * 2048>(wf[1][b2], wcur1); });
+          if constexpr (DMA_NOW && kk == 0 && a < NP) issue_w_piece(std::integral_constant<int, a>{}, soff2, (unsigned)(T2 % 3));   // (NP == NT: one piece behind each k-half-0 group)
           static_for<(kk == 1 ? a * EPG : NE), (kk == 1 ? ((a + 1) * EPG < NE ? (a + 1) * EPG : NE) : NE)>([&](auto ec) {
             constexpr int e = decltype(ec)::value;
             pk[e] = xform_pair(std::integral_constant<int, C0 + e / 4>{}, std::integral_constant<int, e % 4>{}, siluc);
@@ -548,7 +576,13 @@ __global__ __launch_bounds__(256, BN > 128 ? 1 : 2) void conv3x3w_kernel(const C
           mask_store(ic, v, (unsigned)(HP * 128) - hbuf);
         });
         WSTAMP(s2);
-        __syncthreads();   // drains this step's weight DMA (vmcnt(0)) and publishes it
+        if constexpr (RING3) {
+          // the slice the NEXT step reads was issued a step ago: everything older than this step's NP pieces must have landed (the halo loads of tap 0,
+          // issued in front of them, included); the staged halo chunk's LDS stores must be out before the barrier publishes them
+          if constexpr (DMA_NOW) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NP) : "memory");
+          else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+          __builtin_amdgcn_s_barrier();
+        } else __syncthreads();   // drains this step's weight DMA (vmcnt(0)) and publishes it
         WSTAMP(s3);
         WACC(1, s1 - s0); WACC(2, s2 - s1); WACC(3, s3 - s2); WACC(4, 1);
       });
@@ -881,7 +915,7 @@ void launch_c3(const ConvParams& p, hipStream_t s) {
 template <int BN, bool GN>
 void launch_c3w(const ConvParams& p, hipStream_t s) {
   constexpr int TH = 8, TW = 16, HP = 180;
-  const size_t smem = (size_t)2 * HP * 128 + 2 * BN * 128 + 1536;
+  const size_t smem = (size_t)2 * HP * 128 + (BN == 160 ? 3 : 2) * BN * 128 + 1536;   // (the 160-column kernel's weight ring has three slots)
   auto kern = conv3x3w_kernel<BN, GN>;
   ensure_dyn_smem(reinterpret_cast<const void*>(kern), (int)smem);
   const bool par = p.w_par != nullptr;

@@ -3,7 +3,9 @@
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from ldiffusion_amd import configs, weights
+from ldiffusion_amd import configs, weights, _lib
+if os.environ.get("LDIFF_LIB"):   # an A/B build of the library (diagnostic)
+    _lib.LIB_PATH = os.path.abspath(os.environ["LDIFF_LIB"])
 from ldiffusion_amd.models import UNet2DConditionModel
 ucfg = configs.SD15_UNET
 unet = UNet2DConditionModel(ucfg, weights.synthetic_state_dict(weights.unet_param_shapes(ucfg), 42, fp16_values=True), "cuda:0")

@@ -322,7 +322,7 @@ __device__ __forceinline__ void lds_wait(f16x8& a, f16x8& b, f16x8& c, f16x8& d,
 __device__ __forceinline__ int swzx(int hx) { return (0xcb5888 >> (3 * (hx >> 1))) & 7; }
 
 #ifdef C3W_STAMPS   // diagnostic build only (scripts/build_c3w_stamps.sh, scripts/conv_stamps_w.py): where a (slab, tap) step of wave 0 of workgroup 0 goes
-__device__ unsigned long long c3w_dbg[16];
+__device__ unsigned long long c3w_dbg[32];   // [0..4] totals, [8 + T] MFMA segment of tap T, [20 + T] issue segment of tap T
 __device__ __forceinline__ unsigned long long w_stamp() {
   __builtin_amdgcn_sched_barrier(0);
   unsigned long long t = __builtin_amdgcn_s_memtime();
@@ -387,7 +387,7 @@ __global__ __launch_bounds__(256, BN > 128 ? 1 : 2) void conv3x3w_kernel(const C
   const int He = p.Hin << sh, We = p.Win << sh;
   const unsigned lds0 = (unsigned)(size_t)(lptr_t*)smem_raw;
 #ifdef C3W_STAMPS
-  unsigned long long wdbg[16] = {0};
+  unsigned long long wdbg[32] = {0};
   WSTAMP(w_t0);
 #endif
 
@@ -584,7 +584,7 @@ __global__ __launch_bounds__(256, BN > 128 ? 1 : 2) void conv3x3w_kernel(const C
           __builtin_amdgcn_s_barrier();
         } else __syncthreads();   // drains this step's weight DMA (vmcnt(0)) and publishes it
         WSTAMP(s3);
-        WACC(1, s1 - s0); WACC(2, s2 - s1); WACC(3, s3 - s2); WACC(4, 1);
+        WACC(1, s1 - s0); WACC(2, s2 - s1); WACC(3, s3 - s2); WACC(4, 1); WACC(8 + T, s2 - s1); WACC(20 + T, s1 - s0);
       });
       sp ^= (unsigned)(NTAPS & 1);
     };
@@ -595,7 +595,7 @@ __global__ __launch_bounds__(256, BN > 128 ? 1 : 2) void conv3x3w_kernel(const C
   else { if (par) run(std::true_type{}, std::false_type{}); else run(std::false_type{}, std::false_type{}); }
 #ifdef C3W_STAMPS
   { WSTAMP(w_t1); wdbg[0] = w_t1 - w_t0; }   // kernel start -> end of the main loop (set-up and the first halo / weight round trip included; the epilogue is not)
-  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) for (int i = 0; i < 8; ++i) c3w_dbg[i] = wdbg[i];
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) for (int i = 0; i < 32; ++i) c3w_dbg[i] = wdbg[i];
 #endif
 
   if (S > 1) {   // raw fp32 partial sums; bias / time embedding / residual are applied by splitk_reduce_kernel
@@ -1046,6 +1046,6 @@ void launch_conv3x3(const ConvParams& p, hipStream_t s) {
 
 #ifdef C3W_STAMPS
 extern "C" int ldiff_debug_c3w_stamps(unsigned long long* out) {   // diagnostic build only
-  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(c3w_dbg), sizeof(unsigned long long) * 16);
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(c3w_dbg), sizeof(unsigned long long) * 32);
 }
 #endif

@@ -46,11 +46,12 @@ for name, (B, C1, C2, H, Cout) in SHAPES.items():
     e1.record()
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) * 100.0
-    buf = (C.c_ulonglong * 16)()
+    buf = (C.c_ulonglong * 32)()
     assert raw.ldiff_debug_c3w_stamps(buf) == 0
     d = list(buf)
     steps = max(d[4], 1)
     loop = d[1] + d[2] + d[3]
     print(f"{name}: {us:.1f} us per launch ({2e-6 * B * H * H * Cout * 9 * Cin / us:.0f} TFLOP/s); workgroup 0, wave 0: {steps} steps, start -> end of the loop {d[0]} ticks;\n"
           f"    per step: issue {d[1] / steps:.0f}  mfma + transform {d[2] / steps:.0f}  barrier (waits for the weight DMA) {d[3] / steps:.0f}  ticks "
-          f"= {100 * d[1] / loop:.0f} % / {100 * d[2] / loop:.0f} % / {100 * d[3] / loop:.0f} %; loop {100 * loop / max(d[0], 1):.0f} % of start -> end of loop", flush=True)
+          f"= {100 * d[1] / loop:.0f} % / {100 * d[2] / loop:.0f} % / {100 * d[3] / loop:.0f} %; loop {100 * loop / max(d[0], 1):.0f} % of start -> end of loop\n"
+          f"    per tap (x {steps // 9} slabs), MFMA segment: {[round(9 * v / steps) for v in d[8:17]]}  issue segment: {[round(9 * v / steps) for v in d[20:29]]}", flush=True)

@@ -591,6 +591,10 @@ FUSED_STATS_CASES = {
     "conv3x3_8x8_split4": (3, 256, 8, 8, 128, 3, 1, 4),
     "conv3x3_8x8_split16_of_20_slabs": (1, 1280, 8, 8, 128, 3, 1, 16),
     "conv3x3_16x16_split2_320": (2, 128, 16, 16, 320, 3, 1, 2),
+    # the 160-column kernel's three-slot weight ring: K ranges that start at a later slab and run over more than one (the next slab's first two slices
+    # are fetched during the last two taps of the current one)
+    "conv3x3_16x16_split2_320_two_slabs_each": (1, 256, 16, 16, 320, 3, 1, 2),
+    "conv3x3_32x32_split3_320_of_7_slabs": (1, 448, 32, 32, 320, 3, 1, 3),
     "gemm_dma_1x1_split3": (2, 512, 16, 16, 256, 1, 1, 3),
     "gemm_dma_1x1_split9_tail_rows": (1, 1280, 8, 8, 320, 1, 1, 9),
     "igemm_stride2_split2": (2, 64, 32, 32, 64, 3, 2, 2),

@@ -12,6 +12,8 @@ unet = UNet2DConditionModel(ucfg, weights.synthetic_state_dict(weights.unet_para
 B = int(os.environ.get("LDIFF_UNET_B", "8"))   # batch (default 8; 1 = the reference's own batch)
 lat = torch.randn((B, 4, 64, 64), device="cuda:0")
 ctx = torch.randn((1, 6, 768), device="cuda:0") * 0.5
+if os.environ.get("LDIFF_UNET_EAGER"):   # eager launches instead of hipGraph replay (diagnostic)
+    unet.set_graph(False)
 for _ in range(3):
     unet(lat, 501, ctx)
 torch.cuda.synchronize()

@@ -13,6 +13,7 @@
 typedef _Float16 f16;
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __attribute__((address_space(3))) void lptr_t;
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
 
@@ -34,6 +35,10 @@ template <int CNT>
 __device__ __forceinline__ void lds_wait4(f16x8& a, f16x8& b, f16x8& c, f16x8& d) {
   asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(CNT));
 }
+template <int CNT>
+__device__ __forceinline__ void vm_wait1(f16x8& a) { asm volatile("s_waitcnt vmcnt(%1)" : "+v"(a) : "n"(CNT)); }
+template <int OFF>
+__device__ __forceinline__ void gload128(f16x8& d, const char* q) { asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(d) : "v"(q), "n"(OFF) : "memory"); }
 __device__ __forceinline__ int swzx(int hx) { return (0xcb5888 >> (3 * (hx >> 1))) & 7; }
 __device__ __forceinline__ float silu_f(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v * -1.4426950408889634f)); }
 
@@ -45,7 +50,7 @@ constexpr unsigned W_OFF = 2 * HB, DUMP = W_OFF + NSLOT * WSLOT, LDS_BYTES = DUM
 // ORDER: 0 = dependent pairs (k-half 0 and 1 of an accumulator back to back), 1 = k-half 0 of the 8 accumulators of a channel tile pair, then k-half 1
 // PRIO: s_setprio level of the consumer waves; XF: 0 = compiler-scheduled GroupNorm+SiLU, 1 = v_fma_mix form (6 instructions per element),
 // 2 = same instruction count without transcendentals; PACE: producers follow the consumers' step counter (LDS word) instead of free-running
-template <int PROD, int ORDER, int PRIO, int XF, int PACE, int WG = 0>
+template <int PROD, int ORDER, int PRIO, int XF, int PACE, int WG = 0, int MF = 0>
 __global__ __launch_bounds__(512, 2) void conv_consumer_kernel(int tiles, int nslab, const f16* wsrc, float* sink, unsigned long long* prod_done) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -134,6 +139,97 @@ __global__ __launch_bounds__(512, 2) void conv_consumer_kernel(int tiles, int ns
   }
   // ---- consumer ----
   if (PRIO > 0) __builtin_amdgcn_s_setprio(PRIO);
+  if constexpr (MF == 1) {
+    // ---- the same tile with v_mfma_f32_32x32x16_f16 (round 6 probe): per wave 4 pixel tiles (row pairs: 32 pixels) x 2 channel tiles (32 channels) = 8 accumulators
+    // of 16 registers; a step = 4 k-steps of 16 channels: the same 16 pixel reads + 8 weight loads as the 16x16x32 form, but 32 MFMAs of 8 passes instead of 64 of 4 ----
+    const int wave_m = wave >> 1, wave_n = wave & 1;
+    const int half = lane >> 5, r = (lane >> 4) & 1, l15 = lane & 15;
+    unsigned xb[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int hx = l15 + j;
+      xb[j] = lds0 + (unsigned)(((wave_m * 8 + r) * HWD + hx) * 128 + ((half ^ swzx(hx)) << 4));
+    }
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[a][m][e] = 0.f;
+    f16x8 W[4][2], X[2][4];   // W[k-step][channel tile]; X[buffer][k-step]
+    auto issue_x = [&](auto pc, auto kyc, auto kxc, unsigned hb, f16x8 (&dst)[4]) {
+      constexpr int p = decltype(pc)::value, ky = decltype(kyc)::value, kx = decltype(kxc)::value;
+      const unsigned b0 = xb[kx] + hb;
+      lds_read128<(2 * p + ky) * ROWB>(dst[0], b0);
+      lds_read128<(2 * p + ky) * ROWB>(dst[1], b0 ^ 32u);
+      lds_read128<(2 * p + ky) * ROWB>(dst[2], b0 ^ 64u);
+      lds_read128<(2 * p + ky) * ROWB>(dst[3], b0 ^ 96u);
+    };
+    const char* wg_base = reinterpret_cast<const char*>(wsrc) + wave_n * 8192 + lane * 16;
+    long long wg_step = 0;
+    auto issue_w = [&](auto nc) {   // load n = 2 j + a of the NEXT step, in the order of use
+      constexpr int n = decltype(nc)::value;
+      const char* q = wg_base + ((wg_step + 1) % 18) * 16384;
+      gload128<(n & 3) * 1024>(W[n >> 1][n & 1], q + (n >> 2) * 4096);
+    };
+    auto group = [&](auto pc, f16x8 (&x)[4], auto first) {   // the 8 MFMAs of a pixel tile; first: the step's weight loads are still landing
+      constexpr int p = decltype(pc)::value;
+      static_for<0, 8>([&](auto nc) {
+        constexpr int n = decltype(nc)::value, j = n >> 1, a = n & 1;
+        if constexpr (decltype(first)::value) vm_wait1<7 - n>(W[j][a]);
+        acc[a][p] = __builtin_amdgcn_mfma_f32_32x32x16_f16(W[j][a], x[j], acc[a][p], 0, 0, 0);
+      });
+    };
+    --wg_step;
+    static_for<0, 8>([&](auto nc) { issue_w(nc); });   // the first step's weights
+    ++wg_step;
+    issue_x(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, 0u, X[0]);
+    const int nsl = tiles * nslab;
+    for (int c = 0; c < nsl; ++c) {
+      const unsigned hb = (unsigned)(c & 1) * HB;
+      static_for<0, 9>([&](auto tc) {
+        constexpr int T = decltype(tc)::value, ky = T / 3, kx = T % 3;
+        constexpr int nky = (T + 1) % 9 / 3, nkx = (T + 1) % 3;
+        const unsigned hb_next = T == 8 ? HB - hb : hb;
+        issue_x(std::integral_constant<int, 1>{}, std::integral_constant<int, ky>{}, std::integral_constant<int, kx>{}, hb, X[1]);
+        lds_wait4<4>(X[0][0], X[0][1], X[0][2], X[0][3]);
+        group(std::integral_constant<int, 0>{}, X[0], std::true_type{});
+        __builtin_amdgcn_sched_barrier(0);
+        issue_x(std::integral_constant<int, 2>{}, std::integral_constant<int, ky>{}, std::integral_constant<int, kx>{}, hb, X[0]);
+        lds_wait4<4>(X[1][0], X[1][1], X[1][2], X[1][3]);
+        group(std::integral_constant<int, 1>{}, X[1], std::false_type{});
+        __builtin_amdgcn_sched_barrier(0);
+        issue_x(std::integral_constant<int, 3>{}, std::integral_constant<int, ky>{}, std::integral_constant<int, kx>{}, hb, X[1]);
+        lds_wait4<4>(X[0][0], X[0][1], X[0][2], X[0][3]);
+        group(std::integral_constant<int, 2>{}, X[0], std::false_type{});
+        __builtin_amdgcn_sched_barrier(0);
+        issue_x(std::integral_constant<int, 0>{}, std::integral_constant<int, nky>{}, std::integral_constant<int, nkx>{}, hb_next, X[0]);
+        lds_wait4<4>(X[1][0], X[1][1], X[1][2], X[1][3]);
+        // last pixel tile: the next step's weights go out behind the MFMA that last used their registers
+        static_for<0, 8>([&](auto nc) {
+          constexpr int n = decltype(nc)::value, j = n >> 1, a = n & 1;
+          acc[a][3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(W[j][a], X[1][j], acc[a][3], 0, 0, 0);
+          issue_w(nc);
+          __builtin_amdgcn_sched_barrier(0);
+        });
+        ++wg_step;
+        if (PACE && wave == 0 && lane == 0) *reinterpret_cast<volatile unsigned*>(smem + FLAG) = (unsigned)(c * 9 + T + 1);
+      });
+    }
+    const unsigned long long t1 = __builtin_readcyclecounter();
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    float sm = 0.f;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) sm += acc[a][m][e];
+    if (sm == 12345.678f) sink[0] = sm + (float)X[0][0][0] + (float)W[0][0][0];
+    if (lane == 0 && blockIdx.x == 0) prod_done[4 + wave] = t1 - tstart;
+    return;
+  }
   const int wave_m = wave >> 1, wave_n = wave & 1;
   const int g = lane >> 4, l15 = lane & 15;
   unsigned xb[3];
@@ -253,9 +349,9 @@ __global__ __launch_bounds__(512, 2) void conv_consumer_kernel(int tiles, int ns
   if (lane == 0 && blockIdx.x == 0) prod_done[4 + wave] = t1 - t0;
 }
 
-template <int PROD, int ORDER, int PRIO = 0, int XF = 0, int PACE = 0, int WG = 0>
+template <int PROD, int ORDER, int PRIO = 0, int XF = 0, int PACE = 0, int WG = 0, int MF = 0>
 void run(int tiles, int nslab, const f16* w, float* sink, unsigned long long* pd, int cus) {
-  auto k = conv_consumer_kernel<PROD, ORDER, PRIO, XF, PACE, WG>;
+  auto k = conv_consumer_kernel<PROD, ORDER, PRIO, XF, PACE, WG, MF>;
   CK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -274,7 +370,7 @@ void run(int tiles, int nslab, const f16* w, float* sink, unsigned long long* pd
   const double flops = (double)cus * tiles * 2.0 * 256 * 128 * (nslab * 64 * 9);
   unsigned long long h[8];
   CK(hipMemcpy(h, pd, sizeof(h), hipMemcpyDeviceToHost));
-  printf("WG %d PROD %d ORDER %d PRIO %d XF %d PACE %d: best %.3f ms mean %.3f ms  %7.1f TFLOP/s = %.3f of 2500;  wg0 ticks: producers %llu..%llu consumers %llu..%llu\n", WG, PROD, ORDER, PRIO, XF, PACE, best, sum / 5,
+  printf("MF %d WG %d PROD %d ORDER %d PRIO %d XF %d PACE %d: best %.3f ms mean %.3f ms  %7.1f TFLOP/s = %.3f of 2500;  wg0 ticks: producers %llu..%llu consumers %llu..%llu\n", MF, WG, PROD, ORDER, PRIO, XF, PACE, best, sum / 5,
          flops / (best * 1e-3) * 1e-12, flops / (best * 1e-3) * 1e-12 / 2500.0, h[0] < h[3] ? h[0] : h[3], h[0] > h[3] ? h[0] : h[3], h[4] < h[7] ? h[4] : h[7], h[4] > h[7] ? h[4] : h[7]);
   CK(hipEventDestroy(e0)); CK(hipEventDestroy(e1));
 }
@@ -293,6 +389,11 @@ int main() {
     run<1, 0, 0, 1, 1, 0>(32, 2, w, sink, pd, cus);
     run<1, 0, 0, 1, 1, 1>(32, 2, w, sink, pd, cus);
     run<2, 0, 0, 1, 1, 0>(32, 2, w, sink, pd, cus);
+    // round 6: the consumer loop on v_mfma_f32_32x32x16_f16 (same operand traffic, half the MFMA instructions), alone and beside the producers
+    run<0, 0, 0, 0, 0, 1, 1>(32, 2, w, sink, pd, cus);
+    run<1, 0, 0, 1, 1, 1, 1>(32, 2, w, sink, pd, cus);
+    run<1, 0, 0, 1, 0, 1>(32, 2, w, sink, pd, cus);
+    run<1, 0, 0, 1, 0, 1, 1>(32, 2, w, sink, pd, cus);
   }
   return 0;
 }

@@ -93,6 +93,19 @@ def pmc_traffic(kernel_name):
         return None
 
 
+def pmc_unet(batch):
+    """MFMA-busy share and memory-side bytes of a UNet pass at `batch` from the rocprofv3 PMC passes of scripts/pmc_unet_pass.sh on exactly this
+    kernel source (profiles/pmc_unet_<source hash>.json); None when no such profile is committed (same rule as pmc_traffic)."""
+    try:
+        with open(os.path.join(ROOT, "profiles", f"pmc_unet_{kernel_source_hash()}.json")) as f:
+            d = json.load(f)["batches"][str(batch)]
+        return {"mfma_busy": d["mfma_busy"], "memory_side_GBps": d["memory_side_GBps"], "memory_side_bytes": d["memory_side_bytes"],
+                "how": "rocprofv3 --pmc over the pass with eager launches (profiler clocks), SQ_VALU_MFMA_BUSY_CYCLES / SIMD-cycles and 2 x FETCH_SIZE + WRITE_SIZE; "
+                       "the bytes are counted on the memory side of the L2s: Infinity-Cache hits included"}
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def cpu_baseline(ucfg, vcfg, usd, vsd, img, n_passes):
     """The CPU oracle (oracle/, plain-torch fp32 restatement) TIMED end to end on ONE patch of the bench workload: the whole
     n_passes sampler (encode, n x [UNet, PLMS step, decode, uint8, luma]) after a small warm-up of the thread pool."""
@@ -412,14 +425,14 @@ def main():
         result["unet_step"] = {"ms": unet_ms, "batch": PATCHES_PER_GPU,
                                "hbm_GBps": ub / (unet_ms * 1e-3) / 1e9, "hbm_frac": ub / (unet_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                                "tflops": uf / (unet_ms * 1e-3) / 1e12, "mfma_frac": uf / (unet_ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS,
-                               "ms_eager_launches": unet_eager_ms, "launches": unet_nodes.get(PATCHES_PER_GPU),
+                               "ms_eager_launches": unet_eager_ms, "launches": unet_nodes.get(PATCHES_PER_GPU), "pmc": pmc_unet(PATCHES_PER_GPU),
                                "launch": "hipGraph replay (ms) vs the same kernels launched one by one (ms_eager_launches); launches = nodes of the captured graph"}
         for b, (g_ms, e_ms) in unet_small.items():
             bb = UNET_WEIGHT_BYTES + b * UNET_ACT_BYTES_PER_SAMPLE
             result[f"unet_step_b{b}"] = {"ms": g_ms, "batch": b, "hbm_GBps": bb / (g_ms * 1e-3) / 1e9, "hbm_frac": bb / (g_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                                          "tflops": b * UNET_FLOP_PER_SAMPLE / (g_ms * 1e-3) / 1e12,
                                          "mfma_frac": b * UNET_FLOP_PER_SAMPLE / (g_ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS,
-                                         "ms_eager_launches": e_ms, "launches": unet_nodes.get(b),
+                                         "ms_eager_launches": e_ms, "launches": unet_nodes.get(b), "pmc": pmc_unet(b),
                                          "algorithmic_bytes": bb}
     if sample_b1_ms is not None:
         result["sample_b1"] = {"ms_per_patch": sample_b1_ms, "patches_per_sec": 1e3 / sample_b1_ms,
